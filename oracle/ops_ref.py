@@ -1,0 +1,132 @@
+"""CPU oracle (TEST INFRASTRUCTURE ONLY) for the operator surface of the reference's kernel library.
+
+Each function restates, in torch-CPU / numpy, what the reference op of the same name computes:
+  boundary A  get_ops()            vllm_i64/kernels/kernel_loader.py:31-68 (FallbackOps), kernels/i64_ops.py:17-97,
+                                   csrc/i64_ops_binding.cu:32-209, csrc/i64_router.cu:51-165
+  boundary B  get_i64_cuda_ops()   csrc/I64_rmsnorm.cu:41-191, I64_rope.cu:24-104, I64_quantize.cu:40-166,
+                                   I64_softmax.cu:75-159 (with the truncating LUT of layers/moe.py:44-47),
+                                   I64_gemm.cu:40-126
+  integer activations              vllm_i64/layers/integer_activations.py:29-66
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# ---- boundary A ------------------------------------------------------------------------------
+def route_tokens(token_ids: torch.Tensor, num_experts: int) -> torch.Tensor:
+    return (token_ids & (num_experts - 1)).to(torch.int32)
+
+
+def silu_hadamard(gate_up: torch.Tensor, expert_inter: int) -> torch.Tensor:
+    return F.silu(gate_up[:, :expert_inter]) * gate_up[:, expert_inter:]
+
+
+def scatter_by_expert(hidden: torch.Tensor, expert_ids: torch.Tensor, num_experts: int):
+    """Stable grouping by expert: (scattered, scatter_indices, offsets, counts).
+
+    scatter_indices[t] is the row of ``scattered`` that token t went to.  The reference's CUDA kernel
+    assigns slots by atomics (any order inside an expert) and its fallback uses an unstable argsort; the
+    only contract its tests hold is gather(scatter(x)) == x and the per-expert counts
+    (tests/test_i64_pipeline.py:75-96).  This build fixes the order: token order is kept inside an expert.
+    """
+    order = torch.argsort(expert_ids.long(), stable=True)
+    counts = torch.bincount(expert_ids.long(), minlength=num_experts).to(torch.int32)
+    offsets = torch.zeros(num_experts, dtype=torch.int32)
+    offsets[1:] = torch.cumsum(counts, 0)[:-1]
+    where = torch.empty_like(order)
+    where[order] = torch.arange(order.numel())
+    return hidden[order], where.to(torch.int32), offsets, counts
+
+
+def gather_by_expert(expert_out: torch.Tensor, scatter_indices: torch.Tensor) -> torch.Tensor:
+    return expert_out[scatter_indices.long()]
+
+
+# ---- boundary B ------------------------------------------------------------------------------
+def rmsnorm_forward(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    x = x.float()
+    rr = torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps)
+    return x * rr * weight.float()
+
+
+def quantize_int8(x: torch.Tensor):
+    """Per-row symmetric int8: s = max(amax, 1e-8)/127, q = clamp(rint(x / s), -128, 127)."""
+    x = x.float()
+    s = x.abs().amax(-1, keepdim=True).clamp(min=1e-8) / 127.0
+    q = torch.round(x / s).clamp(-128, 127).to(torch.int8)
+    return q, s.squeeze(-1)
+
+
+def dequantize_int8(q: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    return q.float() * scale.float().unsqueeze(-1)
+
+
+def rmsnorm_quant_forward(x, weight, eps):
+    return quantize_int8(rmsnorm_forward(x, weight, eps))
+
+
+def rope_forward(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    d = x.shape[-1] // 2
+    x1, x2 = x[..., :d].float(), x[..., d:].float()
+    c, s = cos[..., :d].unsqueeze(1).float(), sin[..., :d].unsqueeze(1).float()
+    return torch.cat([x1 * c - x2 * s, x2 * c + x1 * s], dim=-1)
+
+
+def rope_integer_forward(x: torch.Tensor, cos_q14: torch.Tensor, sin_q14: torch.Tensor) -> torch.Tensor:
+    d = x.shape[-1] // 2
+    x1 = torch.round(x[..., :d].float() * 128.0).to(torch.int32)
+    x2 = torch.round(x[..., d:].float() * 128.0).to(torch.int32)
+    c = cos_q14[..., :d].unsqueeze(1).to(torch.int32)
+    s = sin_q14[..., :d].unsqueeze(1).to(torch.int32)
+    r1, r2 = x1 * c - x2 * s, x2 * c + x1 * s
+    return torch.cat([r1.float(), r2.float()], dim=-1) / float(128 * 16384)
+
+
+def exp_lut_q16() -> torch.Tensor:
+    """1025-entry table trunc(exp(i/128) * 65536), i in [-1024, 0] (layers/moe.py:44-47)."""
+    idx = torch.arange(-1024, 1, dtype=torch.float32)
+    return (torch.exp(idx / 128.0) * 65536.0).to(torch.int32)
+
+
+def softmax_integer(logits: torch.Tensor) -> torch.Tensor:
+    q = torch.round(logits.float() * 128.0).to(torch.int32)
+    sh = (q - q.max(-1, keepdim=True).values).clamp(min=-1024)
+    e = exp_lut_q16()[(sh + 1024).long()]
+    tot = e.sum(-1, keepdim=True).clamp(min=1)
+    return e.float() / tot.float()
+
+
+def gemm_dequant_int8(x: torch.Tensor, w_q: torch.Tensor, w_scale: torch.Tensor) -> torch.Tensor:
+    return x.float() @ (w_q.float() * w_scale.float().unsqueeze(-1)).t()
+
+
+def gemm_silu_int8(x, gate_q, gate_s, up_q, up_s):
+    g = gemm_dequant_int8(x, gate_q, gate_s)
+    u = gemm_dequant_int8(x, up_q, up_s)
+    return g * torch.sigmoid(g) * u
+
+
+# ---- integer activations (layers/integer_activations.py) --------------------------------------
+def silu_lut_q7() -> torch.Tensor:
+    x = torch.arange(-1024, 1025, dtype=torch.float32) / 128.0
+    return torch.round(F.silu(x) * 128.0).to(torch.int32)
+
+
+def silu_multiply_integer(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    g = torch.round(gate.float() * 128.0).to(torch.int32)
+    u = torch.round(up.float() * 128.0).to(torch.int32)
+    s = silu_lut_q7()[(g.clamp(-1024, 1024) + 1024).long()]
+    s = torch.where(g > 1024, g, s)
+    s = torch.where(g < -1024, torch.zeros_like(s), s)
+    return (s * u).float() / float(128 * 128)
+
+
+# ---- per-token int8 linear (core/quantization.py:103-176, the torch._int_mm branch) ------------
+def int8_linear_pertoken(x: torch.Tensor, w_q: torch.Tensor, w_scale: torch.Tensor) -> torch.Tensor:
+    xq, xs = quantize_int8(x)
+    acc = (xq.double() @ w_q.double().t()).to(torch.int64).to(torch.int32)
+    return acc.float() * (xs.unsqueeze(1) * w_scale.float().unsqueeze(0))
