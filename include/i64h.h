@@ -1,0 +1,153 @@
+/* libi64hip.so - C ABI of the gfx950 (MI355X) kernels for vllm-i64's quantized token-routed-MoE forward.
+ *
+ * Conventions (every entry point):
+ *   - plain C: raw DEVICE pointers, explicit sizes, `void* stream` is a hipStream_t (NULL = default stream);
+ *   - the caller allocates every output and every workspace; the library allocates nothing and never
+ *     synchronises, so every call can be captured into a HIP graph;
+ *   - returns 0 on success, non-zero on failure with the reason in i64h_last_error() (per thread);
+ *   - "stat slot": two consecutive uint32 (order-preserving encodings of a float min and max) that collect the
+ *     min/max of the activations of one quantized Linear CALL; reset with i64h_stats_reset before each forward.
+ *
+ * Citations name the reference interface each entry point stands in for (paths under the reference tree).
+ */
+#ifndef I64H_H
+#define I64H_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library ---- */
+const char* i64h_last_error(void);
+int i64h_version(void);
+int i64h_device_check(void); /* 0 iff the current device is gfx950 */
+
+/* ---- routing -------------------------------------------------------------------------------------------
+ * expert = token_id & (E-1).  Replaces route_tokens (csrc/i64_ops_binding.cu:32-65, csrc/i64_router.cu:51-70,
+ * vllm_i64/kernels/i64_ops.py:17-34). */
+int i64h_route_tokens(const int64_t* token_ids, int32_t* expert_ids, int64_t n, int32_t num_experts, void* stream);
+
+/* routes[k][t] = table[k][clamp(id[t], 0, V-1)], table int64 [top_k, V].  Replaces TokenRoutedMLP.route
+ * (vllm_i64/layers/token_routed_mlp.py:113-130). */
+int i64h_route_lookup(const int64_t* token_ids, const int64_t* table, int64_t* routes, int64_t n, int32_t top_k, int64_t vocab,
+                      void* stream);
+
+/* Stable grouping of `rows` keys (bucket ids in [0, num_buckets)):
+ *   keys[rows] (copy), offsets[num_buckets+1] (exclusive), perm[j] = source row of sorted row j,
+ *   inv[s] = sorted row of source row s, sorted_bucket[j] = bucket of sorted row j (may be NULL).
+ * Source order is kept inside a bucket.  workspace: i64h_bucketize_workspace_bytes(rows, num_buckets, 1) bytes.
+ * Replaces the count / prefix-sum / scatter-index part of i64_route_and_scatter (csrc/i64_router.cu:200-249),
+ * scatter_by_expert (csrc/i64_ops_binding.cu:179-204) and i64_scatter (vllm_i64/kernels/i64_ops.py:37-78). */
+int64_t i64h_bucketize_workspace_bytes(int64_t rows, int32_t num_buckets, int32_t layers);
+int i64h_bucketize(const int32_t* keys_in, int32_t* keys, int32_t* offsets, int32_t* perm, int32_t* inv, int32_t* sorted_bucket,
+                   int32_t* workspace, int64_t rows, int32_t num_buckets, void* stream);
+
+/* Routing plan of a whole forward: for each of `layers` routing tables (tables + l*table_layer_stride, int64
+ * [top_k, V]) look up the top_k routes of the n tokens and bucket the top_k*n (route, token) rows by
+ * bucket = expert*top_k + route.  Source row of (route k, token t) is k*n + t.  Outputs are per layer,
+ * contiguous: routes[l][top_k][n] (may be NULL), keys/perm/inv/sorted_bucket[l][top_k*n], offsets[l][E*top_k+1],
+ * expert_offsets[l][E+1] (rows of expert e = all its routes; may be NULL), tok_slots[l][n][1+top_k] (may be NULL):
+ * relative stat slots of a token's Linear calls, [0] = 0 (the call over all tokens), [1+k] = 1 + bucket of route k.
+ * The live model's per-layer route() + per-expert boolean masks (token_routed_mlp.py:113-139) in one pass. */
+int i64h_moe_plan(const int64_t* token_ids, const int64_t* tables, int64_t table_layer_stride, int64_t* routes, int32_t* keys,
+                  int32_t* tok_slots, int32_t* offsets, int32_t* expert_offsets, int32_t* perm, int32_t* inv, int32_t* sorted_bucket,
+                  int32_t* workspace, int64_t n, int32_t top_k, int64_t vocab, int32_t num_experts, int32_t layers, void* stream);
+
+/* dst[i] = src[idx[i]] for rows of row_bytes bytes (idx NULL = copy).  Replaces the row moves of i64_scatter_kernel /
+ * i64_gather_kernel (csrc/i64_router.cu:94-165), gather_by_expert (csrc/i64_ops_binding.cu:207-209). */
+int i64h_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n_rows, int64_t row_bytes, void* stream);
+
+/* out[r, j] = silu(gate_up[r, j]) * gate_up[r, inter + j]; dtype 0 fp32, 1 fp16, 2 bf16 (fp32 math).  Replaces
+ * silu_hadamard (csrc/i64_ops_binding.cu:74-137, csrc/i64_expert_dispatch.cu:100-122). */
+int i64h_silu_mul(const void* gate_up, void* out, int64_t n, int32_t inter, int32_t dtype, void* stream);
+
+/* ---- dynamic (reference CPU engine) activation quantization ---------------------------------------------------------
+ * The x86/FBGEMM dynamic Linear the reference gets from torch.ao quantize_dynamic (vllm_i64/core/loader.py:57-76):
+ * per call 7-bit asymmetric activations, min/max over the whole call. */
+int i64h_stats_reset(uint32_t* stats, int64_t n_slots, void* stream);
+/* fold min/max of every row of x[rows, K] into slot_base + slots[r][0..slots_per_row) (slots NULL: slot_base) */
+int i64h_rows_minmax(const float* x, int64_t rows, int32_t K, const int32_t* slots, int32_t slots_per_row, int32_t slot_base,
+                     uint32_t* stats, void* stream);
+/* a[r] = quantize(x[src_row ? src_row[r] % src_mod : r]) with the parameters of slot slot_base + (row_slot ? row_slot[r] : 0):
+ * a = clamp(rne(fma(x, 1/scale, zp)), 0, 255) - zp as int8; row_scale[r] = scale; row_zp[r] = zp (may be NULL). */
+int i64h_quantize_dynamic(const float* x, int64_t out_rows, int32_t K, const int32_t* src_row, int32_t src_mod, const int32_t* row_slot,
+                          int32_t slot_base, const uint32_t* stats, int8_t* a, float* row_scale, int32_t* row_zp, void* stream);
+/* parameters of slots [0, n_slots): scale, zero point, and (optional) [lo, hi] */
+int i64h_qparams(const uint32_t* stats, int32_t n_slots, float* scale, int32_t* zp, float* lo_hi, void* stream);
+
+/* ---- per-row symmetric int8 (operator API) -----------------------------------------------------------------------------
+ * s = max(amax, 1e-8)/127, q = clamp(rint(x/s), -128, 127).  Replace I64_quantize_int8 / I64_quantize_perchannel_int8 /
+ * I64_dequantize_int8 (csrc/I64_quantize.cu:40-166) and I64_rmsnorm_quant_forward (csrc/I64_rmsnorm.cu:97-191). */
+int i64h_quant_rows(const float* x, int8_t* out, float* scale, int64_t rows, int32_t K, void* stream);
+int i64h_dequant_rows(const int8_t* q, const float* scale, float* out, int64_t rows, int32_t K, void* stream);
+int i64h_rmsnorm_quant(const float* x, const float* weight, float eps, int8_t* out, float* scale, int64_t rows, int32_t H, void* stream);
+
+/* ---- contractions ----------------------------------------------------------------------------------------------------
+ * Grouped int8 GEMM on the int8 matrix cores:  C[r, c] = float(sum_k A[r,k] * B[g][c,k]) * (row_scale[r] * w_scale[g]),
+ * rows [group_offsets[g], group_offsets[g+1]) belong to group g (group_offsets NULL: one group).  B is [G][N][K]
+ * (nn.Linear layout).  epilogue 0: C fp32 [M_total, N].  epilogue 1 (SwiGLU): N = 2*I, C fp32 [M_total, I] =
+ * silu(C[:, :I]) * C[:, I:], and if stats != NULL min/max of the result go to slot slot_base + (row_slot ? row_slot[r] : 0).
+ * Replaces the per-expert cuBLAS loop of i64_expert_dispatch (csrc/i64_expert_dispatch.cu:144-233), the per-expert Linear
+ * calls of TokenRoutedMLP.expert_forward (token_routed_mlp.py:135-144) and every quantized nn.Linear of the model. */
+int i64h_gemm_i8(const int8_t* A, const float* row_scale, const int8_t* B, const float* w_scale, const int32_t* group_offsets,
+                 int32_t num_groups, int64_t M_total, int32_t N, int32_t K, float* C, int32_t epilogue, const int32_t* row_slot,
+                 int32_t slot_base, uint32_t* stats, void* stream);
+/* C[M, N] = A[a_rows ? a_rows[m] : m, :K] . B[N, K]^T in fp32 (tied lm_head, vllm_i64/models/complexity_deep/model.py:436-437). */
+int i64h_gemm_f32(const float* A, const int32_t* a_rows, const float* B, float* C, int64_t M, int32_t N, int32_t K, void* stream);
+/* fp32 activations x int8 weights with per-output-channel scale: I64_gemm_dequant_int8 / I64_gemm_silu_int8
+ * (csrc/I64_gemm.cu:40-126). */
+int i64h_gemm_w8a32(const float* x, const int8_t* w, const float* w_scale, float* out, int64_t M, int32_t N, int32_t K, void* stream);
+int i64h_gemm_w8a32_swiglu(const float* x, const int8_t* gate_w, const float* gate_scale, const int8_t* up_w, const float* up_scale,
+                           float* out, int64_t M, int32_t I, int32_t K, void* stream);
+
+/* ---- row kernels -------------------------------------------------------------------------------------------------------
+ * nn.Embedding lookup (model.py:415). */
+int i64h_embedding(const int64_t* ids, const float* table, float* out, int64_t n, int32_t H, int64_t V, void* stream);
+/* x * rsqrt(mean(x^2) + eps) * w : I64_rmsnorm_forward (csrc/I64_rmsnorm.cu:41-91), nn.RMSNorm in the model. */
+int i64h_rmsnorm(const float* x, const float* weight, float* out, int64_t rows, int32_t H, float eps, void* stream);
+/* Residual update + MoE combine + RMSNorm + call statistics in one pass (decoder-layer glue, model.py:349-363, and
+ * the weighted combine of TokenRoutedMLP.forward, token_routed_mlp.py:156-185):
+ *   v = h (+ add) (+ routed_scale * sum_k w_k * moe_rows[moe_inv[k*n+t]] (+ shared_scale * moe_shared));  h_out = v;
+ *   normed = rmsnorm(v) (skipped if normed NULL); min/max(normed row) -> slots (skipped if stats NULL).
+ * route_weights is a HOST array of top_k floats. */
+int i64h_fused_residual_norm(const float* h, const float* add, const float* moe_rows, const int32_t* moe_inv, const float* moe_shared,
+                             const float* route_weights, int32_t top_k, float routed_scale, float shared_scale, float* h_out,
+                             const float* norm_weight, float eps, float* normed, int64_t n, int32_t H, const int32_t* slots,
+                             int32_t slots_per_row, int32_t slot_base, uint32_t* stats, void* stream);
+/* Per-head QK RMSNorm + rotate-half RoPE on the fused qkv projection, q to q_out, K/V into the paged cache
+ * (model.py:172-184,212-219; core/kv_cache.py:294-316).  rope_tab [max_pos, head_dim] = cos(head_dim/2) | sin(head_dim/2).
+ * kv_dtype 0 fp32, 1 fp16, 2 bf16.  q_norm_w / k_norm_w NULL = no QK norm. */
+int i64h_qk_norm_rope_kv(const float* qkv, const float* q_norm_w, const float* k_norm_w, float qk_eps, const float* rope_tab,
+                         const int32_t* positions, const int32_t* slot_ids, const int32_t* block_table, int32_t max_blocks_per_seq,
+                         float* q_out, void* k_cache, void* v_cache, int32_t kv_dtype, int64_t n, int32_t num_heads, int32_t num_kv_heads,
+                         int32_t head_dim, int32_t block_size, void* stream);
+/* I64_rope_forward / I64_rope_integer_forward (csrc/I64_rope.cu:24-104): x [n, heads, hd], cos/sin [n, hd]. */
+int i64h_rope(const float* x, const float* cos_, const float* sin_, float* out, int64_t n, int32_t heads, int32_t head_dim, void* stream);
+int i64h_rope_q14(const float* x, const int16_t* cos_q14, const int16_t* sin_q14, float* out, int64_t n, int32_t heads, int32_t head_dim,
+                  void* stream);
+/* I64_softmax_integer (csrc/I64_softmax.cu:75-159) with the table of vllm_i64/layers/moe.py:44-47 supplied by the host. */
+int i64h_softmax_q7(const float* logits, float* out, int64_t rows, int32_t D, const int32_t* exp_lut_1025, void* stream);
+/* silu_multiply_integer (vllm_i64/layers/integer_activations.py:53-66), table of 2049 entries supplied by the host. */
+int i64h_silu_mul_q7(const float* gate, const float* up, float* out, int64_t total, const int32_t* silu_lut_2049, void* stream);
+
+/* Greedy sampling glue of one engine step: out[r] = first index of max(x[r, :D]) (argmax sampling,
+ * vllm_i64/core/sampling.py:435-436); positions[i] += 1, ctx_len[i] += 1 (what scheduler.update_after_step does to a
+ * decoding sequence, vllm_i64/engine/i64_scheduler.py:505-546). */
+int i64h_argmax_rows(const float* x, int64_t* out, int64_t rows, int32_t D, void* stream);
+int i64h_advance(int32_t* positions, int32_t* ctx_len, int64_t n, void* stream);
+
+/* ---- attention -----------------------------------------------------------------------------------------------------------
+ * Causal GQA attention over the paged cache (num_blocks, block_size, kv_heads, head_dim): row r attends to the first
+ * ctx_len[r] cached tokens of sequence slot_ids[r] (NULL: r).  Replaces naive_paged_decode_attention
+ * (vllm_i64/layers/attention.py:517-601), naive_cached_attention (190-245) and the model's per-sequence cache loop
+ * (model.py:203-236).  workspace: i64h_paged_attn_workspace_floats(...) floats when splits > 1. */
+int64_t i64h_paged_attn_workspace_floats(int64_t rows, int32_t num_heads, int32_t head_dim, int32_t splits);
+int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, int32_t kv_dtype, const int32_t* block_table,
+                    int32_t max_blocks_per_seq, const int32_t* slot_ids, const int32_t* ctx_len, float softmax_scale, float* out,
+                    float* workspace, int64_t rows, int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
+                    int32_t splits, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* I64H_H */

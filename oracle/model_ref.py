@@ -412,6 +412,8 @@ def model_forward(cfg: SynthConfig, bank: LinearBank, token_ids: torch.Tensor, p
         if record is not None:
             record[f"{p}mlp_out"] = m.clone()
         h = h + m
+        if record is not None:
+            record[f"{p}out"] = h.clone()
     h = rmsnorm(h, bank.w["final_norm"], cfg.rms_eps)
     return F.linear(h.float(), bank.w["embed"].float())
 

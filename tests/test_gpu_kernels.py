@@ -1,0 +1,382 @@
+"""GPU parity tests: every kernel through the C ABI against the CPU oracle / golden vectors.  Run with -m gpu."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model_ref as M
+from oracle import ops_ref as O
+from oracle import qlinear as Q
+
+pytestmark = pytest.mark.gpu
+warnings.filterwarnings("ignore")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from vllm_i64_amd import _lib
+    lib = _lib.load()
+    assert lib.i64h_device_check() == 0, lib.i64h_last_error().decode()
+    return torch.device("cuda:0")
+
+
+def _ops():
+    from vllm_i64_amd import ops
+    return ops
+
+
+# ---- int8 MFMA GEMM: exact integer accumulators --------------------------------------------------------------
+@pytest.mark.parametrize("M_,N_,K_,G_", [(1, 16, 64, 1), (77, 200, 448, 1), (300, 896, 1024, 1), (515, 130, 1024, 5),
+                                          (64, 1536, 1024, 1), (1000, 384, 160, 3)])
+def test_gemm_i8_exact(dev, M_, N_, K_, G_):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M_ * 7 + N_)
+    a = torch.randint(-127, 128, (M_, K_), generator=g, dtype=torch.int8)
+    w = torch.randint(-128, 128, (G_, N_, K_), generator=g, dtype=torch.int8)
+    # asymmetric group sizes incl. an empty group
+    cuts = sorted(torch.randint(0, M_ + 1, (G_ - 1,), generator=g).tolist()) if G_ > 1 else []
+    if G_ > 2:
+        cuts[1] = cuts[0]
+    off = [0] + cuts + [M_]
+    rs = torch.rand(M_, generator=g) + 0.5
+    ws = torch.rand(G_, generator=g) + 0.5
+    ref = torch.empty(M_, N_)
+    for gi in range(G_):
+        s, e = off[gi], off[gi + 1]
+        acc = (a[s:e].double() @ w[gi].double().t())
+        ref[s:e] = acc.float() * (rs[s:e].unsqueeze(1) * ws[gi])
+    out = ops.gemm_i8(a.to(dev), rs.to(dev), w.to(dev), ws.to(dev),
+                      group_offsets=torch.tensor(off, dtype=torch.int32, device=dev) if G_ > 1 else None)
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_gemm_i8_identity_asymmetric(dev):
+    """A = I against an asymmetric B catches a transposed accumulator layout."""
+    ops = _ops()
+    K = 64
+    a = torch.eye(K, dtype=torch.int8)
+    w = (torch.arange(48 * K).reshape(48, K) % 113 - 50).to(torch.int8)
+    out = ops.gemm_i8(a.to(dev), torch.ones(K, device=dev), w.to(dev), torch.ones(1, device=dev))
+    assert torch.equal(out.cpu(), w.t().float())
+
+
+def test_gemm_i8_swiglu_and_stats(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    M_, I_, K_, G_ = 333, 72, 256, 3
+    a = torch.randint(-127, 128, (M_, K_), generator=g, dtype=torch.int8)
+    w = torch.randint(-128, 128, (G_, 2 * I_, K_), generator=g, dtype=torch.int8)
+    off = [0, 100, 100, M_]
+    rs = (torch.rand(M_, generator=g) + 0.5) * 1e-3
+    ws = (torch.rand(G_, generator=g) + 0.5) * 1e-2
+    slot = torch.randint(0, 4, (M_,), generator=g, dtype=torch.int32)
+    ref = torch.empty(M_, I_)
+    for gi in range(G_):
+        s, e = off[gi], off[gi + 1]
+        c = (a[s:e].double() @ w[gi].double().t()).float() * (rs[s:e].unsqueeze(1) * ws[gi])
+        ref[s:e] = torch.nn.functional.silu(c[:, :I_]) * c[:, I_:]
+    stats = ops.stats_alloc(8, dev)
+    ops.stats_reset(stats)
+    out = ops.gemm_i8(a.to(dev), rs.to(dev), w.to(dev), ws.to(dev), group_offsets=torch.tensor(off, dtype=torch.int32, device=dev),
+                      epilogue=ops.EPI_SWIGLU, row_slot=slot.to(dev), slot_base=2, stats=stats)
+    torch.testing.assert_close(out.cpu(), ref, rtol=2e-6, atol=1e-7)
+    _, _, lohi = ops.qparams(stats, 8)
+    lohi, o = lohi.cpu(), out.cpu()
+    for s in range(4):
+        rows = o[slot == s]
+        assert lohi[2 + s, 0] == min(rows.min().item(), 0.0) and lohi[2 + s, 1] == max(rows.max().item(), 0.0)
+    assert lohi[0, 0] == 0 and lohi[0, 1] == 0
+
+
+# ---- routing / bucketing: bit exact --------------------------------------------------------------------------
+def test_route_tokens_and_lookup(dev, golden_dir):
+    ops = _ops()
+    z = np.load(os.path.join(golden_dir, "ops.npz"))
+    ids = torch.from_numpy(z["route_ids"]).to(dev)
+    for E in (2, 4, 8, 16):
+        assert np.array_equal(ops.route_tokens(ids, E).cpu().numpy(), z[f"route_E{E}"])
+    assert ops.route_tokens(torch.arange(8, device=dev), 4).tolist() == [0, 1, 2, 3, 0, 1, 2, 3]
+    cfg = M.named_config("tiny-moe")
+    tables = M.make_tables(cfg)
+    ids = torch.cat([M.make_token_ids(cfg, 500), torch.tensor([-5, cfg.vocab_size + 3])])
+    r = ops.route_lookup(ids.to(dev), tables[1].to(dev))
+    assert torch.equal(r.cpu(), M.route(tables[1], ids))
+    z = np.load(os.path.join(golden_dir, "moe_layer.npz"))
+    w = M.make_weights(cfg, seed=0)
+    for n in (1, 64, 300):
+        ids = torch.from_numpy(z[f"tiny-moe_n{n}_ids"])
+        assert np.array_equal(ops.route_lookup(ids.to(dev), w["l1.table"].to(dev)).cpu().numpy(), z[f"tiny-moe_n{n}_routes"])
+
+
+@pytest.mark.parametrize("n", [0, 1, 64, 777, 5000])
+def test_moe_plan_bit_exact(dev, n):
+    ops = _ops()
+    cfg = M.named_config("tiny-moe")
+    tables = torch.stack(M.make_tables(cfg))
+    ids = M.make_token_ids(cfg, max(n, 1), seed=3)[:n]
+    plan = ops.MoePlan(n, cfg.top_k, cfg.num_experts, cfg.num_layers, dev, with_routes=True).run(ids.to(dev), tables.to(dev))
+    torch.cuda.synchronize()
+    R = n * cfg.top_k
+    for l in range(cfg.num_layers):
+        routes = M.route(tables[l], ids) if n else torch.zeros(cfg.top_k, 0, dtype=torch.long)
+        counts, offsets, perm = M.bucketize(routes, cfg.num_experts)
+        assert torch.equal(plan.offsets[l].cpu(), offsets)
+        if n == 0:
+            continue
+        assert torch.equal(plan.routes[l].cpu(), routes)
+        assert torch.equal(plan.perm[l, :R].cpu(), perm)
+        inv = torch.empty(R, dtype=torch.int32)
+        inv[perm.long()] = torch.arange(R, dtype=torch.int32)
+        assert torch.equal(plan.inv[l, :R].cpu(), inv)
+        key = (routes * cfg.top_k + torch.arange(cfg.top_k).unsqueeze(1)).reshape(-1).to(torch.int32)
+        assert torch.equal(plan.sorted_bucket[l, :R].cpu(), key[perm.long()])
+        assert torch.equal(plan.expert_offsets[l].cpu(), offsets[:: cfg.top_k])
+        ts = plan.tok_slots[l, :n].cpu()
+        assert torch.all(ts[:, 0] == 0) and torch.equal(ts[:, 1:], 1 + key.reshape(cfg.top_k, n).t())
+
+
+def test_scatter_gather_roundtrip(dev, golden_dir):
+    ops = _ops()
+    z = np.load(os.path.join(golden_dir, "ops.npz"))
+    x, eid = torch.from_numpy(z["scatter_x"]), torch.from_numpy(z["scatter_eid"])
+    off, perm, inv, _ = ops.bucketize(eid.to(dev), 4)
+    sc, si, offs, cnt = O.scatter_by_expert(x, eid, 4)
+    assert np.array_equal(off.cpu().numpy()[:4], z["scatter_offsets"])
+    assert np.array_equal((off[1:] - off[:-1]).cpu().numpy(), z["scatter_counts"])
+    scat = ops.gather_rows(x.to(dev), perm)
+    assert torch.equal(scat.cpu(), sc) and torch.equal(inv.cpu(), si)
+    assert torch.equal(ops.gather_rows(scat, inv).cpu(), x)
+
+
+# ---- dynamic quantization: bit exact --------------------------------------------------------------------------
+@pytest.mark.parametrize("case", [(1, 96, 1.0, 0.0), (64, 1024, 1.0, 0.0), (33, 448, 1.0, 3.0), (33, 448, 1.0, -3.0),
+                                  (8, 96, 0.0, 0.0), (8, 96, 1e-7, 0.0), (257, 1024, 30.0, 0.1), (5, 100, 1.0, 0.0)])
+def test_quantize_dynamic_bit_exact(dev, case):
+    ops = _ops()
+    m, k, xs, shift = case
+    g = torch.Generator().manual_seed(int(m * 131 + k))
+    x = (torch.empty(m, k).normal_(0, 1, generator=g) + shift) * xs
+    stats = ops.stats_alloc(3, dev)
+    ops.stats_reset(stats)
+    xd = x.to(dev)
+    ops.rows_minmax(xd, stats, slot_base=1)
+    a, scale, zp = ops.quantize_dynamic(xd, stats, slot_base=1, want_zp=True)
+    s_ref, zp_ref = Q.dynamic_qparams(x.numpy())
+    xq_ref = Q.quantize_activation(x.numpy(), s_ref, zp_ref).astype(np.int32) - zp_ref
+    assert np.all(scale.cpu().numpy() == s_ref) and np.all(zp.cpu().numpy() == zp_ref)
+    assert np.array_equal(a.cpu().numpy().astype(np.int32), xq_ref)
+
+
+def test_dynamic_linear_bit_exact(dev, golden_dir):
+    """Whole Linear call (statistics -> qparams -> quantize -> int8 MFMA -> rescale) against torch's own output."""
+    ops = _ops()
+    from vllm_i64_amd.model import pack_per_tensor
+    z = np.load(os.path.join(golden_dir, "qlinear.npz"))
+    for ci in range(int(z["n_cases"][0])):
+        m, k, n = (int(v) for v in z[f"c{ci}_shape"])
+        if k % 16:
+            continue
+        xs, shift = z[f"c{ci}_xs_shift"]
+        g = torch.Generator().manual_seed(500 + ci)
+        wt = torch.empty(n, k).normal_(0, 0.02, generator=g)
+        x = (torch.empty(m, k).normal_(0, 1.0, generator=g) + float(shift)) * float(xs)
+        pl = pack_per_tensor(wt, dev)
+        wq, ws = Q.quantize_weight_per_tensor(wt.numpy())
+        assert np.array_equal(pl.w_q[0].cpu().numpy(), wq) and pl.w_s.cpu().numpy()[0] == ws
+        stats = ops.stats_alloc(1, dev)
+        ops.stats_reset(stats)
+        xd = x.to(dev)
+        ops.rows_minmax(xd, stats)
+        a, scale = ops.quantize_dynamic(xd, stats)
+        y = ops.gemm_i8(a, scale, pl.w_q, pl.w_s).cpu().numpy()
+        exp = z[f"c{ci}_y"]
+        got = y if exp.shape == y.shape else y[:: max(1, m // 16)]
+        assert np.array_equal(got, exp), ci
+
+
+# ---- operator-API row kernels against the golden vectors ----------------------------------------------------------
+def test_row_ops_golden(dev, golden_dir):
+    ops = _ops()
+    z = np.load(os.path.join(golden_dir, "ops.npz"))
+    d = lambda k: torch.from_numpy(z[k]).to(dev)
+    # integer softmax: LUT from the host (truncating table of the reference's Python path), bit exact
+    lut = O.exp_lut_q16().to(dev)
+    assert np.array_equal(ops.softmax_q7(d("softmax_in"), lut).cpu().numpy(), z["softmax_out"])
+    slut = O.silu_lut_q7().to(dev)
+    assert np.array_equal(ops.silu_mul_q7(d("smi_gate"), d("smi_up"), slut).cpu().numpy(), z["smi_out"])
+    assert np.array_equal(ops.rope_q14(d("rope_x"), d("rope_cq"), d("rope_sq")).cpu().numpy(), z["rope_int_out"])
+    assert np.allclose(ops.rope(d("rope_x"), d("rope_cos"), d("rope_sin")).cpu().numpy(), z["rope_out"], rtol=0, atol=1e-6)
+    assert np.allclose(ops.rmsnorm(d("rms_x"), d("rms_w"), 1e-6).cpu().numpy(), z["rms_out"], rtol=1e-5, atol=1e-6)
+    assert np.allclose(ops.silu_mul(d("silu_in"), 32).cpu().numpy(), z["silu_out"], rtol=1e-5, atol=1e-6)
+    q, s = ops.quant_rows(d("rms_x"))
+    assert np.array_equal(s.cpu().numpy(), z["q8_as"])
+    assert np.abs(q.cpu().numpy().astype(np.int32) - z["q8_a"].astype(np.int32)).max() <= 1  # x/s ties may round either way
+    assert (q.cpu().numpy() != z["q8_a"]).mean() < 1e-3
+    assert np.allclose(ops.dequant_rows(q, s).cpu().numpy(), O.dequantize_int8(q.cpu(), s.cpu()).numpy(), rtol=0, atol=0)
+    qn, sn = ops.rmsnorm_quant(d("rms_x"), d("rms_w"), 1e-6)
+    qr, sr = O.rmsnorm_quant_forward(torch.from_numpy(z["rms_x"]), torch.from_numpy(z["rms_w"]), 1e-6)
+    assert np.allclose(sn.cpu().numpy(), sr.numpy(), rtol=1e-5) and np.abs(qn.cpu().numpy().astype(int) - qr.numpy().astype(int)).max() <= 1
+
+
+def test_w8a32_gemm(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(21)
+    x = torch.empty(70, 200).normal_(0, 1, generator=g)
+    w = torch.randint(-128, 128, (90, 200), generator=g, dtype=torch.int8)
+    s = torch.rand(90, generator=g) * 0.01
+    w2 = torch.randint(-128, 128, (90, 200), generator=g, dtype=torch.int8)
+    s2 = torch.rand(90, generator=g) * 0.01
+    torch.testing.assert_close(ops.gemm_w8a32(x.to(dev), w.to(dev), s.to(dev)).cpu(), O.gemm_dequant_int8(x, w, s), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(ops.gemm_w8a32_swiglu(x.to(dev), w.to(dev), s.to(dev), w2.to(dev), s2.to(dev)).cpu(),
+                               O.gemm_silu_int8(x, w, s, w2, s2), rtol=1e-4, atol=1e-4)
+
+
+def test_gemm_f32(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(22)
+    a = torch.empty(67, 128).normal_(0, 1, generator=g)
+    b = torch.empty(301, 128).normal_(0, 0.02, generator=g)
+    rows = torch.tensor([66, 0, 5], dtype=torch.int32)
+    torch.testing.assert_close(ops.gemm_f32(a.to(dev), b.to(dev)).cpu(), a @ b.t(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(ops.gemm_f32(a.to(dev), b.to(dev), a_rows=rows.to(dev)).cpu(), a[rows.long()] @ b.t(), rtol=1e-5, atol=1e-6)
+
+
+def test_argmax_and_advance(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(23)
+    x = torch.empty(9, 1000).normal_(0, 1, generator=g)
+    x[3, 17] = x[3, 900] = 50.0  # tie -> first index
+    assert torch.equal(ops.argmax_rows(x.to(dev)).cpu(), x.argmax(-1))
+    assert int(ops.argmax_rows(x.to(dev))[3]) == 17
+    p = torch.arange(5, dtype=torch.int32, device=dev)
+    c = p + 1
+    ops.advance(p, c)
+    assert p.tolist() == [1, 2, 3, 4, 5] and c.tolist() == [2, 3, 4, 5, 6]
+
+
+# ---- attention ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kv_dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 2e-2), (torch.float16, 2e-3)])
+@pytest.mark.parametrize("splits", [1, 3])
+def test_paged_decode_attention_golden(dev, golden_dir, kv_dtype, tol, splits):
+    """naive_paged_decode_attention fixture incl. a zero-length sequence (tests/test_new_features.py:422-443)."""
+    ops = _ops()
+    z = np.load(os.path.join(golden_dir, "ops.npz"))
+    q = torch.from_numpy(z["pd_q"]).to(dev)
+    kc, vc = torch.from_numpy(z["pd_k"]).to(dev).to(kv_dtype), torch.from_numpy(z["pd_v"]).to(dev).to(kv_dtype)
+    out = ops.paged_attn(q, kc, vc, torch.from_numpy(z["pd_bt"]).to(dev), torch.from_numpy(z["pd_sl"]).to(dev), splits=splits)
+    assert np.allclose(out.cpu().numpy(), z["pd_out"], rtol=0, atol=tol)
+    assert np.array_equal(out.cpu().numpy()[2], np.zeros_like(z["pd_out"][2]))
+
+
+@pytest.mark.parametrize("hd,nh,kvh", [(64, 16, 4), (128, 8, 8), (32, 4, 2), (16, 8, 1)])
+def test_paged_attention_random(dev, hd, nh, kvh):
+    """Causal rows of several sequences against the oracle's cached attention; block table is a random permutation."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(hd + nh)
+    lens, nblk = [70, 1, 33, 16], 16
+    kc = torch.empty(nblk, 16, kvh, hd).normal_(0, 1, generator=g)
+    vc = torch.empty(nblk, 16, kvh, hd).normal_(0, 1, generator=g)
+    perm = torch.randperm(nblk, generator=g).to(torch.int32)
+    bt = torch.full((4, 5), -1, dtype=torch.int32)
+    used = 0
+    for s, n in enumerate(lens):
+        nb = (n + 15) // 16
+        bt[s, :nb] = perm[used:used + nb]
+        used += nb
+    rows_slot, rows_ctx = [], []
+    for s, n in enumerate(lens):
+        for c in sorted({1, n, max(1, n // 2)}):
+            rows_slot.append(s), rows_ctx.append(c)
+    q = torch.empty(len(rows_slot), nh, hd).normal_(0, 1, generator=g)
+    out = ops.paged_attn(q.to(dev), kc.to(dev), vc.to(dev), bt.to(dev), torch.tensor(rows_ctx, dtype=torch.int32, device=dev),
+                         slot_ids=torch.tensor(rows_slot, dtype=torch.int32, device=dev), splits=2).cpu()
+    for i, (s, c) in enumerate(zip(rows_slot, rows_ctx)):
+        nb = (c + 15) // 16
+        kf = kc[bt[s, :nb].long()].reshape(-1, kvh, hd)[:c]
+        vf = vc[bt[s, :nb].long()].reshape(-1, kvh, hd)[:c]
+        ref = M.cached_attention(q[i:i + 1], kf, vf, nh // kvh, torch.tensor([c - 1]), 1.0 / hd ** 0.5)[0]
+        torch.testing.assert_close(out[i], ref, rtol=1e-5, atol=2e-6)
+
+
+def test_varlen_prefill_attention_golden(dev, golden_dir):
+    """naive_varlen_attention fixture through qk-less cache writes: K/V placed in the paged cache, causal rows."""
+    ops = _ops()
+    z = np.load(os.path.join(golden_dir, "ops.npz"))
+    q, k, v = (torch.from_numpy(z[n]) for n in ("vl_q", "vl_k", "vl_v"))
+    tps = [int(t) for t in z["vl_tps"]]
+    kc, vc = torch.zeros(8, 16, 2, 16), torch.zeros(8, 16, 2, 16)
+    bt = torch.full((3, 2), -1, dtype=torch.int32)
+    slot, ctx, off, blk = [], [], 0, 0
+    for s, n in enumerate(tps):
+        for b in range((n + 15) // 16):
+            bt[s, b] = blk
+            m = min(16, n - b * 16)
+            kc[blk, :m], vc[blk, :m] = k[off + b * 16: off + b * 16 + m], v[off + b * 16: off + b * 16 + m]
+            blk += 1
+        slot += [s] * n
+        ctx += list(range(1, n + 1))
+        off += n
+    out = ops.paged_attn(q.to(dev), kc.to(dev), vc.to(dev), bt.to(dev), torch.tensor(ctx, dtype=torch.int32, device=dev),
+                         slot_ids=torch.tensor(slot, dtype=torch.int32, device=dev))
+    assert np.allclose(out.cpu().numpy(), z["vl_out"], rtol=0, atol=2e-6)
+
+
+def test_qk_norm_rope_kv(dev):
+    ops = _ops()
+    from vllm_i64_amd.model import rope_table
+    g = torch.Generator().manual_seed(31)
+    nh, kvh, hd, n = 4, 2, 32, 11
+    qkv = torch.empty(n, (nh + 2 * kvh) * hd).normal_(0, 1, generator=g)
+    qw, kw = torch.rand(hd, generator=g) + 0.5, torch.rand(hd, generator=g) + 0.5
+    pos = torch.tensor([0, 1, 2, 3, 4, 5, 17, 18, 40, 41, 42], dtype=torch.int32)
+    slot = torch.tensor([0, 0, 0, 0, 0, 0, 1, 1, 2, 2, 2], dtype=torch.int32)
+    bt = torch.tensor([[2, -1, -1], [5, 0, -1], [1, 3, 4]], dtype=torch.int32)
+    kc = torch.zeros(6, 16, kvh, hd, device=dev)
+    vc = torch.zeros(6, 16, kvh, hd, device=dev)
+    tab = rope_table(64, hd, 10000.0)
+    qo = ops.qk_norm_rope_kv(qkv.to(dev), qw.to(dev), kw.to(dev), 1e-6, tab.to(dev), pos.to(dev), slot.to(dev), bt.to(dev), kc, vc,
+                             nh, kvh, hd).cpu()
+    q, k, v = qkv.split((nh * hd, kvh * hd, kvh * hd), dim=-1)
+    q, k, v = q.reshape(n, nh, hd), k.reshape(n, kvh, hd), v.reshape(n, kvh, hd)
+    cos, sin = M.rope_cos_sin(pos, hd, 10000.0)
+    assert torch.equal(tab[pos.long(), : hd // 2], cos[:, : hd // 2]) and torch.equal(tab[pos.long(), hd // 2:], sin[:, : hd // 2])
+    qr = M.apply_rope(M.rmsnorm(q, qw, 1e-6), cos, sin)
+    kr = M.apply_rope(M.rmsnorm(k, kw, 1e-6), cos, sin)
+    torch.testing.assert_close(qo, qr, rtol=1e-5, atol=1e-6)
+    kc, vc = kc.cpu(), vc.cpu()
+    for t in range(n):
+        pb = int(bt[slot[t], pos[t] // 16])
+        torch.testing.assert_close(kc[pb, pos[t] % 16], kr[t], rtol=1e-5, atol=1e-6)
+        assert torch.equal(vc[pb, pos[t] % 16], v[t])
+
+
+def test_fused_residual_norm(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(41)
+    n, H, top_k = 37, 128, 2
+    h, add = torch.empty(n, H).normal_(0, 1, generator=g), torch.empty(n, H).normal_(0, 1, generator=g)
+    rows = torch.empty(top_k * n, H).normal_(0, 1, generator=g)
+    inv = torch.randperm(top_k * n, generator=g).to(torch.int32)
+    sh = torch.empty(n, H).normal_(0, 1, generator=g)
+    w = torch.rand(H, generator=g) + 0.5
+    slots = torch.randint(0, 5, (n, 3), generator=g, dtype=torch.int32)
+    stats = ops.stats_alloc(8, dev)
+    ops.stats_reset(stats)
+    ho, no = ops.fused_residual_norm(h.to(dev), w.to(dev), 1e-6, add=add.to(dev), moe_rows=rows.to(dev), moe_inv=inv.to(dev),
+                                     moe_shared=sh.to(dev), route_weights=[0.3, 0.7], routed_scale=1.5, shared_scale=0.75,
+                                     slots=slots.to(dev), slot_base=1, stats=stats)
+    routed = 0.3 * rows[inv[:n].long()]
+    routed = routed + 0.7 * rows[inv[n:].long()]
+    ref_h = (h + add) + (1.5 * routed + 0.75 * sh)
+    assert torch.equal(ho.cpu(), ref_h)                      # same fp32 operations in the same order
+    ref_n = M.rmsnorm(ref_h, w, 1e-6)
+    torch.testing.assert_close(no.cpu(), ref_n, rtol=1e-5, atol=1e-6)
+    _, _, lohi = ops.qparams(stats, 8)
+    lohi, nn = lohi.cpu(), no.cpu()
+    for s in range(5):
+        sel = (slots == s).any(dim=1)
+        assert lohi[1 + s, 0] == min(nn[sel].min().item(), 0.0) and lohi[1 + s, 1] == max(nn[sel].max().item(), 0.0)

@@ -1,0 +1,98 @@
+"""ctypes binding of libi64hip.so (the C ABI declared in include/i64h.h).
+
+The product path has no CPU fallback: if the shared library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Dict, Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libi64hip.so")
+
+_P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+
+# name -> argument kinds, in the order of include/i64h.h (p = device/host pointer, i = int32, l = int64, f = float)
+SIGNATURES: Dict[str, str] = {
+    "i64h_route_tokens": "pplip",
+    "i64h_route_lookup": "ppplilp",
+    "i64h_bucketize": "ppppppplip",
+    "i64h_moe_plan": "pplpppppppppliliip",
+    "i64h_gather_rows": "pppllp",
+    "i64h_silu_mul": "ppliip",
+    "i64h_stats_reset": "plp",
+    "i64h_rows_minmax": "plipiipp",
+    "i64h_quantize_dynamic": "plipipipppp" + "p",
+    "i64h_qparams": "pipppp",
+    "i64h_quant_rows": "ppplip",
+    "i64h_dequant_rows": "ppplip",
+    "i64h_rmsnorm_quant": "ppfpplip",
+    "i64h_gemm_i8": "pppppiliipipipp",
+    "i64h_gemm_f32": "pppplii" + "p",
+    "i64h_gemm_w8a32": "pppplii" + "p",
+    "i64h_gemm_w8a32_swiglu": "ppppppliip",
+    "i64h_embedding": "pppli" + "lp",
+    "i64h_rmsnorm": "ppplifp",
+    "i64h_fused_residual_norm": "ppppppiffppfplipiipp",
+    "i64h_qk_norm_rope_kv": "pppfppppipppiliiiip",
+    "i64h_rope": "ppppliip",
+    "i64h_rope_q14": "ppppliip",
+    "i64h_softmax_q7": "pplipp",
+    "i64h_silu_mul_q7": "ppplpp",
+    "i64h_argmax_rows": "pplip",
+    "i64h_advance": "pplp",
+    "i64h_paged_attn": "pppipippfppliiiiip",
+}
+_KIND = {"p": _P, "i": _I, "l": _L, "f": _F}
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+class I64HError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    return ["i64h_last_error", "i64h_version", "i64h_device_check", "i64h_bucketize_workspace_bytes",
+            "i64h_paged_attn_workspace_floats", *SIGNATURES.keys()]
+
+
+def load() -> ctypes.CDLL:
+    """Load the library once; raises if it has not been built (python vllm_i64_amd/build.py)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise I64HError(f"{LIB_PATH} not found: build it with `python vllm_i64_amd/build.py` (no CPU fallback exists)")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.i64h_last_error.restype = ctypes.c_char_p
+    lib.i64h_last_error.argtypes = []
+    lib.i64h_version.restype = _I
+    lib.i64h_device_check.restype = _I
+    lib.i64h_bucketize_workspace_bytes.restype = _L
+    lib.i64h_bucketize_workspace_bytes.argtypes = [_L, _I, _I]
+    lib.i64h_paged_attn_workspace_floats.restype = _L
+    lib.i64h_paged_attn_workspace_floats.argtypes = [_L, _I, _I, _I]
+    for name, sig in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = _I
+        fn.argtypes = [_KIND[c] for c in sig]
+    _lib = lib
+    return lib
+
+
+def ptr(t) -> int:
+    """Device (or host) address of a tensor / ctypes buffer; None -> NULL."""
+    if t is None:
+        return 0
+    if hasattr(t, "data_ptr"):
+        return t.data_ptr()
+    return ctypes.addressof(t)
+
+
+def call(name: str, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise I64HError(f"{name} failed ({rc}): {lib.i64h_last_error().decode()}")

@@ -1,0 +1,133 @@
+// Shared device/host helpers for the gfx950 kernels of libi64hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define I64H_WAVE 64
+
+// ---- host-side error plumbing ---------------------------------------------------------------
+// Every extern "C" entry point returns 0 on success; on failure the message is kept per thread
+// and read back through i64h_last_error().
+void i64h_set_error(const char* fmt, ...);
+
+#define I64H_CHECK_ARG(cond, ...)          \
+    do {                                   \
+        if (!(cond)) {                     \
+            i64h_set_error(__VA_ARGS__);   \
+            return 1;                      \
+        }                                  \
+    } while (0)
+
+#define I64H_CHECK_HIP(expr)                                                              \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            i64h_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return 2;                                                                     \
+        }                                                                                 \
+    } while (0)
+
+#define I64H_CHECK_LAUNCH() I64H_CHECK_HIP(hipGetLastError())
+
+static inline int i64h_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- device helpers ----------------------------------------------------------------------------
+#ifdef __HIPCC__
+
+// Order-preserving map float -> uint32 so that integer atomicMin/atomicMax implement float min/max
+// exactly and independently of arrival order.
+__device__ __forceinline__ uint32_t f32_to_ordered(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_to_f32(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+#define I64H_ORDERED_ZERO 0x80000000u  // f32_to_ordered(+0.0f)
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+    return v;
+}
+
+// Activation quantization parameters of the reference's dynamic int8 Linear (7-bit, asymmetric):
+// restated from the published x86/FBGEMM algorithm; doubles exactly where the CPU code uses them.
+struct QParams {
+    float scale;      // fp32 scale used for the rescale
+    float inv_scale;  // fp32 reciprocal used by the row quantizer
+    int zp;           // zero point in [0,127]
+};
+
+__device__ __forceinline__ QParams choose_qparams_u7(float lo, float hi) {
+    lo = fminf(lo, 0.0f);
+    hi = fmaxf(hi, 0.0f);
+    double scale = ((double)hi - (double)lo) / 127.0;
+    float fs = (float)scale;
+    if (fs == 0.0f || isinf(1.0f / fs)) scale = 0.1;
+    double lo_d = (double)lo, hi_d = (double)hi;
+    const float kSmall = 6.1e-5f;
+    if (scale < (double)kSmall) {
+        float org = (float)scale;
+        scale = (double)kSmall;
+        float span = kSmall * 127.0f;
+        if (lo == 0.0f) {
+            hi_d = (double)span;
+        } else if (hi == 0.0f) {
+            lo_d = (double)(-span);
+        } else {
+            float amp = kSmall / org;
+            lo_d = (double)(lo * amp);
+            hi_d = (double)(hi * amp);
+        }
+    }
+    double zmin = 0.0 - lo_d / scale;
+    double zmax = 127.0 - hi_d / scale;
+    double emin = 0.0 - fabs(lo_d / scale);
+    double emax = 127.0 - fabs(hi_d / scale);
+    double init = (emin < emax) ? zmin : zmax;
+    int zp;
+    if (init < 0.0) zp = 0;
+    else if (init > 127.0) zp = 127;
+    else zp = (int)rintf((float)init);
+    QParams q;
+    q.scale = (float)scale;
+    q.inv_scale = 1.0f / q.scale;
+    q.zp = zp;
+    return q;
+}
+
+// uint8 row quantizer of the x86 engine: rne(fma(x, 1/scale, zp)) clamped to [0,255]; returned with
+// the zero point already subtracted (signed operand for the int8 MFMA; |value| <= 127 for any x
+// inside the [lo,hi] the parameters were chosen from).
+__device__ __forceinline__ int quantize_u7_signed(float x, const QParams& q) {
+    float t = rintf(__builtin_fmaf(x, q.inv_scale, (float)q.zp));
+    t = fminf(fmaxf(t, 0.0f), 255.0f);
+    int v = (int)t - q.zp;
+    return max(-128, min(127, v));
+}
+
+#endif  // __HIPCC__

@@ -1,0 +1,428 @@
+// Bandwidth-bound row kernels: embedding gather, RMSNorm (plain and fused with the residual / MoE combine and
+// the min/max statistics the next quantized Linear needs), per-head QK-norm + rotate-half RoPE + paged-KV
+// write, RoPE (float and Q14), integer softmax (Q7, exp LUT) and the Q7 SiLU*up activation.
+#include "i64h_common.h"
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+
+// ---- embedding ---------------------------------------------------------------------------------------
+__global__ void embedding_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table, float* __restrict__ out, int H,
+                                 int64_t V) {
+    const int64_t t = blockIdx.x;
+    int64_t id = ids[t];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    const float4* s = (const float4*)(table + id * H);
+    float4* d = (float4*)(out + t * H);
+    for (int i = threadIdx.x; i < H / 4; i += blockDim.x) d[i] = s[i];
+}
+
+// ---- plain RMSNorm: out = x * rsqrt(mean(x^2) + eps) * w -------------------------------------------------
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ out,
+                                                      int H, float eps) {
+    __shared__ float red[4];
+    __shared__ float bc;
+    const int64_t r = blockIdx.x;
+    const float* xr = x + r * H;
+    float ss = 0.0f;
+    for (int i = threadIdx.x; i < H; i += 256) ss = __builtin_fmaf(xr[i], xr[i], ss);
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) bc = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)H + eps);
+    __syncthreads();
+    const float rr = bc;
+    for (int i = threadIdx.x; i < H; i += 256) out[r * H + i] = xr[i] * rr * w[i];
+}
+
+// ---- fused residual update + RMSNorm + call statistics ------------------------------------------------------
+// Per token row t (one workgroup):
+//   v = h[t]
+//   if add:            v = v + add[t]                                        (attention / dense-MLP residual)
+//   if moe_rows:       routed = wk[0] * R[inv[0*n+t]]; routed = routed + wk[k] * R[inv[k*n+t]] ...
+//                      m = routed_scale * routed (+ shared_scale * shared[t]);  v = v + m
+//   h_out[t] = v ;  normed[t] = v * rsqrt(mean(v^2) + eps) * w
+//   min/max(normed[t]) -> stat slots slot_base + slots[t][0..spr)            (slots == nullptr: slot_base only)
+// Evaluation order of the combine follows the reference layer (separate multiplies and adds, no fused
+// multiply-add) so that given equal inputs the fp32 result is the same.
+struct MoeCombine {
+    const float* rows;    // [top_k*n, H] expert outputs in bucket order (nullptr: no routed part)
+    const int32_t* inv;   // [top_k*n]    source row (k*n+t) -> bucket-order row
+    const float* shared;  // [n, H] shared-expert output or nullptr
+    float wk[8];
+    int top_k;
+    float routed_scale, shared_scale;
+};
+
+#define FRN_MAXV 4  // float4 per thread => H <= 4096
+__global__ __launch_bounds__(256) void fused_residual_norm_kernel(const float* __restrict__ h, const float* __restrict__ add,
+                                                                  MoeCombine mc, int n, float* __restrict__ h_out,
+                                                                  const float* __restrict__ w, float eps, float* __restrict__ normed,
+                                                                  int H, const int32_t* __restrict__ slots, int spr, int slot_base,
+                                                                  uint32_t* __restrict__ stats) {
+    __shared__ float red[4], rlo[4], rhi[4];
+    __shared__ float bc;
+    const int64_t t = blockIdx.x;
+    const int nv = H / 4;
+    float4 v[FRN_MAXV];
+    float ss = 0.0f;
+#pragma unroll
+    for (int j = 0; j < FRN_MAXV; ++j) {
+        const int i = threadIdx.x + j * 256;
+        if (i < nv) {
+            float4 a = ((const float4*)(h + t * H))[i];
+            if (add) {
+                float4 b = ((const float4*)(add + t * H))[i];
+                a.x = a.x + b.x; a.y = a.y + b.y; a.z = a.z + b.z; a.w = a.w + b.w;
+            }
+            if (mc.rows) {
+                float4 r0 = ((const float4*)(mc.rows + (int64_t)mc.inv[t] * H))[i];
+                float4 o = make_float4(mc.wk[0] * r0.x, mc.wk[0] * r0.y, mc.wk[0] * r0.z, mc.wk[0] * r0.w);
+                for (int k = 1; k < mc.top_k; ++k) {
+                    float4 rk = ((const float4*)(mc.rows + (int64_t)mc.inv[(int64_t)k * n + t] * H))[i];
+                    o.x = o.x + mc.wk[k] * rk.x; o.y = o.y + mc.wk[k] * rk.y;
+                    o.z = o.z + mc.wk[k] * rk.z; o.w = o.w + mc.wk[k] * rk.w;
+                }
+                if (mc.shared) {
+                    float4 s = ((const float4*)(mc.shared + t * H))[i];
+                    o.x = mc.routed_scale * o.x + mc.shared_scale * s.x; o.y = mc.routed_scale * o.y + mc.shared_scale * s.y;
+                    o.z = mc.routed_scale * o.z + mc.shared_scale * s.z; o.w = mc.routed_scale * o.w + mc.shared_scale * s.w;
+                } else {
+                    o.x = mc.routed_scale * o.x; o.y = mc.routed_scale * o.y; o.z = mc.routed_scale * o.z; o.w = mc.routed_scale * o.w;
+                }
+                a.x = a.x + o.x; a.y = a.y + o.y; a.z = a.z + o.z; a.w = a.w + o.w;
+            }
+            if (h_out) ((float4*)(h_out + t * H))[i] = a;
+            v[j] = a;
+            ss = __builtin_fmaf(a.x, a.x, ss); ss = __builtin_fmaf(a.y, a.y, ss);
+            ss = __builtin_fmaf(a.z, a.z, ss); ss = __builtin_fmaf(a.w, a.w, ss);
+        }
+    }
+    if (!normed) return;
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) bc = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)H + eps);
+    __syncthreads();
+    const float rr = bc;
+    float lo = 0.0f, hi = 0.0f;
+#pragma unroll
+    for (int j = 0; j < FRN_MAXV; ++j) {
+        const int i = threadIdx.x + j * 256;
+        if (i < nv) {
+            float4 g = ((const float4*)w)[i];
+            float4 a = v[j];
+            a.x = a.x * rr * g.x; a.y = a.y * rr * g.y; a.z = a.z * rr * g.z; a.w = a.w * rr * g.w;
+            ((float4*)(normed + t * H))[i] = a;
+            lo = fminf(lo, fminf(fminf(a.x, a.y), fminf(a.z, a.w)));
+            hi = fmaxf(hi, fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)));
+        }
+    }
+    if (!stats) return;
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+    if ((threadIdx.x & 63) == 0) {
+        rlo[threadIdx.x >> 6] = lo;
+        rhi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        lo = fminf(fminf(rlo[0], rlo[1]), fminf(rlo[2], rlo[3]));
+        hi = fmaxf(fmaxf(rhi[0], rhi[1]), fmaxf(rhi[2], rhi[3]));
+        const int ns = slots ? spr : 1;
+        for (int j = 0; j < ns; ++j) {
+            const int s = slot_base + (slots ? slots[t * spr + j] : 0);
+            atomicMin(&stats[2 * s], f32_to_ordered(lo));
+            atomicMax(&stats[2 * s + 1], f32_to_ordered(hi));
+        }
+    }
+}
+
+// ---- per-head QK RMSNorm + rotate-half RoPE + paged KV write ----------------------------------------------
+// qkv [n, (nh + 2*kvh) * hd] fp32 from the fused projection.  One wave per head; heads of a token are spread
+// over the workgroup's waves.  q_out [n, nh, hd] fp32.  K (normed, rotated) and V (raw) go to the paged cache
+// (num_blocks, block, kvh, hd) at block_table[slot[t]][pos/block], pos % block.  rope_tab[pos][0..hd/2) = cos,
+// [hd/2..hd) = sin (fp32, built by the host with the same formula as the reference).
+template <typename KV>
+__device__ __forceinline__ KV to_kv(float v);
+template <> __device__ __forceinline__ float to_kv<float>(float v) { return v; }
+template <> __device__ __forceinline__ __hip_bfloat16 to_kv<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
+template <> __device__ __forceinline__ __half to_kv<__half>(float v) { return __float2half(v); }
+
+#define QKR_MAX_HD 256
+template <typename KV>
+__global__ __launch_bounds__(256) void qk_norm_rope_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ qw,
+                                                              const float* __restrict__ kw, float qk_eps, const float* __restrict__ rope_tab,
+                                                              const int32_t* __restrict__ positions, const int32_t* __restrict__ slot_ids,
+                                                              const int32_t* __restrict__ block_table, int max_blocks_per_seq,
+                                                              float* __restrict__ q_out, KV* __restrict__ k_cache, KV* __restrict__ v_cache,
+                                                              int nh, int kvh, int hd, int block) {
+    __shared__ float buf[4][QKR_MAX_HD];
+    const int64_t t = blockIdx.x;
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int pos = positions[t];
+    const int half = hd / 2;
+    const int width = (nh + 2 * kvh) * hd;
+    const float* row = qkv + t * width;
+    const float* cs = rope_tab + (int64_t)pos * hd;
+    const int pb = block_table[(int64_t)slot_ids[t] * max_blocks_per_seq + pos / block];
+    const int64_t cache_row = ((int64_t)pb * block + pos % block) * kvh;  // in heads
+    for (int head = wid; head < nh + 2 * kvh; head += 4) {
+        const float* x = row + (int64_t)head * hd;
+        if (head >= nh + kvh) {  // V: raw copy into the cache
+            if (pb >= 0) {
+                KV* dst = v_cache + (cache_row + (head - nh - kvh)) * hd;
+                for (int d = lane; d < hd; d += 64) dst[d] = to_kv<KV>(x[d]);
+            }
+            continue;
+        }
+        const bool is_q = head < nh;
+        const float* w = is_q ? qw : kw;
+        float ss = 0.0f;
+        for (int d = lane; d < hd; d += 64) ss = __builtin_fmaf(x[d], x[d], ss);
+        ss = wave_sum(ss);
+        const float rr = w ? rsqrtf(ss / (float)hd + qk_eps) : 1.0f;
+        for (int d = lane; d < hd; d += 64) buf[wid][d] = w ? x[d] * rr * w[d] : x[d];
+        __builtin_amdgcn_wave_barrier();
+        for (int d = lane; d < hd; d += 64) {
+            const int f = d < half ? d : d - half;
+            const float c = cs[f], s = cs[half + f];
+            const float self = buf[wid][d];
+            const float other = d < half ? -buf[wid][d + half] : buf[wid][d - half];
+            const float o = self * c + other * s;
+            if (is_q) q_out[(t * nh + head) * hd + d] = o;
+            else if (pb >= 0) k_cache[(cache_row + (head - nh)) * hd + d] = to_kv<KV>(o);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---- RoPE operator (x [n, heads, hd], cos/sin [n, hd], first half used) --------------------------------------
+__global__ void rope_kernel(const float* __restrict__ x, const float* __restrict__ cos_, const float* __restrict__ sin_, float* __restrict__ out,
+                            int64_t total, int heads, int hd) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int half = hd / 2;
+    int d = (int)(i % half);
+    int64_t tmp = i / half;
+    int hh = (int)(tmp % heads);
+    int64_t n = tmp / heads;
+    int64_t base = (n * heads + hh) * hd;
+    float x1 = x[base + d], x2 = x[base + d + half];
+    float c = cos_[n * hd + d], s = sin_[n * hd + d];
+    out[base + d] = x1 * c - x2 * s;
+    out[base + d + half] = x2 * c + x1 * s;
+}
+
+__global__ void rope_q14_kernel(const float* __restrict__ x, const int16_t* __restrict__ cos_, const int16_t* __restrict__ sin_,
+                                float* __restrict__ out, int64_t total, int heads, int hd) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int half = hd / 2;
+    int d = (int)(i % half);
+    int64_t tmp = i / half;
+    int hh = (int)(tmp % heads);
+    int64_t n = tmp / heads;
+    int64_t base = (n * heads + hh) * hd;
+    int x1 = (int)rintf(x[base + d] * 128.0f), x2 = (int)rintf(x[base + d + half] * 128.0f);
+    int c = cos_[n * hd + d], s = sin_[n * hd + d];
+    out[base + d] = (float)(x1 * c - x2 * s) / 2097152.0f;
+    out[base + d + half] = (float)(x2 * c + x1 * s) / 2097152.0f;
+}
+
+// ---- integer softmax: Q7 logits, row max, clamp [-1024, 0], exp LUT (Q16), exp / sum -------------------------
+__global__ __launch_bounds__(256) void softmax_q7_kernel(const float* __restrict__ logits, float* __restrict__ out, int D,
+                                                         const int32_t* __restrict__ lut) {
+    __shared__ int red[4];
+    __shared__ int bc;
+    const int64_t r = blockIdx.x;
+    const float* lr = logits + r * D;
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int mx = INT32_MIN;
+    for (int i = threadIdx.x; i < D; i += 256) mx = max(mx, (int)rintf(lr[i] * 128.0f));
+    mx = wave_max_i(mx);
+    if (lane == 0) red[wid] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) bc = max(max(red[0], red[1]), max(red[2], red[3]));
+    __syncthreads();
+    mx = bc;
+    __syncthreads();
+    int sum = 0;
+    for (int i = threadIdx.x; i < D; i += 256) {
+        int sh = max((int)rintf(lr[i] * 128.0f) - mx, -1024);
+        sum += lut[sh + 1024];
+    }
+    sum = wave_sum_i(sum);
+    if (lane == 0) red[wid] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) bc = max(red[0] + red[1] + red[2] + red[3], 1);
+    __syncthreads();
+    const float tot = (float)bc;
+    for (int i = threadIdx.x; i < D; i += 256) {
+        int sh = max((int)rintf(lr[i] * 128.0f) - mx, -1024);
+        out[r * D + i] = (float)lut[sh + 1024] / tot;
+    }
+}
+
+// ---- Q7 SiLU(gate) * up via the 2049-entry SiLU table ------------------------------------------------------------
+__global__ void silu_mul_q7_kernel(const float* __restrict__ gate, const float* __restrict__ up, float* __restrict__ out, int64_t total,
+                                   const int32_t* __restrict__ lut) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int g = (int)rintf(gate[i] * 128.0f), u = (int)rintf(up[i] * 128.0f);
+    int s = g > 1024 ? g : (g < -1024 ? 0 : lut[g + 1024]);
+    out[i] = (float)(s * u) / 16384.0f;
+}
+
+// ---- greedy sampling glue: first index of the row maximum; position / context advance ------------------------------
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int64_t* __restrict__ out, int D) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int64_t r = blockIdx.x;
+    const float* xr = x + r * D;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < D; i += 256) {
+        const float v = xr[i];
+        if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = bv; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
+        out[r] = bi == 0x7fffffff ? 0 : bi;
+    }
+}
+
+__global__ void advance_kernel(int32_t* __restrict__ positions, int32_t* __restrict__ ctx_len, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        positions[i] += 1;
+        ctx_len[i] += 1;
+    }
+}
+
+// =====================================================================================================
+extern "C" {
+
+int i64h_argmax_rows(const float* x, int64_t* out, int64_t rows, int32_t D, void* stream) {
+    I64H_CHECK_ARG(rows >= 0 && D > 0, "argmax_rows: bad sizes");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, out, (int)D);
+    I64H_CHECK_LAUNCH();
+    return 0;
+}
+
+int i64h_advance(int32_t* positions, int32_t* ctx_len, int64_t n, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(advance_kernel, dim3(i64h_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, positions, ctx_len, (int)n);
+    I64H_CHECK_LAUNCH();
+    return 0;
+}
+
+int i64h_embedding(const int64_t* ids, const float* table, float* out, int64_t n, int32_t H, int64_t V, void* stream) {
+    I64H_CHECK_ARG(n >= 0 && H > 0 && H % 4 == 0, "embedding: H must be a multiple of 4");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(embedding_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, ids, table, out, (int)H, V);
+    I64H_CHECK_LAUNCH();
+    return 0;
+}
+
+int i64h_rmsnorm(const float* x, const float* weight, float* out, int64_t rows, int32_t H, float eps, void* stream) {
+    I64H_CHECK_ARG(rows >= 0 && H > 0, "rmsnorm: bad sizes");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, weight, out, (int)H, eps);
+    I64H_CHECK_LAUNCH();
+    return 0;
+}
+
+int i64h_fused_residual_norm(const float* h, const float* add, const float* moe_rows, const int32_t* moe_inv, const float* moe_shared,
+                             const float* route_weights, int32_t top_k, float routed_scale, float shared_scale, float* h_out,
+                             const float* norm_weight, float eps, float* normed, int64_t n, int32_t H, const int32_t* slots,
+                             int32_t slots_per_row, int32_t slot_base, uint32_t* stats, void* stream) {
+    I64H_CHECK_ARG(n >= 0 && H > 0 && H % 4 == 0 && H <= 1024 * FRN_MAXV, "fused_residual_norm: H=%d unsupported (multiple of 4, <= %d)", H,
+                   1024 * FRN_MAXV);
+    I64H_CHECK_ARG(top_k >= 0 && top_k <= 8, "fused_residual_norm: top_k=%d unsupported", top_k);
+    I64H_CHECK_ARG(moe_rows == nullptr || (moe_inv != nullptr && route_weights != nullptr && top_k > 0), "fused_residual_norm: moe args");
+    if (n == 0) return 0;
+    MoeCombine mc;
+    mc.rows = moe_rows;
+    mc.inv = moe_inv;
+    mc.shared = moe_shared;
+    mc.top_k = top_k;
+    for (int k = 0; k < 8; ++k) mc.wk[k] = (moe_rows && k < top_k) ? route_weights[k] : 0.0f;
+    mc.routed_scale = routed_scale;
+    mc.shared_scale = shared_scale;
+    hipLaunchKernelGGL(fused_residual_norm_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, h, add, mc, (int)n, h_out,
+                       norm_weight, eps, normed, (int)H, slots, (int)slots_per_row, (int)slot_base, stats);
+    I64H_CHECK_LAUNCH();
+    return 0;
+}
+
+// kv_dtype: 0 = fp32, 1 = fp16, 2 = bf16
+int i64h_qk_norm_rope_kv(const float* qkv, const float* q_norm_w, const float* k_norm_w, float qk_eps, const float* rope_tab,
+                         const int32_t* positions, const int32_t* slot_ids, const int32_t* block_table, int32_t max_blocks_per_seq,
+                         float* q_out, void* k_cache, void* v_cache, int32_t kv_dtype, int64_t n, int32_t num_heads, int32_t num_kv_heads,
+                         int32_t head_dim, int32_t block_size, void* stream) {
+    I64H_CHECK_ARG(n >= 0 && head_dim > 0 && head_dim <= QKR_MAX_HD && head_dim % 2 == 0, "qk_norm_rope_kv: head_dim=%d unsupported", head_dim);
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)n), blk(256);
+#define LAUNCH_QKR(T)                                                                                                             \
+    hipLaunchKernelGGL(qk_norm_rope_kv_kernel<T>, grid, blk, 0, st, qkv, q_norm_w, k_norm_w, qk_eps, rope_tab, positions, slot_ids, \
+                       block_table, (int)max_blocks_per_seq, q_out, (T*)k_cache, (T*)v_cache, (int)num_heads, (int)num_kv_heads,     \
+                       (int)head_dim, (int)block_size)
+    if (kv_dtype == 0) LAUNCH_QKR(float);
+    else if (kv_dtype == 1) LAUNCH_QKR(__half);
+    else if (kv_dtype == 2) LAUNCH_QKR(__hip_bfloat16);
+    else I64H_CHECK_ARG(false, "qk_norm_rope_kv: unknown kv dtype %d", kv_dtype);
+#undef LAUNCH_QKR
+    I64H_CHECK_LAUNCH();
+    return 0;
+}
+
+int i64h_rope(const float* x, const float* cos_, const float* sin_, float* out, int64_t n, int32_t heads, int32_t head_dim, void* stream) {
+    I64H_CHECK_ARG(n >= 0 && heads > 0 && head_dim > 0 && head_dim % 2 == 0, "rope: bad sizes");
+    int64_t total = n * heads * (head_dim / 2);
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(rope_kernel, dim3(i64h_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, cos_, sin_, out, total, (int)heads,
+                       (int)head_dim);
+    I64H_CHECK_LAUNCH();
+    return 0;
+}
+
+int i64h_rope_q14(const float* x, const int16_t* cos_q14, const int16_t* sin_q14, float* out, int64_t n, int32_t heads, int32_t head_dim,
+                  void* stream) {
+    I64H_CHECK_ARG(n >= 0 && heads > 0 && head_dim > 0 && head_dim % 2 == 0, "rope_q14: bad sizes");
+    int64_t total = n * heads * (head_dim / 2);
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(rope_q14_kernel, dim3(i64h_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, cos_q14, sin_q14, out, total,
+                       (int)heads, (int)head_dim);
+    I64H_CHECK_LAUNCH();
+    return 0;
+}
+
+int i64h_softmax_q7(const float* logits, float* out, int64_t rows, int32_t D, const int32_t* exp_lut_1025, void* stream) {
+    I64H_CHECK_ARG(rows >= 0 && D > 0 && exp_lut_1025 != nullptr, "softmax_q7: bad args");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(softmax_q7_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, out, (int)D, exp_lut_1025);
+    I64H_CHECK_LAUNCH();
+    return 0;
+}
+
+int i64h_silu_mul_q7(const float* gate, const float* up, float* out, int64_t total, const int32_t* silu_lut_2049, void* stream) {
+    I64H_CHECK_ARG(total >= 0 && silu_lut_2049 != nullptr, "silu_mul_q7: bad args");
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(silu_mul_q7_kernel, dim3(i64h_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, gate, up, out, total,
+                       silu_lut_2049);
+    I64H_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

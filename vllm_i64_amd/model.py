@@ -1,0 +1,369 @@
+"""Model runner for the int8 token-routed-MoE forward on one MI355X.
+
+Host-side counterpart of the reference's ComplexityDeepModel.forward (vllm_i64/models/complexity_deep/model.py:389-441)
+with every Linear quantized the way the reference's CPU engine does it (core/loader.py:57-94), re-designed for the GPU:
+one routing plan per step for all layers, bucket-ordered grouped GEMMs on the int8 matrix cores, quantization statistics
+gathered by the producing kernels, no host synchronisation inside a step (so a decode step replays as one HIP graph).
+
+torch is used for device memory, streams and graphs only; every arithmetic step is a libi64hip.so kernel.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import ops
+from .config import ModelConfig
+
+
+# ---------------------------------------------------------------------------------------------------------
+# offline weight packing (per fused matrix: one symmetric int8 scale, MinMaxObserver qint8 semantics)
+# ---------------------------------------------------------------------------------------------------------
+class PackedLinear:
+    """w_q int8 [G, N, K], w_s fp32 [G] (G = 1 for a dense Linear, E for per-expert Linears)."""
+
+    def __init__(self, w_q: torch.Tensor, w_s: torch.Tensor):
+        self.w_q, self.w_s = w_q, w_s
+        self.G, self.N, self.K = w_q.shape
+
+
+def pack_per_tensor(w: torch.Tensor, device) -> PackedLinear:
+    """w fp32 [N, K] or [G, N, K]; scale_g = max|W_g| / 127.5, W_q = clamp(rne(W * (1/scale)), -128, 127)."""
+    if w.dim() == 2:
+        w = w.unsqueeze(0)
+    w = w.to(device=device, dtype=torch.float32)
+    # max is exact anywhere; the two divisions are done on the host, where fp32 division is correctly rounded
+    # (the device's fp32 divide in torch is not), so the scale is bit-identical to the CPU quantizer's.
+    amax = w.abs().amax(dim=(1, 2)).cpu()
+    scale = torch.clamp(amax / 127.5, min=torch.finfo(torch.float32).eps)
+    inv = (1.0 / scale).view(-1, 1, 1).to(w.device)
+    q = torch.clamp(torch.round(w * inv), -128, 127).to(torch.int8).contiguous()
+    return PackedLinear(q, scale.to(w.device).contiguous())
+
+
+def rope_table(max_pos: int, head_dim: int, theta: float) -> torch.Tensor:
+    """[max_pos, head_dim] = cos(head_dim/2) | sin(head_dim/2), computed on the host with the reference's formula
+    (models/complexity_deep/model.py:27-37) so that the fp32 table entries are the reference's own values."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2).float() / head_dim))
+    freqs = torch.outer(torch.arange(max_pos).float(), inv_freq)
+    return torch.cat([freqs.cos(), freqs.sin()], dim=-1).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# paged KV cache: reference layout (num_blocks, 16, kv_heads, head_dim) + int32 block table (core/kv_cache.py:84-107)
+# ---------------------------------------------------------------------------------------------------------
+class PagedKVCache:
+    def __init__(self, cfg: ModelConfig, num_blocks: int, max_seqs: int, device, dtype=torch.float32):
+        self.cfg, self.block, self.device, self.dtype = cfg, cfg.kv_block, device, dtype
+        shape = (num_blocks, cfg.kv_block, cfg.num_kv_heads, cfg.head_dim)
+        self.k = [torch.zeros(shape, dtype=dtype, device=device) for _ in range(cfg.num_layers)]
+        self.v = [torch.zeros(shape, dtype=dtype, device=device) for _ in range(cfg.num_layers)]
+        self.max_blocks_per_seq = (cfg.max_pos + cfg.kv_block - 1) // cfg.kv_block
+        self._bt_host = torch.full((max_seqs, self.max_blocks_per_seq), -1, dtype=torch.int32)
+        self.block_table = self._bt_host.to(device)
+        self._free = list(range(num_blocks - 1, -1, -1))
+        self._owned: Dict[int, int] = {}
+
+    def reserve(self, slot: int, length: int):
+        """Make sure sequence `slot` owns blocks for positions [0, length). Host bookkeeping + one small upload."""
+        need = (length + self.block - 1) // self.block
+        have = self._owned.get(slot, 0)
+        if need <= have:
+            return
+        if need > self.max_blocks_per_seq:
+            raise RuntimeError(f"sequence length {length} exceeds max_pos {self.cfg.max_pos}")
+        if need - have > len(self._free):
+            raise RuntimeError("paged KV cache exhausted")
+        for b in range(have, need):
+            self._bt_host[slot, b] = self._free.pop()
+        self._owned[slot] = need
+        self.block_table[slot].copy_(self._bt_host[slot], non_blocking=True)
+
+    def free(self, slot: int):
+        for b in range(self._owned.pop(slot, 0)):
+            self._free.append(int(self._bt_host[slot, b]))
+            self._bt_host[slot, b] = -1
+        self.block_table[slot].copy_(self._bt_host[slot], non_blocking=True)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the model
+# ---------------------------------------------------------------------------------------------------------
+class _Buffers:
+    """Per-step device buffers for N tokens (allocated once per N, reused: graph-safe)."""
+
+    def __init__(self, cfg: ModelConfig, n: int, n_logit_rows: int, device):
+        H, R = cfg.hidden_size, n * cfg.top_k
+        f32 = dict(dtype=torch.float32, device=device)
+        i8 = dict(dtype=torch.int8, device=device)
+        kvw = cfg.num_kv_heads * cfg.head_dim
+        self.h = torch.empty(n, H, **f32)
+        self.normed = torch.empty(n, H, **f32)
+        self.qkv = torch.empty(n, H + 2 * kvw, **f32)
+        self.q = torch.empty(n, cfg.num_heads, cfg.head_dim, **f32)
+        self.attn = torch.empty(n, cfg.num_heads, cfg.head_dim, **f32)
+        self.o = torch.empty(n, H, **f32)
+        self.xa = torch.empty(n, H, **i8)
+        self.xs = torch.empty(n, **f32)
+        if cfg.is_moe:
+            S, ei = cfg.shared_intermediate_size, cfg.expert_inter
+            self.ea = torch.empty(max(R, 1), H, **i8)
+            self.es = torch.empty(max(R, 1), **f32)
+            self.e_inter = torch.empty(max(R, 1), ei, **f32)
+            self.eia = torch.empty(max(R, 1), ei, **i8)
+            self.eis = torch.empty(max(R, 1), **f32)
+            self.e_out = torch.empty(max(R, 1), H, **f32)
+            if S:
+                self.sh_inter = torch.empty(n, S, **f32)
+                self.sha = torch.empty(n, S, **i8)
+                self.shs = torch.empty(n, **f32)
+                self.sh_out = torch.empty(n, H, **f32)
+            self.plan = ops.MoePlan(n, cfg.top_k, cfg.num_experts, cfg.num_layers, device)
+        else:
+            I = cfg.intermediate_size
+            self.d_inter = torch.empty(n, I, **f32)
+            self.da = torch.empty(n, I, **i8)
+            self.ds = torch.empty(n, **f32)
+            self.d_out = torch.empty(n, H, **f32)
+        self.logits = torch.empty(n_logit_rows, cfg.vocab_size, **f32)
+        self.attn_ws: Optional[torch.Tensor] = None
+        self.attn_splits = 1
+
+
+class I64MoEModel:
+    def __init__(self, cfg: ModelConfig, weights: Dict[str, torch.Tensor], device="cuda:0", kv_dtype=torch.float32,
+                 max_seqs: int = 64, num_kv_blocks: Optional[int] = None):
+        self.cfg, self.device = cfg, torch.device(device)
+        dev = self.device
+        f = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
+        self.embed = f(weights["embed"])
+        self.final_norm = f(weights["final_norm"])
+        self.layers: List[dict] = []
+        tables = []
+        for l in range(cfg.num_layers):
+            p = f"l{l}."
+            d = dict(ln1=f(weights[p + "ln1"]), ln2=f(weights[p + "ln2"]), q_norm=f(weights[p + "q_norm"]),
+                     k_norm=f(weights[p + "k_norm"]), qkv=pack_per_tensor(weights[p + "qkv"], dev), o=pack_per_tensor(weights[p + "o"], dev))
+            if cfg.is_moe:
+                d["exp_gu"] = pack_per_tensor(weights[p + "exp_gate_up"], dev)
+                d["exp_dn"] = pack_per_tensor(weights[p + "exp_down"], dev)
+                if cfg.shared_intermediate_size:
+                    d["sh_gu"] = pack_per_tensor(weights[p + "sh_gate_up"], dev)
+                    d["sh_dn"] = pack_per_tensor(weights[p + "sh_down"], dev)
+                tables.append(weights[p + "table"].to(torch.int64))
+            else:
+                d["gu"] = pack_per_tensor(weights[p + "gate_up"], dev)
+                d["dn"] = pack_per_tensor(weights[p + "down"], dev)
+            self.layers.append(d)
+        self.tables = torch.stack(tables).to(dev).contiguous() if tables else None  # [L, top_k, V] int64
+        self.rope = rope_table(cfg.max_pos, cfg.head_dim, cfg.rope_theta).to(dev)
+        nb = num_kv_blocks or max_seqs * ((cfg.max_pos + cfg.kv_block - 1) // cfg.kv_block)
+        self.kv = PagedKVCache(cfg, nb, max_seqs, dev, kv_dtype)
+        self.nb = cfg.num_experts * cfg.top_k if cfg.is_moe else 0
+        self.spl = 4 + 2 * self.nb if cfg.is_moe else 4       # stat slots per layer
+        self.stats = ops.stats_alloc(self.spl * cfg.num_layers + 1, dev)
+        self._bufs: Dict[tuple, _Buffers] = {}
+
+    # ---- helpers ----
+    def buffers(self, n: int, n_logit_rows: int) -> _Buffers:
+        key = (n, n_logit_rows)
+        if key not in self._bufs:
+            self._bufs[key] = _Buffers(self.cfg, n, n_logit_rows, self.device)
+        return self._bufs[key]
+
+    def _linear(self, x, pl: PackedLinear, slot: int, xa, xs, out, epilogue=ops.EPI_STORE, stats_slot: Optional[int] = None):
+        """One dense dynamic-int8 Linear call: quantize with the call's statistics, int8 GEMM, fp32 rescale."""
+        ops_call = ops.call
+        n, K = x.shape
+        ops_call("i64h_quantize_dynamic", ops.ptr(x), n, K, 0, 0, 0, slot, ops.ptr(self.stats), ops.ptr(xa), ops.ptr(xs), 0, ops._stream())
+        ops.gemm_i8(xa, xs, pl.w_q, pl.w_s, epilogue=epilogue, slot_base=stats_slot or 0,
+                    stats=self.stats if stats_slot is not None else None, out=out)
+        return out
+
+    # ---- one forward (prefill chunk or decode step) ----
+    def forward(self, token_ids: torch.Tensor, positions: torch.Tensor, slot_ids: torch.Tensor, ctx_len: torch.Tensor,
+                logit_rows: Optional[torch.Tensor] = None, max_ctx_hint: int = 0, record: Optional[dict] = None,
+                inject: Optional[Dict[int, torch.Tensor]] = None) -> torch.Tensor:
+        """token_ids int64 [N]; positions / slot_ids / ctx_len int32 [N] (ctx_len = position + 1 for causal rows);
+        logit_rows int32 [M] selects the rows whose logits are wanted (None = all).  Returns fp32 logits [M, V].
+        record: dict filled with per-layer activations; inject: {layer: hidden [N, H]} replaces the residual stream at the
+        entry of a layer (teacher forcing for per-layer parity tests)."""
+        cfg, st = self.cfg, self.stats
+        n = token_ids.numel()
+        B = self.buffers(n, logit_rows.numel() if logit_rows is not None else n)
+        H, nbk, spl = cfg.hidden_size, self.nb, self.spl
+        eps = cfg.rms_eps
+        rw = cfg.route_weights
+        if cfg.is_moe:
+            B.plan.run(token_ids, self.tables)
+        ops.stats_reset(st)
+        ops.embedding(token_ids, self.embed, out=B.h)
+        # attention splits: enough workgroups to fill the chip when few rows carry long contexts
+        splits = 1
+        if max_ctx_hint > 0 and n * cfg.num_kv_heads < 1024:
+            splits = max(1, min(16, 1024 // max(1, n * cfg.num_kv_heads), (max_ctx_hint + 255) // 256))
+        if splits > 1 and (B.attn_ws is None or B.attn_splits != splits):
+            B.attn_ws = torch.empty(ops._lib.load().i64h_paged_attn_workspace_floats(n, cfg.num_heads, cfg.head_dim, splits),
+                                    dtype=torch.float32, device=self.device)
+            B.attn_splits = splits
+        ops.fused_residual_norm(B.h, self.layers[0]["ln1"], eps, h_out=B.h, normed=B.normed, slot_base=0, stats=st)
+        for l, W in enumerate(self.layers):
+            base = l * spl
+            if inject is not None and l in inject:
+                B.h.copy_(inject[l])
+                ops.stats_reset(st[2 * base: 2 * base + 2])
+                ops.fused_residual_norm(B.h, W["ln1"], eps, h_out=B.h, normed=B.normed, slot_base=base, stats=st)
+            if record is not None:
+                record[f"l{l}.in"] = B.h.clone()
+            self._linear(B.normed, W["qkv"], base + 0, B.xa, B.xs, B.qkv)
+            ops.qk_norm_rope_kv(B.qkv, W["q_norm"], W["k_norm"], 1e-6, self.rope, positions, slot_ids, self.kv.block_table,
+                                self.kv.k[l], self.kv.v[l], cfg.num_heads, cfg.num_kv_heads, cfg.head_dim, q_out=B.q)
+            ops.paged_attn(B.q, self.kv.k[l], self.kv.v[l], self.kv.block_table, ctx_len, slot_ids=slot_ids,
+                           softmax_scale=1.0 / math.sqrt(cfg.head_dim), splits=splits, out=B.attn, workspace=B.attn_ws)
+            attn2d = B.attn.view(n, H)
+            if record is not None:
+                record[f"l{l}.attn_out"] = attn2d.clone()
+            ops.rows_minmax(attn2d, st, slot_base=base + 1)
+            self._linear(attn2d, W["o"], base + 1, B.xa, B.xs, B.o)
+            if cfg.is_moe:
+                # h += o ; normed = ln2(h) ; statistics for the shared call and for every (route, expert) bucket
+                ops.fused_residual_norm(B.h, W["ln2"], eps, add=B.o, h_out=B.h, normed=B.normed, slots=B.plan.tok_slots[l],
+                                        slot_base=base + 2, stats=st)
+                if record is not None:
+                    record[f"l{l}.mlp_in"] = B.normed.clone()
+                self._moe(B, W, l, base)
+                nxt = self.layers[l + 1]["ln1"] if l + 1 < cfg.num_layers else self.final_norm
+                last = l + 1 == cfg.num_layers
+                ops.fused_residual_norm(B.h, nxt, eps, moe_rows=B.e_out, moe_inv=B.plan.inv[l],
+                                        moe_shared=B.sh_out if cfg.shared_intermediate_size else None, route_weights=rw,
+                                        routed_scale=cfg.routed_scale, shared_scale=cfg.shared_scale, h_out=B.h, normed=B.normed,
+                                        slot_base=base + spl, stats=None if last else st)
+                if record is not None:
+                    record[f"l{l}.out"] = B.h.clone()
+            else:
+                ops.fused_residual_norm(B.h, W["ln2"], eps, add=B.o, h_out=B.h, normed=B.normed, slot_base=base + 2, stats=st)
+                if record is not None:
+                    record[f"l{l}.mlp_in"] = B.normed.clone()
+                self._linear(B.normed, W["gu"], base + 2, B.xa, B.xs, B.d_inter, epilogue=ops.EPI_SWIGLU, stats_slot=base + 3)
+                self._linear(B.d_inter, W["dn"], base + 3, B.da, B.ds, B.d_out)
+                nxt = self.layers[l + 1]["ln1"] if l + 1 < cfg.num_layers else self.final_norm
+                last = l + 1 == cfg.num_layers
+                ops.fused_residual_norm(B.h, nxt, eps, add=B.d_out, h_out=B.h, normed=B.normed, slot_base=base + spl,
+                                        stats=None if last else st)
+                if record is not None:
+                    record[f"l{l}.out"] = B.h.clone()
+        ops.call("i64h_gemm_f32", ops.ptr(B.normed), ops.ptr(logit_rows), ops.ptr(self.embed), ops.ptr(B.logits), B.logits.shape[0],
+                 cfg.vocab_size, H, ops._stream())
+        return B.logits
+
+    def _moe(self, B: _Buffers, W: dict, l: int, base: int):
+        """Routed experts (grouped by expert, rows in bucket order) + shared expert; outputs stay in B.e_out / B.sh_out and
+        are combined by the next fused_residual_norm (token_routed_mlp.py:154-187)."""
+        cfg, st, nbk = self.cfg, self.stats, self.nb
+        plan = B.plan
+        n, R = plan.n, plan.rows
+        if cfg.shared_intermediate_size:
+            self._linear(B.normed, W["sh_gu"], base + 2, B.xa, B.xs, B.sh_inter, epilogue=ops.EPI_SWIGLU, stats_slot=base + 3 + nbk)
+            self._linear(B.sh_inter, W["sh_dn"], base + 3 + nbk, B.sha, B.shs, B.sh_out)
+        if R == 0:
+            return
+        # every (route, expert) bucket is its own Linear call: rows gathered in bucket order, bucket statistics
+        ops.call("i64h_quantize_dynamic", ops.ptr(B.normed), R, cfg.hidden_size, ops.ptr(plan.perm[l]), n, ops.ptr(plan.sorted_bucket[l]),
+                 base + 3, ops.ptr(st), ops.ptr(B.ea), ops.ptr(B.es), 0, ops._stream())
+        ops.gemm_i8(B.ea, B.es, W["exp_gu"].w_q, W["exp_gu"].w_s, group_offsets=plan.expert_offsets[l], epilogue=ops.EPI_SWIGLU,
+                    row_slot=plan.sorted_bucket[l], slot_base=base + 4 + nbk, stats=st, out=B.e_inter)
+        ops.call("i64h_quantize_dynamic", ops.ptr(B.e_inter), R, cfg.expert_inter, 0, 0, ops.ptr(plan.sorted_bucket[l]), base + 4 + nbk,
+                 ops.ptr(st), ops.ptr(B.eia), ops.ptr(B.eis), 0, ops._stream())
+        ops.gemm_i8(B.eia, B.eis, W["exp_dn"].w_q, W["exp_dn"].w_s, group_offsets=plan.expert_offsets[l], out=B.e_out)
+
+    # ---- stand-alone MoE layer (operator form of TokenRoutedMLP.forward) ----
+    def moe_layer(self, l: int, x: torch.Tensor, token_ids: torch.Tensor) -> torch.Tensor:
+        """out = TokenRoutedMLP_l(x, token_ids) with int8 dynamic Linears; x fp32 [N, H]."""
+        cfg = self.cfg
+        n = x.shape[0]
+        B = self.buffers(n, n)
+        B.plan.run(token_ids, self.tables)
+        ops.stats_reset(self.stats)
+        base = l * self.spl
+        B.normed.copy_(x)
+        ops.rows_minmax(B.normed, self.stats, slots=B.plan.tok_slots[l], slot_base=base + 2)
+        self._moe(B, self.layers[l], l, base)
+        zero = torch.zeros_like(x)
+        out, _ = ops.fused_residual_norm(zero, None, cfg.rms_eps, moe_rows=B.e_out, moe_inv=B.plan.inv[l],
+                                         moe_shared=B.sh_out if cfg.shared_intermediate_size else None,
+                                         route_weights=cfg.route_weights, routed_scale=cfg.routed_scale,
+                                         shared_scale=cfg.shared_scale, want_normed=False)
+        return out
+
+
+class GreedyDecoder:
+    """Batch greedy decoding with the CPUEngine's step shapes (vllm_i64/cpu/engine.py:95-134): one prefill step over all
+    prompts, then one token per sequence per step.  The decode step (forward + argmax + position advance) is captured
+    once into a HIP graph and replayed; nothing returns to the host inside a step."""
+
+    def __init__(self, model: I64MoEModel, batch: int, use_graph: bool = True):
+        self.m, self.batch, self.use_graph = model, batch, use_graph
+        dev = model.device
+        self.tokens = torch.zeros(batch, dtype=torch.int64, device=dev)
+        self.positions = torch.zeros(batch, dtype=torch.int32, device=dev)
+        self.ctx_len = torch.zeros(batch, dtype=torch.int32, device=dev)
+        self.slot_ids = torch.arange(batch, dtype=torch.int32, device=dev)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.logits: Optional[torch.Tensor] = None
+        self.max_ctx_hint = 0
+
+    def prefill(self, prompts: Sequence[torch.Tensor], reserve_extra: int = 0) -> torch.Tensor:
+        m, dev = self.m, self.m.device
+        lens = [int(p.numel()) for p in prompts]
+        for s, n in enumerate(lens):
+            m.kv.reserve(s, n + reserve_extra)
+        ids = torch.cat([p.to(torch.int64) for p in prompts]).to(dev)
+        pos = torch.cat([torch.arange(n, dtype=torch.int32) for n in lens]).to(dev)
+        slots = torch.cat([torch.full((n,), s, dtype=torch.int32) for s, n in enumerate(lens)]).to(dev)
+        last = (torch.cumsum(torch.tensor(lens), 0) - 1).to(torch.int32).to(dev)
+        logits = m.forward(ids, pos, slots, (pos + 1).contiguous(), logit_rows=last, max_ctx_hint=0)
+        self.positions.copy_(torch.tensor(lens, dtype=torch.int32))
+        self.ctx_len.copy_(torch.tensor(lens, dtype=torch.int32) + 1)
+        self.max_ctx_hint = max(lens) + reserve_extra
+        ops.argmax_rows(logits, out=self.tokens)
+        return logits
+
+    def set_state(self, tokens: torch.Tensor, lens: Sequence[int], reserve_extra: int = 0):
+        """Start decoding from an externally filled cache: next input token and current length per sequence."""
+        for s, n in enumerate(lens):
+            self.m.kv.reserve(s, n + reserve_extra)
+        self.tokens.copy_(tokens.to(torch.int64))
+        self.positions.copy_(torch.tensor(list(lens), dtype=torch.int32))
+        self.ctx_len.copy_(torch.tensor(list(lens), dtype=torch.int32) + 1)
+        self.max_ctx_hint = max(lens) + reserve_extra
+
+    def _step_body(self):
+        self.logits = self.m.forward(self.tokens, self.positions, self.slot_ids, self.ctx_len, max_ctx_hint=self.max_ctx_hint)
+        ops.argmax_rows(self.logits, out=self.tokens)
+        ops.advance(self.positions, self.ctx_len)
+
+    def step(self) -> torch.Tensor:
+        """One decode step for the whole batch; returns the logits of the step (valid until the next step)."""
+        if not self.use_graph:
+            self._step_body()
+            return self.logits
+        if self.graph is None:
+            # warm up eagerly on a side stream (allocates every buffer), restoring the state afterwards, then capture
+            state = (self.tokens.clone(), self.positions.clone(), self.ctx_len.clone())
+            s = torch.cuda.Stream(device=self.m.device)
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self._step_body()
+            torch.cuda.current_stream().wait_stream(s)
+            for dst, src in zip((self.tokens, self.positions, self.ctx_len), state):
+                dst.copy_(src)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._step_body()
+            for dst, src in zip((self.tokens, self.positions, self.ctx_len), state):
+                dst.copy_(src)
+        self.graph.replay()
+        return self.logits

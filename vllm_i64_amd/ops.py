@@ -1,0 +1,345 @@
+"""Torch-facing wrappers over the C ABI: allocate outputs with torch, launch on torch's current HIP stream.
+
+torch is plumbing here (device memory, streams); all compute is in libi64hip.so.  Nothing in this module falls
+back to torch math: a missing library or a non-GPU tensor raises.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Tuple
+
+import ctypes
+import torch
+
+from . import _lib
+from ._lib import call, ptr
+
+KV_DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+EPI_STORE, EPI_SWIGLU = 0, 1
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, dtype=None, name="tensor"):
+    if not t.is_cuda:
+        raise _lib.I64HError(f"{name}: expected a GPU tensor (this package has no CPU path)")
+    if dtype is not None and t.dtype != dtype:
+        raise _lib.I64HError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.I64HError(f"{name}: expected a contiguous tensor")
+    return t
+
+
+# ---- routing ---------------------------------------------------------------------------------------------
+def route_tokens(token_ids: torch.Tensor, num_experts: int) -> torch.Tensor:
+    _chk(token_ids, torch.int64, "token_ids")
+    out = torch.empty(token_ids.numel(), dtype=torch.int32, device=token_ids.device)
+    call("i64h_route_tokens", ptr(token_ids), ptr(out), token_ids.numel(), num_experts, _stream())
+    return out
+
+
+def route_lookup(token_ids: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+    _chk(token_ids, torch.int64, "token_ids"), _chk(table, torch.int64, "table")
+    top_k, V = table.shape
+    n = token_ids.numel()
+    routes = torch.empty(top_k, n, dtype=torch.int64, device=token_ids.device)
+    call("i64h_route_lookup", ptr(token_ids), ptr(table), ptr(routes), n, top_k, V, _stream())
+    return routes
+
+
+def bucketize(keys: torch.Tensor, num_buckets: int):
+    """Stable grouping: returns (offsets[nb+1], perm, inv, sorted_bucket), all int32."""
+    _chk(keys, torch.int32, "keys")
+    n, dev = keys.numel(), keys.device
+    lib = _lib.load()
+    ws = torch.empty(max(1, lib.i64h_bucketize_workspace_bytes(n, num_buckets, 1) // 4), dtype=torch.int32, device=dev)
+    kcopy = torch.empty(n, dtype=torch.int32, device=dev)
+    offsets = torch.empty(num_buckets + 1, dtype=torch.int32, device=dev)
+    perm = torch.empty(n, dtype=torch.int32, device=dev)
+    inv = torch.empty(n, dtype=torch.int32, device=dev)
+    sb = torch.empty(n, dtype=torch.int32, device=dev)
+    call("i64h_bucketize", ptr(keys), ptr(kcopy), ptr(offsets), ptr(perm), ptr(inv), ptr(sb), ptr(ws), n, num_buckets, _stream())
+    return offsets, perm, inv, sb
+
+
+class MoePlan:
+    """Routing plan of one forward for all layers (see i64h_moe_plan)."""
+
+    def __init__(self, n: int, top_k: int, num_experts: int, layers: int, device, with_routes: bool = False):
+        self.n, self.top_k, self.E, self.L = n, top_k, num_experts, layers
+        R, nb = n * top_k, num_experts * top_k
+        self.rows, self.nb = R, nb
+        i32 = dict(dtype=torch.int32, device=device)
+        self.routes = torch.empty(layers, top_k, n, dtype=torch.int64, device=device) if with_routes else None
+        self.keys = torch.empty(layers, max(R, 1), **i32)
+        self.offsets = torch.empty(layers, nb + 1, **i32)
+        self.perm = torch.empty(layers, max(R, 1), **i32)
+        self.inv = torch.empty(layers, max(R, 1), **i32)
+        self.sorted_bucket = torch.empty(layers, max(R, 1), **i32)
+        self.expert_offsets = torch.empty(layers, num_experts + 1, **i32)
+        self.tok_slots = torch.empty(layers, max(n, 1), 1 + top_k, **i32)
+        lib = _lib.load()
+        self.ws = torch.empty(max(1, lib.i64h_bucketize_workspace_bytes(R, nb, layers) // 4), **i32)
+
+    def run(self, token_ids: torch.Tensor, tables: torch.Tensor):
+        """tables: int64 [L, top_k, V] contiguous."""
+        _chk(token_ids, torch.int64, "token_ids"), _chk(tables, torch.int64, "tables")
+        L, top_k, V = tables.shape
+        assert L == self.L and top_k == self.top_k and token_ids.numel() == self.n
+        call("i64h_moe_plan", ptr(token_ids), ptr(tables), top_k * V, ptr(self.routes), ptr(self.keys), ptr(self.tok_slots),
+             ptr(self.offsets), ptr(self.expert_offsets), ptr(self.perm), ptr(self.inv), ptr(self.sorted_bucket), ptr(self.ws),
+             self.n, top_k, V, self.E, L, _stream())
+        return self
+
+
+def gather_rows(src: torch.Tensor, idx: Optional[torch.Tensor], n_rows: Optional[int] = None) -> torch.Tensor:
+    _chk(src, None, "src")
+    if idx is not None:
+        _chk(idx, torch.int32, "idx")
+    n = idx.numel() if idx is not None else (n_rows if n_rows is not None else src.shape[0])
+    out = torch.empty((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    row_bytes = src[0].numel() * src.element_size() if src.shape[0] > 0 else 0
+    if n and row_bytes:
+        call("i64h_gather_rows", ptr(src), ptr(idx), ptr(out), n, row_bytes, _stream())
+    return out
+
+
+def silu_mul(gate_up: torch.Tensor, inter: int) -> torch.Tensor:
+    _chk(gate_up, None, "gate_up")
+    code = KV_DTYPE_CODE[gate_up.dtype]
+    n = gate_up.shape[0]
+    out = torch.empty(n, inter, dtype=gate_up.dtype, device=gate_up.device)
+    call("i64h_silu_mul", ptr(gate_up), ptr(out), n, inter, code, _stream())
+    return out
+
+
+# ---- dynamic quantization -----------------------------------------------------------------------------------
+def stats_alloc(n_slots: int, device) -> torch.Tensor:
+    """uint32 pairs stored in an int32 tensor (torch has no uint32 arithmetic; only the bits matter)."""
+    return torch.empty(2 * n_slots, dtype=torch.int32, device=device)
+
+
+def stats_reset(stats: torch.Tensor):
+    call("i64h_stats_reset", ptr(stats), stats.numel() // 2, _stream())
+
+
+def rows_minmax(x: torch.Tensor, stats: torch.Tensor, slots: Optional[torch.Tensor] = None, slot_base: int = 0):
+    _chk(x, torch.float32, "x")
+    rows, K = x.shape
+    spr = 1 if slots is None else (slots.shape[1] if slots.dim() == 2 else 1)
+    call("i64h_rows_minmax", ptr(x), rows, K, ptr(slots), spr, slot_base, ptr(stats), _stream())
+
+
+def quantize_dynamic(x: torch.Tensor, stats: torch.Tensor, slot_base: int = 0, src_row: Optional[torch.Tensor] = None,
+                     src_mod: int = 0, row_slot: Optional[torch.Tensor] = None, out_rows: Optional[int] = None,
+                     want_zp: bool = False):
+    _chk(x, torch.float32, "x")
+    K = x.shape[1]
+    R = out_rows if out_rows is not None else (src_row.numel() if src_row is not None else x.shape[0])
+    a = torch.empty(R, K, dtype=torch.int8, device=x.device)
+    scale = torch.empty(R, dtype=torch.float32, device=x.device)
+    zp = torch.empty(R, dtype=torch.int32, device=x.device) if want_zp else None
+    call("i64h_quantize_dynamic", ptr(x), R, K, ptr(src_row), src_mod, ptr(row_slot), slot_base, ptr(stats), ptr(a), ptr(scale),
+         ptr(zp), _stream())
+    return (a, scale, zp) if want_zp else (a, scale)
+
+
+def qparams(stats: torch.Tensor, n_slots: int):
+    dev = stats.device
+    scale = torch.empty(n_slots, dtype=torch.float32, device=dev)
+    zp = torch.empty(n_slots, dtype=torch.int32, device=dev)
+    lohi = torch.empty(n_slots, 2, dtype=torch.float32, device=dev)
+    call("i64h_qparams", ptr(stats), n_slots, ptr(scale), ptr(zp), ptr(lohi), _stream())
+    return scale, zp, lohi
+
+
+# ---- symmetric per-row int8 (operator API) --------------------------------------------------------------------
+def quant_rows(x: torch.Tensor):
+    _chk(x, torch.float32, "x")
+    rows, K = x.shape
+    q = torch.empty(rows, K, dtype=torch.int8, device=x.device)
+    s = torch.empty(rows, dtype=torch.float32, device=x.device)
+    call("i64h_quant_rows", ptr(x), ptr(q), ptr(s), rows, K, _stream())
+    return q, s
+
+
+def dequant_rows(q: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    _chk(q, torch.int8, "q"), _chk(scale, torch.float32, "scale")
+    rows, K = q.shape
+    out = torch.empty(rows, K, dtype=torch.float32, device=q.device)
+    call("i64h_dequant_rows", ptr(q), ptr(scale), ptr(out), rows, K, _stream())
+    return out
+
+
+def rmsnorm_quant(x: torch.Tensor, weight: torch.Tensor, eps: float):
+    _chk(x, torch.float32, "x"), _chk(weight, torch.float32, "weight")
+    rows, H = x.shape
+    q = torch.empty(rows, H, dtype=torch.int8, device=x.device)
+    s = torch.empty(rows, dtype=torch.float32, device=x.device)
+    call("i64h_rmsnorm_quant", ptr(x), ptr(weight), float(eps), ptr(q), ptr(s), rows, H, _stream())
+    return q, s
+
+
+# ---- contractions ---------------------------------------------------------------------------------------------
+def gemm_i8(a: torch.Tensor, row_scale: torch.Tensor, w: torch.Tensor, w_scale: torch.Tensor,
+            group_offsets: Optional[torch.Tensor] = None, epilogue: int = EPI_STORE, row_slot: Optional[torch.Tensor] = None,
+            slot_base: int = 0, stats: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a int8 [M, K]; w int8 [G, N, K] (or [N, K]); w_scale fp32 [G]."""
+    _chk(a, torch.int8, "a"), _chk(w, torch.int8, "w"), _chk(row_scale, torch.float32, "row_scale")
+    _chk(w_scale, torch.float32, "w_scale")
+    if w.dim() == 2:
+        w = w.unsqueeze(0)
+    G, N, K = w.shape
+    M = a.shape[0]
+    assert a.shape[1] == K
+    n_out = N // 2 if epilogue == EPI_SWIGLU else N
+    if out is None:
+        out = torch.empty(M, n_out, dtype=torch.float32, device=a.device)
+    call("i64h_gemm_i8", ptr(a), ptr(row_scale), ptr(w), ptr(w_scale), ptr(group_offsets), G, M, N, K, ptr(out), epilogue,
+         ptr(row_slot), slot_base, ptr(stats), _stream())
+    return out
+
+
+def gemm_f32(a: torch.Tensor, b: torch.Tensor, a_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(a, torch.float32, "a"), _chk(b, torch.float32, "b")
+    M = a_rows.numel() if a_rows is not None else a.shape[0]
+    N, K = b.shape
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    call("i64h_gemm_f32", ptr(a), ptr(a_rows), ptr(b), ptr(out), M, N, K, _stream())
+    return out
+
+
+def gemm_w8a32(x: torch.Tensor, w: torch.Tensor, w_scale: torch.Tensor) -> torch.Tensor:
+    _chk(x, torch.float32, "x"), _chk(w, torch.int8, "w"), _chk(w_scale, torch.float32, "w_scale")
+    M, K = x.shape
+    N = w.shape[0]
+    out = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    call("i64h_gemm_w8a32", ptr(x), ptr(w), ptr(w_scale), ptr(out), M, N, K, _stream())
+    return out
+
+
+def gemm_w8a32_swiglu(x, gate_w, gate_s, up_w, up_s) -> torch.Tensor:
+    _chk(x, torch.float32, "x"), _chk(gate_w, torch.int8, "gate_w"), _chk(up_w, torch.int8, "up_w")
+    M, K = x.shape
+    I = gate_w.shape[0]
+    out = torch.empty(M, I, dtype=torch.float32, device=x.device)
+    call("i64h_gemm_w8a32_swiglu", ptr(x), ptr(gate_w), ptr(gate_s), ptr(up_w), ptr(up_s), ptr(out), M, I, K, _stream())
+    return out
+
+
+# ---- row kernels ------------------------------------------------------------------------------------------------
+def embedding(ids: torch.Tensor, table: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(ids, torch.int64, "ids"), _chk(table, torch.float32, "table")
+    V, H = table.shape
+    n = ids.numel()
+    if out is None:
+        out = torch.empty(n, H, dtype=torch.float32, device=table.device)
+    call("i64h_embedding", ptr(ids), ptr(table), ptr(out), n, H, V, _stream())
+    return out
+
+
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    _chk(x, torch.float32, "x"), _chk(weight, torch.float32, "weight")
+    rows, H = x.shape
+    out = torch.empty_like(x)
+    call("i64h_rmsnorm", ptr(x), ptr(weight), ptr(out), rows, H, float(eps), _stream())
+    return out
+
+
+def fused_residual_norm(h: torch.Tensor, norm_weight: Optional[torch.Tensor], eps: float, add: Optional[torch.Tensor] = None,
+                        moe_rows: Optional[torch.Tensor] = None, moe_inv: Optional[torch.Tensor] = None,
+                        moe_shared: Optional[torch.Tensor] = None, route_weights: Sequence[float] = (), routed_scale: float = 1.0,
+                        shared_scale: float = 1.0, h_out: Optional[torch.Tensor] = None, normed: Optional[torch.Tensor] = None,
+                        want_normed: bool = True, slots: Optional[torch.Tensor] = None, slot_base: int = 0,
+                        stats: Optional[torch.Tensor] = None):
+    _chk(h, torch.float32, "h")
+    n, H = h.shape
+    if h_out is None:
+        h_out = torch.empty_like(h)
+    if want_normed and normed is None:
+        normed = torch.empty_like(h)
+    rw = (ctypes.c_float * 8)(*([float(w) for w in route_weights] + [0.0] * (8 - len(route_weights))))
+    spr = 1 if slots is None else (slots.shape[1] if slots.dim() == 2 else 1)
+    call("i64h_fused_residual_norm", ptr(h), ptr(add), ptr(moe_rows), ptr(moe_inv), ptr(moe_shared), ctypes.addressof(rw),
+         len(route_weights), float(routed_scale), float(shared_scale), ptr(h_out), ptr(norm_weight), float(eps),
+         ptr(normed) if want_normed else 0, n, H, ptr(slots), spr, slot_base, ptr(stats), _stream())
+    return h_out, normed
+
+
+def qk_norm_rope_kv(qkv, q_norm_w, k_norm_w, qk_eps, rope_tab, positions, slot_ids, block_table, k_cache, v_cache,
+                    num_heads: int, num_kv_heads: int, head_dim: int, q_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(qkv, torch.float32, "qkv"), _chk(positions, torch.int32, "positions"), _chk(slot_ids, torch.int32, "slot_ids")
+    _chk(block_table, torch.int32, "block_table"), _chk(rope_tab, torch.float32, "rope_tab")
+    n = qkv.shape[0]
+    if q_out is None:
+        q_out = torch.empty(n, num_heads, head_dim, dtype=torch.float32, device=qkv.device)
+    call("i64h_qk_norm_rope_kv", ptr(qkv), ptr(q_norm_w), ptr(k_norm_w), float(qk_eps), ptr(rope_tab), ptr(positions), ptr(slot_ids),
+         ptr(block_table), block_table.shape[1], ptr(q_out), ptr(k_cache), ptr(v_cache), KV_DTYPE_CODE[k_cache.dtype], n,
+         num_heads, num_kv_heads, head_dim, k_cache.shape[1], _stream())
+    return q_out
+
+
+def rope(x, cos, sin) -> torch.Tensor:
+    _chk(x, torch.float32, "x"), _chk(cos, torch.float32, "cos"), _chk(sin, torch.float32, "sin")
+    n, heads, hd = x.shape
+    out = torch.empty_like(x)
+    call("i64h_rope", ptr(x), ptr(cos), ptr(sin), ptr(out), n, heads, hd, _stream())
+    return out
+
+
+def rope_q14(x, cos_q14, sin_q14) -> torch.Tensor:
+    _chk(x, torch.float32, "x"), _chk(cos_q14, torch.int16, "cos_q14"), _chk(sin_q14, torch.int16, "sin_q14")
+    n, heads, hd = x.shape
+    out = torch.empty_like(x)
+    call("i64h_rope_q14", ptr(x), ptr(cos_q14), ptr(sin_q14), ptr(out), n, heads, hd, _stream())
+    return out
+
+
+def softmax_q7(logits: torch.Tensor, lut: torch.Tensor) -> torch.Tensor:
+    _chk(logits, torch.float32, "logits"), _chk(lut, torch.int32, "lut")
+    shape = logits.shape
+    x = logits.reshape(-1, shape[-1])
+    out = torch.empty_like(x)
+    call("i64h_softmax_q7", ptr(x), ptr(out), x.shape[0], x.shape[1], ptr(lut), _stream())
+    return out.reshape(shape)
+
+
+def silu_mul_q7(gate: torch.Tensor, up: torch.Tensor, lut: torch.Tensor) -> torch.Tensor:
+    _chk(gate, torch.float32, "gate"), _chk(up, torch.float32, "up"), _chk(lut, torch.int32, "lut")
+    out = torch.empty_like(gate)
+    call("i64h_silu_mul_q7", ptr(gate), ptr(up), ptr(out), gate.numel(), ptr(lut), _stream())
+    return out
+
+
+# ---- attention --------------------------------------------------------------------------------------------------
+def paged_attn(q, k_cache, v_cache, block_table, ctx_len, slot_ids=None, softmax_scale: Optional[float] = None, splits: int = 1,
+               out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(q, torch.float32, "q"), _chk(block_table, torch.int32, "block_table"), _chk(ctx_len, torch.int32, "ctx_len")
+    rows, nh, hd = q.shape
+    _, block, kvh, hd2 = k_cache.shape
+    assert hd == hd2
+    if softmax_scale is None:
+        softmax_scale = 1.0 / (hd ** 0.5)
+    if out is None:
+        out = torch.empty_like(q)
+    if splits > 1 and workspace is None:
+        workspace = torch.empty(_lib.load().i64h_paged_attn_workspace_floats(rows, nh, hd, splits), dtype=torch.float32, device=q.device)
+    call("i64h_paged_attn", ptr(q), ptr(k_cache), ptr(v_cache), KV_DTYPE_CODE[k_cache.dtype], ptr(block_table), block_table.shape[1],
+         ptr(slot_ids), ptr(ctx_len), float(softmax_scale), ptr(out), ptr(workspace), rows, nh, kvh, hd, block, splits, _stream())
+    return out
+
+
+# ---- greedy step glue ---------------------------------------------------------------------------------------------
+def argmax_rows(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(x, torch.float32, "x")
+    rows, D = x.shape
+    if out is None:
+        out = torch.empty(rows, dtype=torch.int64, device=x.device)
+    call("i64h_argmax_rows", ptr(x), ptr(out), rows, D, _stream())
+    return out
+
+
+def advance(positions: torch.Tensor, ctx_len: torch.Tensor):
+    _chk(positions, torch.int32, "positions"), _chk(ctx_len, torch.int32, "ctx_len")
+    call("i64h_advance", ptr(positions), ptr(ctx_len), positions.numel(), _stream())
