@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Headline benchmark: decode tokens/s of the int8 token-routed-MoE forward on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json configs[2]): `trhash500m-synth` (492.1 M parameters, E=8 top-2 hash-table routing, shared
+expert) with every Linear in the reference CPU engine's dynamic int8 scheme; 64 sequences per GPU, 2048-token prompts
+(real prefill, untimed, its rate reported separately), then K greedy decode steps of batch 64 (timed).  A "step" is
+one decode step of the whole batch: routing plan, 24 layers, lm_head, argmax, position advance - one HIP graph replay.
+With N GPUs every rank serves its own 64 sequences (weak scaling, no collective on the data path).
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec
+MFMA_I8_PEAK_TOPS = 5000.0  # dense int8 MFMA (2x the ~2.5 PF bf16 dense peak)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--prompt-len", type=int, default=2048)
+    ap.add_argument("--kv-dtype", default="bf16", choices=["bf16", "fp32", "fp16"])
+    ap.add_argument("--config", default="trhash500m-synth")
+    ap.add_argument("--prefill-chunk-seqs", type=int, default=8)
+    ap.add_argument("--synthetic-kv", action="store_true", help="fill the KV cache with random values instead of a real prefill")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--cpu-ctx", type=int, default=128)
+    ap.add_argument("--no-graph", action="store_true")
+    return ap.parse_args()
+
+
+def get_config(name):
+    from vllm_i64_amd import config as C
+    return {"trhash500m-synth": C.trhash500m_synth, "trmoe306-synth": C.trmoe306_synth, "dense306-synth": C.dense306_synth}[name]()
+
+
+def cpu_baseline(cfg, weights, batch, ctx, steps):
+    """The oracle's CPU engine (own model code + torch.ao dynamic int8 Linears = the reference's quantized kernels),
+    timed on this host's cores on a bounded sample: batch `batch`, context `ctx` (synthetic cache contents), `steps`
+    decode steps after 1 warm-up.  kind = "port"."""
+    from oracle import model_ref as M
+    ncores = len(os.sched_getaffinity(0))
+    ncores = min(ncores, int(os.environ.get("OMP_NUM_THREADS", ncores)))
+    torch.set_num_threads(ncores)
+    ocfg = M.SynthConfig(**{f: getattr(cfg, f) for f in M.SynthConfig.__dataclass_fields__ if hasattr(cfg, f)})
+    t0 = time.time()
+    eng = M.OracleEngine(ocfg, weights, mode="int8_torch", max_seqs=batch, num_blocks=batch * ((ctx + steps + 17) // 16 + 1))
+    g = torch.Generator().manual_seed(99)
+    for s in range(batch):
+        eng.kv.ensure(s, ctx + steps + 1)
+        eng.kv.seq_lens[s] = ctx
+    for l in range(ocfg.num_layers):
+        eng.kv.k[l].normal_(0, 1.0, generator=g)
+        eng.kv.v[l].normal_(0, 0.6, generator=g)
+    eng.lens = [ctx] * batch
+    tok = torch.randint(0, ocfg.vocab_size, (batch,), generator=g)
+    tok = eng.decode(tok).argmax(-1)  # warm-up (also builds the quantized modules lazily)
+    setup = time.time() - t0
+    t1 = time.time()
+    for _ in range(steps):
+        tok = eng.decode(tok).argmax(-1)
+    dt = time.time() - t1
+    return {"value": batch * steps / dt, "unit": "tokens/s", "cores": ncores, "kind": "port",
+            "sample": f"batch {batch}, context {ctx} (synthetic cache), {steps} greedy decode steps after 1 warm-up; "
+                      f"{dt / steps * 1e3:.0f} ms/step; setup {setup:.0f} s (weight packing + warm-up) untimed"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist_.init_process_group("nccl", device_id=dev)
+        dist = dist_
+
+    from vllm_i64_amd import _lib, ops, synth
+    from vllm_i64_amd.model import GreedyDecoder, I64MoEModel
+    lib = _lib.load()
+    if lib.i64h_device_check() != 0:
+        raise SystemExit(lib.i64h_last_error().decode())
+
+    cfg = get_config(args.config)
+    kv_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "fp16": torch.float16}[args.kv_dtype]
+    B, P = args.batch, args.prompt_len
+    assert P + args.steps + args.warmup + 2 <= cfg.max_pos, "prompt + decode steps exceed max_pos"
+    t0 = time.time()
+    weights = synth.make_weights(cfg, seed=0)
+    model = I64MoEModel(cfg, weights, device=dev, kv_dtype=kv_dtype, max_seqs=B)
+    t_setup = time.time() - t0
+    dec = GreedyDecoder(model, B, use_graph=not args.no_graph)
+    total_len = P + args.steps + args.warmup + 2
+
+    # ---- prefill (untimed for the headline; its own rate is reported) ----
+    prefill_tps = None
+    ids = synth.make_token_ids(cfg, B * P, seed=7 + rank).view(B, P)
+    if args.synthetic_kv:
+        g = torch.Generator(device=dev).manual_seed(5)
+        for l in range(cfg.num_layers):
+            model.kv.k[l].copy_(torch.randn(model.kv.k[l].shape, device=dev, generator=g).to(kv_dtype))
+            model.kv.v[l].copy_((0.6 * torch.randn(model.kv.v[l].shape, device=dev, generator=g)).to(kv_dtype))
+        dec.set_state(ids[:, -1].to(dev), [P] * B, reserve_extra=total_len - P)
+    else:
+        for s in range(B):
+            model.kv.reserve(s, total_len)
+        first = torch.empty(B, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        tp = time.time()
+        cs = args.prefill_chunk_seqs
+        for c0 in range(0, B, cs):
+            seqs = list(range(c0, min(B, c0 + cs)))
+            tok = ids[seqs].reshape(-1).to(dev)
+            pos = torch.arange(P, dtype=torch.int32).repeat(len(seqs)).to(dev)
+            slots = torch.tensor(seqs, dtype=torch.int32).repeat_interleave(P).to(dev)
+            last = (torch.arange(1, len(seqs) + 1, dtype=torch.int32) * P - 1).to(dev)
+            lg = model.forward(tok, pos, slots, (pos + 1).contiguous(), logit_rows=last)
+            first[c0:c0 + len(seqs)] = ops.argmax_rows(lg)
+        torch.cuda.synchronize()
+        prefill_tps = B * P / (time.time() - tp)
+        dec.set_state(first, [P] * B, reserve_extra=total_len - P)
+
+    # ---- decode: W warm-up steps, then exactly K timed steps ----
+    for _ in range(args.warmup):
+        dec.step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        dec.step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t1
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = B * world * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel: paged-KV attention of one layer, timed with HIP events on the launch stream ----
+    ctx_now = P + args.warmup + args.steps
+    kvb = {torch.bfloat16: 2, torch.float16: 2, torch.float32: 4}[kv_dtype]
+    Bf = model.buffers(B, B)
+    splits = Bf.attn_splits
+    evs = []
+    for rep in range(3):
+        for l in range(cfg.num_layers):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ops.paged_attn(Bf.q, model.kv.k[l], model.kv.v[l], model.kv.block_table, dec.ctx_len, slot_ids=dec.slot_ids,
+                           softmax_scale=cfg.head_dim ** -0.5, splits=splits, out=Bf.attn, workspace=Bf.attn_ws)
+            e1.record()
+            evs.append((e0, e1))
+    torch.cuda.synchronize()
+    attn_ms = sorted(a.elapsed_time(b) for a, b in evs[cfg.num_layers:])
+    attn_ms = sum(attn_ms) / len(attn_ms)
+    attn_bytes = B * ctx_now * cfg.num_kv_heads * cfg.head_dim * 2 * kvb  # K and V rows of every cached token, once
+    achieved = attn_bytes / (attn_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "paged_attn_kernel (+ attn_merge_kernel) of one layer", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_launch_ms": round(attn_ms, 4), "algorithmic_bytes_per_launch": attn_bytes, "splits": splits,
+                "share_of_step": round(attn_ms * cfg.num_layers / ms_per_step, 3)}
+
+    out = {
+        "metric": "decode tokens/sec tr-hash-moe-500m int8 batch64; % INT8-MFMA roofline", "value": round(value, 1), "unit": "tokens/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "int8 (i8 x i8 -> i32 MFMA, fp32 rescale; fp32 attention math)",
+        "data": "synthetic",
+        "config": {"workload": f"{cfg.name} int8 dynamic-Linear forward, batch {B} per GPU, {P}-token prompts"
+                               f"{' (synthetic KV)' if args.synthetic_kv else ' (real prefill)'} + greedy decode, KV cache {args.kv_dtype}",
+                   "global_batch": B * world, "seq_len": P, "parallelism": f"dp{world} (independent replicas, no collective)" if world > 1 else "single GPU",
+                   "kv_dtype": args.kv_dtype, "hip_graph": not args.no_graph},
+        "roofline": roofline,
+    }
+    if prefill_tps is not None:
+        out["prefill_tokens_per_s"] = round(prefill_tps, 1)
+    out["setup_s"] = round(t_setup, 1)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(cfg, weights, B, args.cpu_ctx, args.cpu_steps)
+            out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 2)
+        except Exception as e:  # the baseline is a reported extra; never lose the GPU line to it
+            out["cpu_baseline"] = {"error": repr(e)}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

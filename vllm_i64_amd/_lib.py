@@ -63,6 +63,9 @@ def load() -> ctypes.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own HIP runtime (same SONAME as ROCm's); import it first so that this process holds exactly one
+    # runtime and the stream handles torch hands out are valid inside libi64hip.so.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise I64HError(f"{LIB_PATH} not found: build it with `python vllm_i64_amd/build.py` (no CPU fallback exists)")
     lib = ctypes.CDLL(LIB_PATH)
