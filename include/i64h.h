@@ -5,8 +5,9 @@
  *   - the caller allocates every output and every workspace; the library allocates nothing and never
  *     synchronises, so every call can be captured into a HIP graph;
  *   - returns 0 on success, non-zero on failure with the reason in i64h_last_error() (per thread);
- *   - "stat slot": two consecutive uint32 (order-preserving encodings of a float min and max) that collect the
- *     min/max of the activations of one quantized Linear CALL; reset with i64h_stats_reset before each forward.
+ *   - "stat slot": i64h_stats_words_per_slot() uint32 (sharded order-preserving encodings of a float min and max)
+ *     that collect the min/max of the activations of one quantized Linear CALL; reset with i64h_stats_reset
+ *     before each forward.
  *
  * Citations name the reference interface each entry point stands in for (paths under the reference tree).
  */
@@ -64,6 +65,7 @@ int i64h_silu_mul(const void* gate_up, void* out, int64_t n, int32_t inter, int3
 /* ---- dynamic (reference CPU engine) activation quantization ---------------------------------------------------------
  * The x86/FBGEMM dynamic Linear the reference gets from torch.ao quantize_dynamic (vllm_i64/core/loader.py:57-76):
  * per call 7-bit asymmetric activations, min/max over the whole call. */
+int i64h_stats_words_per_slot(void); /* a slot is sharded: allocate n_slots * this many uint32 */
 int i64h_stats_reset(uint32_t* stats, int64_t n_slots, void* stream);
 /* fold min/max of every row of x[rows, K] into slot_base + slots[r][0..slots_per_row) (slots NULL: slot_base) */
 int i64h_rows_minmax(const float* x, int64_t rows, int32_t K, const int32_t* slots, int32_t slots_per_row, int32_t slot_base,
@@ -92,6 +94,33 @@ int i64h_rmsnorm_quant(const float* x, const float* weight, float eps, int8_t* o
 int i64h_gemm_i8(const int8_t* A, const float* row_scale, const int8_t* B, const float* w_scale, const int32_t* group_offsets,
                  int32_t num_groups, int64_t M_total, int32_t N, int32_t K, float* C, int32_t epilogue, const int32_t* row_slot,
                  int32_t slot_base, uint32_t* stats, void* stream);
+/* Descriptor form: the operand may be fp32 (a_fp32 = 1), in which case rows are gathered (a_src_row / a_src_mod as in
+ * i64h_quantize_dynamic) and quantized with the parameters of their stat slot while they are staged, i.e. quantize + GEMM
+ * in one launch (meant for small M: every workgroup re-quantizes the rows it needs).  i64h_gemm_i8_pair runs two problems
+ * with the same epilogue / operand kind in ONE launch (the routed experts and the shared expert of a layer); b may be NULL. */
+typedef struct i64h_gemm_desc {
+    const void* A;                /* int8 [M_total, K]  or  fp32 [*, K] when a_fp32 */
+    int32_t a_fp32;
+    const int32_t* a_src_row;     /* a_fp32: operand row r reads source row a_src_row[r] (NULL: r), modulo a_src_mod if > 0 */
+    int32_t a_src_mod;
+    const float* row_scale;       /* int8 operand: per-row scale [M_total] */
+    const int32_t* a_row_slot;    /* a_fp32: stat slot of row r = a_slot_base + (a_row_slot ? a_row_slot[r] : 0) */
+    int32_t a_slot_base;
+    const int8_t* B;              /* [G][N][K] */
+    const float* w_scale;         /* [G] */
+    const int32_t* group_offsets; /* [G+1] device or NULL */
+    int32_t num_groups;
+    int64_t M_total;
+    int32_t N, K;
+    float* C;
+    int32_t epilogue;             /* 0 store, 1 SwiGLU */
+    const int32_t* out_row_slot;  /* SwiGLU statistics: slot of row r = out_slot_base + (out_row_slot ? out_row_slot[r] : 0) */
+    int32_t out_slot_base;
+    uint32_t* stats;
+    int32_t want_stats;
+} i64h_gemm_desc;
+int i64h_gemm_i8_pair(const i64h_gemm_desc* a, const i64h_gemm_desc* b, void* stream);
+int i64h_set_skinny_waves(int32_t waves); /* tuning knob of the decode-sized (weight-streaming) kernel: 4, 8, 16 or 0 = default */
 /* C[M, N] = A[a_rows ? a_rows[m] : m, :K] . B[N, K]^T in fp32 (tied lm_head, vllm_i64/models/complexity_deep/model.py:436-437). */
 int i64h_gemm_f32(const float* A, const int32_t* a_rows, const float* B, float* C, int64_t M, int32_t N, int32_t K, void* stream);
 /* fp32 activations x int8 weights with per-output-channel scale: I64_gemm_dequant_int8 / I64_gemm_silu_int8
@@ -140,12 +169,13 @@ int i64h_advance(int32_t* positions, int32_t* ctx_len, int64_t n, void* stream);
  * Causal GQA attention over the paged cache (num_blocks, block_size, kv_heads, head_dim): row r attends to the first
  * ctx_len[r] cached tokens of sequence slot_ids[r] (NULL: r).  Replaces naive_paged_decode_attention
  * (vllm_i64/layers/attention.py:517-601), naive_cached_attention (190-245) and the model's per-sequence cache loop
- * (model.py:203-236).  workspace: i64h_paged_attn_workspace_floats(...) floats when splits > 1. */
+ * (model.py:203-236).  workspace: i64h_paged_attn_workspace_floats(...) floats when splits > 1.  With splits > 1 and
+ * stats != NULL the merge also folds min/max of the output into stat slot stat_slot (input statistics of o_proj). */
 int64_t i64h_paged_attn_workspace_floats(int64_t rows, int32_t num_heads, int32_t head_dim, int32_t splits);
 int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, int32_t kv_dtype, const int32_t* block_table,
                     int32_t max_blocks_per_seq, const int32_t* slot_ids, const int32_t* ctx_len, float softmax_scale, float* out,
                     float* workspace, int64_t rows, int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
-                    int32_t splits, void* stream);
+                    int32_t splits, uint32_t* stats, int32_t stat_slot, void* stream);
 
 #ifdef __cplusplus
 }

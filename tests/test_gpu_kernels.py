@@ -92,6 +92,43 @@ def test_gemm_i8_swiglu_and_stats(dev):
     assert lohi[0, 0] == 0 and lohi[0, 1] == 0
 
 
+@pytest.mark.parametrize("M_,K_,G_", [(64, 1024, 1), (130, 448, 4), (7, 160, 2)])
+def test_gemm_i8_fused_quantize_matches_two_step(dev, M_, K_, G_):
+    """fp32 operand quantized inside the GEMM (per-row stat slots, gathered rows) == quantize kernel + int8 GEMM, bit for bit;
+    two problems in one launch == two launches."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M_ + K_)
+    n_src = M_ // 2 + 3
+    x = torch.empty(n_src, K_).normal_(0, 1, generator=g).to(dev)
+    src = torch.randint(0, 10 * n_src, (M_,), generator=g, dtype=torch.int32).to(dev)
+    slot = torch.randint(0, 3, (M_,), generator=g, dtype=torch.int32).to(dev)
+    w = torch.randint(-128, 128, (G_, 2 * 40, K_), generator=g, dtype=torch.int8).to(dev)
+    ws = (torch.rand(G_, generator=g) * 0.01 + 0.001).to(dev)
+    cuts = sorted(torch.randint(0, M_ + 1, (G_ - 1,), generator=g).tolist())
+    off = torch.tensor([0] + cuts + [M_], dtype=torch.int32, device=dev)
+    stats = ops.stats_alloc(8, dev)
+    ops.stats_reset(stats)
+    xs_rows = x[(src.long() % n_src)]
+    ops.rows_minmax(xs_rows.contiguous(), stats, slots=slot.view(-1, 1).contiguous(), slot_base=1)
+    a, scale = ops.quantize_dynamic(x, stats, slot_base=1, src_row=src, src_mod=n_src, row_slot=slot, out_rows=M_)
+    for epi in (ops.EPI_STORE, ops.EPI_SWIGLU):
+        ref = ops.gemm_i8(a, scale, w, ws, group_offsets=off, epilogue=epi)
+        out = torch.empty_like(ref)
+        d = ops.gemm_desc(x, w, ws, out, a_src_row=src, a_src_mod=n_src, a_row_slot=slot, a_slot_base=1, group_offsets=off,
+                          epilogue=epi, stats=stats, m_total=M_)
+        ops.gemm_i8_pair(d)
+        assert torch.equal(out, ref)
+        # second problem in the same launch: a dense call over x itself with slot 5
+        ops.rows_minmax(x, stats, slot_base=5)
+        a2, s2 = ops.quantize_dynamic(x, stats, slot_base=5)
+        ref2 = ops.gemm_i8(a2, s2, w[0], ws[:1], epilogue=epi)
+        out.zero_()
+        out2 = torch.empty_like(ref2)
+        d2 = ops.gemm_desc(x, w[0], ws[:1], out2, a_slot_base=5, epilogue=epi, stats=stats)
+        ops.gemm_i8_pair(d, d2)
+        assert torch.equal(out, ref) and torch.equal(out2, ref2)
+
+
 # ---- routing / bucketing: bit exact --------------------------------------------------------------------------
 def test_route_tokens_and_lookup(dev, golden_dir):
     ops = _ops()

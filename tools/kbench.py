@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of the decode-shaped kernels (HIP events on the launch stream).  Usage: python tools/kbench.py [attn|gemm|all]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vllm_i64_amd import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+
+
+def timeit(fn, iters=10, warm=3, inner=20):
+    """Median / best time per call in us; `inner` calls are queued back to back between two events so that host launch
+    latency is hidden behind the GPU work."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(inner):
+            fn()
+        b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    ts = sorted(x.elapsed_time(y) / inner for x, y in evs)
+    return ts[len(ts) // 2] * 1e3, ts[0] * 1e3  # us
+
+
+def flush():
+    # touch 512 MiB so that the next kernel starts from cold caches
+    global _junk
+    _junk = torch.empty(512 << 20, dtype=torch.uint8, device=dev).fill_(1)
+
+
+def bench_attn():
+    B, ctx, nh, kvh, hd = 64, 2048, 16, 4, 64
+    for dt in (torch.bfloat16, torch.float32):
+        nblk = B * (ctx // 16 + 2)
+        kc = torch.randn(nblk, 16, kvh, hd, device=dev).to(dt)
+        vc = torch.randn(nblk, 16, kvh, hd, device=dev).to(dt)
+        bt = torch.randperm(nblk, device=dev).to(torch.int32).view(B, -1).contiguous()
+        q = torch.randn(B, nh, hd, device=dev)
+        cl = torch.full((B,), ctx, dtype=torch.int32, device=dev)
+        out = torch.empty_like(q)
+        nbytes = B * ctx * kvh * hd * 2 * kc.element_size()
+        src = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
+        dst = torch.empty_like(src)
+        med, best = timeit(lambda: dst.copy_(src))
+        print(f"reference: torch device copy of the same bytes {med:7.1f} us -> read {nbytes / med / 1e3:7.1f} GB/s (+ equal write)")
+        for splits in (4, 8, 16, 32):
+            ws = torch.empty(ops._lib.load().i64h_paged_attn_workspace_floats(B, nh, hd, splits), device=dev)
+            med, best = timeit(lambda: ops.paged_attn(q, kc, vc, bt, cl, splits=splits, out=out, workspace=ws))
+            print(f"attn {str(dt)[6:]:9s} splits {splits:2d}: median {med:7.1f} us best {best:7.1f} us -> {nbytes / med / 1e3:7.1f} GB/s (attn+merge)")
+
+
+def bench_gemm():
+    n, H = 64, 1024
+    stats = ops.stats_alloc(64, dev)
+    ops.stats_reset(stats)
+    x = torch.randn(n, H, device=dev)
+    ops.rows_minmax(x, stats, slot_base=0)
+    for (N, K, epi, name) in ((1536, 1024, 0, "qkv"), (1024, 1024, 0, "o"), (3584, 1024, 1, "sh_gu"), (1024, 1792, 0, "sh_dn")):
+        xx = torch.randn(n, K, device=dev)
+        ops.rows_minmax(xx, stats, slot_base=1)
+        w = torch.randint(-128, 128, (1, N, K), dtype=torch.int8, device=dev)
+        ws = torch.ones(1, device=dev) * 0.01
+        out = torch.empty(n, N // 2 if epi else N, device=dev)
+        d = ops.gemm_desc(xx, w, ws, out, a_slot_base=1, epilogue=epi, stats=stats, out_slot_base=3, want_stats=bool(epi))
+        med, best = timeit(lambda: ops.gemm_i8_pair(d))
+        a8, s8 = ops.quantize_dynamic(xx, stats, slot_base=1)
+        med2, best2 = timeit(lambda: ops.gemm_i8(a8, s8, w, ws, epilogue=epi, out=out))
+        print(f"gemm {name:6s} M={n} N={N} K={K}: fused-quant {med:6.1f}/{best:6.1f} us; int8-operand tiled {med2:6.1f}/{best2:6.1f} us; weights {N * K / 1e6:.2f} MB")
+    # expert pair (E=8, top-2, 128 rows) + shared
+    E, ei, S = 8, 448, 1792
+    R = 128
+    perm = torch.randperm(R, device=dev).to(torch.int32)
+    bucket = torch.sort(torch.randint(0, 16, (R,), device=dev))[0].to(torch.int32)
+    eoff = torch.zeros(E + 1, dtype=torch.int32, device=dev)
+    cnt = torch.bincount((bucket // 2).long(), minlength=E)
+    eoff[1:] = torch.cumsum(cnt, 0)
+    ops.rows_minmax(x, stats, slot_base=10)
+    for s in range(16):
+        ops.rows_minmax(x, stats, slot_base=11 + s)
+    wgu = torch.randint(-128, 128, (E, 2 * ei, H), dtype=torch.int8, device=dev)
+    wsh = torch.randint(-128, 128, (1, 2 * S, H), dtype=torch.int8, device=dev)
+    e_inter = torch.empty(R, ei, device=dev)
+    s_inter = torch.empty(n, S, device=dev)
+    one8, one1 = torch.ones(E, device=dev) * 0.01, torch.ones(1, device=dev) * 0.01
+    d1 = ops.gemm_desc(x, wgu, one8, e_inter, a_src_row=perm, a_src_mod=n, a_row_slot=bucket, a_slot_base=11, group_offsets=eoff,
+                       epilogue=1, out_row_slot=bucket, out_slot_base=30, stats=stats, want_stats=True, m_total=R)
+    d2 = ops.gemm_desc(x, wsh, one1, s_inter, a_slot_base=10, epilogue=1, out_slot_base=29, stats=stats, want_stats=True)
+    med, best = timeit(lambda: ops.gemm_i8_pair(d1, d2))
+    print(f"gemm gate_up pair (experts 8x[~16,1024]x896 + shared [64,1024]x3584): {med:6.1f}/{best:6.1f} us; weights {(E * 2 * ei * H + 2 * S * H) / 1e6:.2f} MB")
+    wdn = torch.randint(-128, 128, (E, H, ei), dtype=torch.int8, device=dev)
+    wsd = torch.randint(-128, 128, (1, H, S), dtype=torch.int8, device=dev)
+    e_out, s_out = torch.empty(R, H, device=dev), torch.empty(n, H, device=dev)
+    d3 = ops.gemm_desc(e_inter, wdn, one8, e_out, a_row_slot=bucket, a_slot_base=30, group_offsets=eoff, stats=stats, m_total=R)
+    d4 = ops.gemm_desc(s_inter, wsd, one1, s_out, a_slot_base=29, stats=stats)
+    med, best = timeit(lambda: ops.gemm_i8_pair(d3, d4))
+    print(f"gemm down pair    (experts 8x[~16,448]x1024 + shared [64,1792]x1024): {med:6.1f}/{best:6.1f} us; weights {(E * ei * H + S * H) / 1e6:.2f} MB")
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what == "gemmw":
+        for nw in (4, 8, 16):
+            ops.call("i64h_set_skinny_waves", nw)
+            print(f"--- skinny kernel with {nw} waves per workgroup")
+            bench_gemm()
+        sys.exit(0)
+    if what in ("attn", "all"):
+        bench_attn()
+    if what in ("gemm", "all"):
+        bench_gemm()

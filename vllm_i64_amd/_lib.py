@@ -42,7 +42,9 @@ SIGNATURES: Dict[str, str] = {
     "i64h_silu_mul_q7": "ppplpp",
     "i64h_argmax_rows": "pplip",
     "i64h_advance": "pplp",
-    "i64h_paged_attn": "pppipippfppliiiiip",
+    "i64h_paged_attn": "pppipippfppliiiiipip",
+    "i64h_gemm_i8_pair": "ppp",
+    "i64h_set_skinny_waves": "i",
 }
 _KIND = {"p": _P, "i": _I, "l": _L, "f": _F}
 
@@ -55,7 +57,15 @@ class I64HError(RuntimeError):
 
 def exported_symbols():
     return ["i64h_last_error", "i64h_version", "i64h_device_check", "i64h_bucketize_workspace_bytes",
-            "i64h_paged_attn_workspace_floats", *SIGNATURES.keys()]
+            "i64h_paged_attn_workspace_floats", "i64h_stats_words_per_slot", *SIGNATURES.keys()]
+
+
+class GemmDesc(ctypes.Structure):
+    """Mirror of i64h_gemm_desc (include/i64h.h)."""
+    _fields_ = [("A", _P), ("a_fp32", _I), ("a_src_row", _P), ("a_src_mod", _I), ("row_scale", _P), ("a_row_slot", _P),
+                ("a_slot_base", _I), ("B", _P), ("w_scale", _P), ("group_offsets", _P), ("num_groups", _I), ("M_total", _L),
+                ("N", _I), ("K", _I), ("C", _P), ("epilogue", _I), ("out_row_slot", _P), ("out_slot_base", _I), ("stats", _P),
+                ("want_stats", _I)]
 
 
 def load() -> ctypes.CDLL:
@@ -77,6 +87,8 @@ def load() -> ctypes.CDLL:
     lib.i64h_bucketize_workspace_bytes.argtypes = [_L, _I, _I]
     lib.i64h_paged_attn_workspace_floats.restype = _L
     lib.i64h_paged_attn_workspace_floats.argtypes = [_L, _I, _I, _I]
+    lib.i64h_stats_words_per_slot.restype = _I
+    lib.i64h_stats_words_per_slot.argtypes = []
     for name, sig in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = _I

@@ -14,34 +14,45 @@
 #include <hip/hip_fp16.h>
 #include <math.h>
 
-template <typename KV>
-__device__ __forceinline__ void load8(const KV* p, float (&o)[8]);
-template <>
-__device__ __forceinline__ void load8<float>(const float* p, float (&o)[8]) {
-    float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
-    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
-}
-template <>
-__device__ __forceinline__ void load8<__hip_bfloat16>(const __hip_bfloat16* p, float (&o)[8]) {
-    uint4 r = *(const uint4*)p;
-    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        o[2 * i] = __uint_as_float(w[i] << 16);
-        o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+// 8 consecutive cache elements of one token: raw registers (issued early) and their fp32 view (converted late)
+template <typename KV> struct Raw8;
+template <> struct Raw8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = *(const float4*)p; b = *(const float4*)(p + 4); }
+    __device__ __forceinline__ void zero() { a = make_float4(0, 0, 0, 0); b = a; }
+    __device__ __forceinline__ void get(float (&o)[8]) const {
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
     }
-}
-template <>
-__device__ __forceinline__ void load8<__half>(const __half* p, float (&o)[8]) {
-    uint4 r = *(const uint4*)p;
-    const __half2* h = (const __half2*)&r;
+};
+template <> struct Raw8<__hip_bfloat16> {
+    uint4 r;
+    __device__ __forceinline__ void load(const __hip_bfloat16* p) { r = *(const uint4*)p; }
+    __device__ __forceinline__ void zero() { r = make_uint4(0, 0, 0, 0); }
+    __device__ __forceinline__ void get(float (&o)[8]) const {
+        const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float2 f = __half22float2(h[i]);
-        o[2 * i] = f.x;
-        o[2 * i + 1] = f.y;
+        for (int i = 0; i < 4; ++i) {
+            o[2 * i] = __uint_as_float(w[i] << 16);
+            o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
     }
-}
+};
+template <> struct Raw8<__half> {
+    uint4 r;
+    __device__ __forceinline__ void load(const __half* p) { r = *(const uint4*)p; }
+    __device__ __forceinline__ void zero() { r = make_uint4(0, 0, 0, 0); }
+    __device__ __forceinline__ void get(float (&o)[8]) const {
+        const __half2* h = (const __half2*)&r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float2 f = __half22float2(h[i]);
+            o[2 * i] = f.x;
+            o[2 * i + 1] = f.y;
+        }
+    }
+};
+
+#define PA_UNROLL 2  // token groups in flight per wave: all K/V loads of an iteration are issued before any math
 
 template <int HD, int GS, typename KV>
 __global__ __launch_bounds__(256) void paged_attn_kernel(const float* __restrict__ q, const KV* __restrict__ k_cache,
@@ -79,51 +90,65 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(const float* __restrict
         for (int d = 0; d < 8; ++d) acc[h][d] = 0.0f;
     }
 
-    for (int t0 = t_begin + wid * TPW; t0 < t_end; t0 += 4 * TPW) {
-        const int t = t0 + tl;
-        const bool ok = t < t_end;
-        float kf[8], vf[8];
-        int pb = -1;
-        if (ok) pb = bt[t / block];
-        const bool live = ok && pb >= 0;
-        if (live) {
-            const int64_t off = (((int64_t)pb * block + (t % block)) * kvh + kh) * HD + ch * 8;
-            load8<KV>(k_cache + off, kf);
-            load8<KV>(v_cache + off, vf);
-        } else {
+    // Loads are unconditional (addresses clamped into the sequence, masked afterwards): a branch around a load would
+    // make the compiler wait for each one in turn.  The block-table entries of the next iteration are fetched while the
+    // current iteration computes, so the K/V loads never wait on a dependent lookup.
+    auto fetch_blocks = [&](int t0, int (&pb)[PA_UNROLL]) {
 #pragma unroll
-            for (int d = 0; d < 8; ++d) { kf[d] = 0.0f; vf[d] = 0.0f; }
+        for (int u = 0; u < PA_UNROLL; ++u) {
+            const int tc = max(0, min(t0 + u * TPW + tl, t_end - 1));
+            pb[u] = bt[tc / block];
         }
-        float s[GS];
-        bool grew = false;
+    };
+    int pbn[PA_UNROLL];
+    fetch_blocks(t_begin + wid * (PA_UNROLL * TPW), pbn);
+    for (int t0 = t_begin + wid * (PA_UNROLL * TPW); t0 < t_end; t0 += 4 * PA_UNROLL * TPW) {
+        Raw8<KV> rk[PA_UNROLL], rv[PA_UNROLL];
+        bool live[PA_UNROLL];
 #pragma unroll
-        for (int h = 0; h < GS; ++h) {
-            float a = 0.0f;
+        for (int u = 0; u < PA_UNROLL; ++u) {
+            const int t = t0 + u * TPW + tl;
+            const int tc = max(0, min(t, t_end - 1));
+            const int pb = pbn[u];
+            live[u] = t < t_end && pb >= 0;
+            const int64_t off = (((int64_t)max(pb, 0) * block + (tc % block)) * kvh + kh) * HD + ch * 8;
+            rk[u].load(k_cache + off);
+            rv[u].load(v_cache + off);
+        }
+        fetch_blocks(t0 + 4 * PA_UNROLL * TPW, pbn);
 #pragma unroll
-            for (int d = 0; d < 8; ++d) a = __builtin_fmaf(qr[h][d], kf[d], a);
+        for (int u = 0; u < PA_UNROLL; ++u) {
+            if (t0 + u * TPW >= t_end) break;  // wave-uniform
+            float kf[8], vf[8], s[GS];
+            rk[u].get(kf);
+            rv[u].get(vf);
 #pragma unroll
-            for (int o = 1; o < LPT; o <<= 1) a += __shfl_xor(a, o);
-            a = live ? a * scale : -INFINITY;
-            float mx = a;
+            for (int h = 0; h < GS; ++h) {
+                float a = 0.0f;
 #pragma unroll
-            for (int o = LPT; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-            s[h] = a;
-            if (mx > m[h]) {  // wave-uniform: mx and m[h] are identical in every lane
-                const float alpha = expf(m[h] - mx);
-                l[h] *= alpha;
+                for (int d = 0; d < 8; ++d) a = __builtin_fmaf(qr[h][d], kf[d], a);
 #pragma unroll
-                for (int d = 0; d < 8; ++d) acc[h][d] *= alpha;
-                m[h] = mx;
-                grew = true;
+                for (int o = 1; o < LPT; o <<= 1) a += __shfl_xor(a, o);
+                a = live[u] ? a * scale : -INFINITY;
+                float mx = a;
+#pragma unroll
+                for (int o = LPT; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+                s[h] = a;
+                if (mx > m[h]) {  // wave-uniform: mx and m[h] are identical in every lane
+                    const float alpha = expf(m[h] - mx);
+                    l[h] *= alpha;
+#pragma unroll
+                    for (int d = 0; d < 8; ++d) acc[h][d] *= alpha;
+                    m[h] = mx;
+                }
             }
-        }
-        (void)grew;
 #pragma unroll
-        for (int h = 0; h < GS; ++h) {
-            const float p = (m[h] == -INFINITY) ? 0.0f : expf(s[h] - m[h]);
-            l[h] += p;
+            for (int h = 0; h < GS; ++h) {
+                const float p = live[u] ? expf(s[h] - m[h]) : 0.0f;
+                l[h] += p;
 #pragma unroll
-            for (int d = 0; d < 8; ++d) acc[h][d] = __builtin_fmaf(p, vf[d], acc[h][d]);
+                for (int d = 0; d < 8; ++d) acc[h][d] = __builtin_fmaf(p, vf[d], acc[h][d]);
+            }
         }
     }
 
@@ -168,23 +193,198 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(const float* __restrict
     }
 }
 
-// merge the splits of one (row, head): grid = rows*nh, block = HD threads (>= 64)
-__global__ void attn_merge_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml, float* __restrict__ out, int HD,
-                                  int splits) {
-    const int64_t head = blockIdx.x;
-    float mm = -INFINITY;
-    for (int s = 0; s < splits; ++s) mm = fmaxf(mm, part_ml[(head * splits + s) * 2]);
-    for (int d = threadIdx.x; d < HD; d += blockDim.x) {
-        float lt = 0.0f, ot = 0.0f;
-        if (mm != -INFINITY) {
-            for (int s = 0; s < splits; ++s) {
-                const float ms = part_ml[(head * splits + s) * 2];
-                const float f = (ms == -INFINITY) ? 0.0f : expf(ms - mm);
-                lt = __builtin_fmaf(f, part_ml[(head * splits + s) * 2 + 1], lt);
-                ot = __builtin_fmaf(f, part_o[(head * splits + s) * HD + d], ot);
+// ---- decode form: one workgroup = (query row, split), ALL kv heads --------------------------------------------------
+// In the cache a token's K (or V) for all kv heads is one contiguous KVH*HD-element row, so a wave-instruction that
+// covers whole token rows is fully coalesced (512-B segments at 4 x 64 bf16) instead of one 128-B piece per token.
+// Lane = (token in step, kv head, 8-dim chunk); a wave step covers TPS = 64 / (KVH*HD/8) tokens; PD_U steps are loaded
+// together and share one online-softmax update.  Waves of a workgroup take interleaved token groups.
+#define PD_U 4
+template <int HD, int KVH, int GS, typename KV>
+__global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* __restrict__ q, const KV* __restrict__ k_cache,
+                                                                  const KV* __restrict__ v_cache, const int32_t* __restrict__ block_table,
+                                                                  int max_blocks_per_seq, const int32_t* __restrict__ slot_ids,
+                                                                  const int32_t* __restrict__ ctx_len, float scale, float* __restrict__ out,
+                                                                  float* __restrict__ part_o, float* __restrict__ part_ml, int block,
+                                                                  int splits) {
+    constexpr int CPH = HD / 8;         // chunk lanes per head
+    constexpr int LPT = KVH * CPH;      // lanes per token
+    constexpr int TPS = 64 / LPT;       // tokens per wave step
+    constexpr int NH = KVH * GS;
+    static_assert(64 % LPT == 0, "token row must fit a wave");
+    __shared__ float s_m[4][NH], s_l[4][NH], s_o[4][NH][HD];
+    const int row = blockIdx.x, sp = blockIdx.y;
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ch = lane % CPH, kh = (lane / CPH) % KVH, tl = lane / LPT;
+    const int ctx = ctx_len[row];
+    const int slot = slot_ids ? slot_ids[row] : row;
+    const int32_t* bt = block_table + (int64_t)slot * max_blocks_per_seq;
+    const int nblk = (ctx + block - 1) / block;
+    const int bps = (nblk + splits - 1) / splits;
+    const int t_begin = sp * bps * block;
+    const int t_end = min(ctx, (sp + 1) * bps * block);
+
+    float qr[GS][8], acc[GS][8], m[GS], l[GS];
+#pragma unroll
+    for (int h = 0; h < GS; ++h) {
+        const float* qp = q + ((int64_t)row * NH + kh * GS + h) * HD + ch * 8;
+        float4 a = *(const float4*)qp, b = *(const float4*)(qp + 4);
+        qr[h][0] = a.x; qr[h][1] = a.y; qr[h][2] = a.z; qr[h][3] = a.w;
+        qr[h][4] = b.x; qr[h][5] = b.y; qr[h][6] = b.z; qr[h][7] = b.w;
+        m[h] = -INFINITY;
+        l[h] = 0.0f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) acc[h][d] = 0.0f;
+    }
+    constexpr int TPI = PD_U * TPS;  // tokens per wave iteration
+    auto fetch_blocks = [&](int t0, int (&pb)[PD_U]) {
+#pragma unroll
+        for (int u = 0; u < PD_U; ++u) {
+            const int tc = max(0, min(t0 + u * TPS + tl, t_end - 1));
+            pb[u] = bt[tc / block];
+        }
+    };
+    int pbn[PD_U];
+    fetch_blocks(t_begin + wid * TPI, pbn);
+    for (int t0 = t_begin + wid * TPI; t0 < t_end; t0 += 4 * TPI) {
+        Raw8<KV> rk[PD_U], rv[PD_U];
+        bool live[PD_U];
+#pragma unroll
+        for (int u = 0; u < PD_U; ++u) {
+            const int t = t0 + u * TPS + tl;
+            const int tc = max(0, min(t, t_end - 1));
+            const int pb = pbn[u];
+            live[u] = t < t_end && pb >= 0;
+            const int64_t off = ((int64_t)max(pb, 0) * block + (tc % block)) * (KVH * HD) + (lane % LPT) * 8;
+            rk[u].load(k_cache + off);
+            rv[u].load(v_cache + off);
+        }
+        fetch_blocks(t0 + 4 * TPI, pbn);
+        float s[PD_U][GS];
+#pragma unroll
+        for (int u = 0; u < PD_U; ++u) {
+            float kf[8];
+            rk[u].get(kf);
+#pragma unroll
+            for (int h = 0; h < GS; ++h) {
+                float a = 0.0f;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) a = __builtin_fmaf(qr[h][d], kf[d], a);
+#pragma unroll
+                for (int o = 1; o < CPH; o <<= 1) a += __shfl_xor(a, o);
+                s[u][h] = live[u] ? a * scale : -INFINITY;
             }
         }
-        out[head * HD + d] = (lt > 0.0f) ? ot / lt : 0.0f;
+#pragma unroll
+        for (int h = 0; h < GS; ++h) {  // one online-softmax update per head for the PD_U * TPS tokens of the iteration
+            float mx = s[0][h];
+#pragma unroll
+            for (int u = 1; u < PD_U; ++u) mx = fmaxf(mx, s[u][h]);
+#pragma unroll
+            for (int o = LPT; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            const float mn = fmaxf(m[h], mx);           // identical in the lanes of one kv head
+            const float alpha = (mn == -INFINITY) ? 1.0f : expf(m[h] - mn);
+            m[h] = mn;
+            l[h] *= alpha;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) acc[h][d] *= alpha;
+        }
+#pragma unroll
+        for (int u = 0; u < PD_U; ++u) {
+            float vf[8];
+            rv[u].get(vf);
+#pragma unroll
+            for (int h = 0; h < GS; ++h) {
+                const float p = live[u] ? expf(s[u][h] - m[h]) : 0.0f;
+                l[h] += p;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) acc[h][d] = __builtin_fmaf(p, vf[d], acc[h][d]);
+            }
+        }
+    }
+    // reduce over the token lanes (same kv head and chunk), then over waves through LDS
+#pragma unroll
+    for (int h = 0; h < GS; ++h) {
+#pragma unroll
+        for (int o = LPT; o < 64; o <<= 1) {
+            l[h] += __shfl_xor(l[h], o);
+#pragma unroll
+            for (int d = 0; d < 8; ++d) acc[h][d] += __shfl_xor(acc[h][d], o);
+        }
+        if (tl == 0) {
+            const int head = kh * GS + h;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) s_o[wid][head][ch * 8 + d] = acc[h][d];
+            if (ch == 0) { s_m[wid][head] = m[h]; s_l[wid][head] = l[h]; }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NH * HD; i += 256) {
+        const int h = i / HD, d = i % HD;
+        float mm = fmaxf(fmaxf(s_m[0][h], s_m[1][h]), fmaxf(s_m[2][h], s_m[3][h]));
+        float lt = 0.0f, ot = 0.0f;
+        if (mm != -INFINITY) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float f = (s_m[w][h] == -INFINITY) ? 0.0f : expf(s_m[w][h] - mm);
+                lt = __builtin_fmaf(f, s_l[w][h], lt);
+                ot = __builtin_fmaf(f, s_o[w][h][d], ot);
+            }
+        }
+        const int64_t head = (int64_t)row * NH + h;
+        if (splits == 1) {
+            out[head * HD + d] = (lt > 0.0f) ? ot / lt : 0.0f;
+        } else {
+            part_o[(head * splits + sp) * HD + d] = ot;
+            if (d == 0) {
+                part_ml[(head * splits + sp) * 2] = mm;
+                part_ml[(head * splits + sp) * 2 + 1] = lt;
+            }
+        }
+    }
+}
+
+// merge the splits: one workgroup per query row (all heads), one float4 of one head per thread and pass;
+// optionally folds min/max of the row into a stat slot
+__global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                         float* __restrict__ out, int nh, int HD, int splits, uint32_t* __restrict__ stats,
+                                                         int stat_slot) {
+    __shared__ float rlo[4], rhi[4];
+    const int64_t row = blockIdx.x;
+    float lo = 0.0f, hi = 0.0f;
+    const int per_head = HD / 4;
+    for (int i = threadIdx.x; i < nh * per_head; i += 256) {
+        const int64_t head = row * nh + i / per_head;
+        const int d = (i % per_head) * 4;
+        const float* ml = part_ml + head * splits * 2;
+        float mm = -INFINITY;
+        for (int s = 0; s < splits; ++s) mm = fmaxf(mm, ml[2 * s]);
+        float lt = 0.0f;
+        float4 ot = make_float4(0, 0, 0, 0);
+        if (mm != -INFINITY) {
+            for (int s = 0; s < splits; ++s) {
+                const float ms = ml[2 * s];
+                const float f = (ms == -INFINITY) ? 0.0f : expf(ms - mm);
+                const float4 po = *(const float4*)(part_o + (head * splits + s) * HD + d);
+                lt = __builtin_fmaf(f, ml[2 * s + 1], lt);
+                ot.x = __builtin_fmaf(f, po.x, ot.x); ot.y = __builtin_fmaf(f, po.y, ot.y);
+                ot.z = __builtin_fmaf(f, po.z, ot.z); ot.w = __builtin_fmaf(f, po.w, ot.w);
+            }
+        }
+        float4 v = make_float4(0, 0, 0, 0);
+        if (lt > 0.0f) { v.x = ot.x / lt; v.y = ot.y / lt; v.z = ot.z / lt; v.w = ot.w / lt; }
+        *(float4*)(out + head * HD + d) = v;
+        lo = fminf(lo, fminf(fminf(v.x, v.y), fminf(v.z, v.w)));
+        hi = fmaxf(hi, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+    }
+    if (!stats) return;
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+    if ((threadIdx.x & 63) == 0) { rlo[threadIdx.x >> 6] = lo; rhi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        lo = fminf(fminf(rlo[0], rlo[1]), fminf(rlo[2], rlo[3]));
+        hi = fmaxf(fmaxf(rhi[0], rhi[1]), fmaxf(rhi[2], rhi[3]));
+        stat_update(stats, stat_slot, blockIdx.x, lo, hi);
     }
 }
 
@@ -232,8 +432,9 @@ int64_t i64h_paged_attn_workspace_floats(int64_t rows, int32_t num_heads, int32_
 int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, int32_t kv_dtype, const int32_t* block_table,
                     int32_t max_blocks_per_seq, const int32_t* slot_ids, const int32_t* ctx_len, float softmax_scale, float* out,
                     float* workspace, int64_t rows, int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
-                    int32_t splits, void* stream) {
+                    int32_t splits, uint32_t* stats, int32_t stat_slot, void* stream) {
     I64H_CHECK_ARG(rows >= 0 && rows < (1ll << 31), "paged_attn: bad row count");
+    I64H_CHECK_ARG(stats == nullptr || splits > 1, "paged_attn: output statistics are produced by the split merge (splits > 1)");
     I64H_CHECK_ARG(num_kv_heads > 0 && num_heads % num_kv_heads == 0, "paged_attn: heads %d not a multiple of kv heads %d", num_heads, num_kv_heads);
     I64H_CHECK_ARG(kv_dtype >= 0 && kv_dtype <= 2, "paged_attn: unknown kv dtype %d", kv_dtype);
     I64H_CHECK_ARG(splits >= 1 && splits <= 64, "paged_attn: splits=%d out of range", splits);
@@ -245,6 +446,32 @@ int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, in
     float* part_o = workspace;
     float* part_ml = workspace ? workspace + rows * num_heads * splits * (int64_t)head_dim : nullptr;
     int rc = 1;
+    // decode form (few rows, long contexts): all kv heads per workgroup, fully coalesced token rows
+    bool done = false;
+#define AH(HD_, KVH_, GS_)                                                                                                          \
+    if (!done && splits > 1 && head_dim == HD_ && num_kv_heads == KVH_ && gs == GS_) {                                                 \
+        dim3 grid((unsigned)rows, (unsigned)splits);                                                                                   \
+        if (kv_dtype == 0)                                                                                                             \
+            hipLaunchKernelGGL((paged_attn_allheads_kernel<HD_, KVH_, GS_, float>), grid, dim3(256), 0, st, q, (const float*)k_cache, \
+                               (const float*)v_cache, block_table, max_blocks_per_seq, slot_ids, ctx_len, softmax_scale, out, part_o,   \
+                               part_ml, block_size, splits);                                                                           \
+        else if (kv_dtype == 1)                                                                                                        \
+            hipLaunchKernelGGL((paged_attn_allheads_kernel<HD_, KVH_, GS_, __half>), grid, dim3(256), 0, st, q, (const __half*)k_cache, \
+                               (const __half*)v_cache, block_table, max_blocks_per_seq, slot_ids, ctx_len, softmax_scale, out, part_o,  \
+                               part_ml, block_size, splits);                                                                           \
+        else                                                                                                                           \
+            hipLaunchKernelGGL((paged_attn_allheads_kernel<HD_, KVH_, GS_, __hip_bfloat16>), grid, dim3(256), 0, st, q,                 \
+                               (const __hip_bfloat16*)k_cache, (const __hip_bfloat16*)v_cache, block_table, max_blocks_per_seq,         \
+                               slot_ids, ctx_len, softmax_scale, out, part_o, part_ml, block_size, splits);                            \
+        done = true;                                                                                                                   \
+        rc = 0;                                                                                                                        \
+    }
+    AH(64, 4, 4)
+    AH(32, 2, 2)
+    AH(16, 2, 2)
+    AH(128, 4, 2)
+#undef AH
+    if (!done) {
 #define GO(H) rc = dispatch_gs<H>(gs, kv_dtype, q, k_cache, v_cache, block_table, max_blocks_per_seq, slot_ids, ctx_len, softmax_scale, out, part_o, part_ml, (int)rows, num_heads, num_kv_heads, block_size, splits, st)
     switch (head_dim) {
         case 16: GO(16); break;
@@ -253,11 +480,13 @@ int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, in
         case 128: GO(128); break;
         default: I64H_CHECK_ARG(false, "paged_attn: head_dim=%d unsupported (16, 32, 64, 128)", head_dim);
     }
+    }
 #undef GO
     I64H_CHECK_ARG(rc == 0, "paged_attn: GQA group size %d unsupported (1, 2, 4, 8)", gs);
     I64H_CHECK_LAUNCH();
     if (splits > 1) {
-        hipLaunchKernelGGL(attn_merge_kernel, dim3((unsigned)(rows * num_heads)), dim3(64), 0, st, part_o, part_ml, out, (int)head_dim, (int)splits);
+        hipLaunchKernelGGL(attn_merge_kernel, dim3((unsigned)rows), dim3(256), 0, st, part_o, part_ml, out, (int)num_heads, (int)head_dim,
+                           (int)splits, stats, (int)stat_slot);
         I64H_CHECK_LAUNCH();
     }
     return 0;

@@ -48,6 +48,28 @@ __device__ __forceinline__ float ordered_to_f32(uint32_t k) {
 }
 #define I64H_ORDERED_ZERO 0x80000000u  // f32_to_ordered(+0.0f)
 
+// A stat slot is sharded: I64H_NSHARD (min, max) pairs, 16 words per slot.  Producers spread their atomics over
+// the shards (contended same-address atomics serialise at ~100 ns each on this chip), consumers fold the shards.
+#define I64H_NSHARD 8
+#define I64H_SLOT_WORDS (2 * I64H_NSHARD)
+
+__device__ __forceinline__ void stat_update(uint32_t* stats, int slot, int shard, float lo, float hi) {
+    uint32_t* p = stats + (int64_t)slot * I64H_SLOT_WORDS + 2 * (shard & (I64H_NSHARD - 1));
+    atomicMin(p, f32_to_ordered(lo));
+    atomicMax(p + 1, f32_to_ordered(hi));
+}
+__device__ __forceinline__ void stat_read(const uint32_t* stats, int slot, float& lo, float& hi) {
+    const uint32_t* p = stats + (int64_t)slot * I64H_SLOT_WORDS;
+    uint32_t a = p[0], b = p[1];
+#pragma unroll
+    for (int j = 1; j < I64H_NSHARD; ++j) {
+        a = min(a, p[2 * j]);
+        b = max(b, p[2 * j + 1]);
+    }
+    lo = ordered_to_f32(a);
+    hi = ordered_to_f32(b);
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
@@ -128,6 +150,39 @@ __device__ __forceinline__ int quantize_u7_signed(float x, const QParams& q) {
     t = fminf(fmaxf(t, 0.0f), 255.0f);
     int v = (int)t - q.zp;
     return max(-128, min(127, v));
+}
+
+__device__ __forceinline__ QParams slot_qparams(const uint32_t* stats, int slot) {
+    float lo, hi;
+    stat_read(stats, slot, lo, hi);
+    return choose_qparams_u7(lo, hi);
+}
+
+// Per-workgroup accumulator of (min, max) per RELATIVE slot id, kept in LDS and flushed once per workgroup:
+// a workgroup that handles many rows issues at most one atomic pair per slot it touched.
+#define I64H_STAT_TAB 272  // >= 1 + 256 buckets
+__device__ __forceinline__ void stat_tab_init(float* tab_lo, float* tab_hi) {
+    for (int i = threadIdx.x; i < I64H_STAT_TAB; i += blockDim.x) {
+        tab_lo[i] = 0.0f;  // 0 is the identity: a call's min and max always include 0
+        tab_hi[i] = 0.0f;
+    }
+}
+// called by ONE thread per row, after the row's min/max are known
+__device__ __forceinline__ void stat_tab_fold(float* tab_lo, float* tab_hi, const int32_t* row_slots, int ns, float lo, float hi,
+                                              uint32_t* stats, int slot_base, int shard) {
+    for (int j = 0; j < ns; ++j) {
+        const int rel = row_slots ? row_slots[j] : 0;
+        if (rel >= 0 && rel < I64H_STAT_TAB) {
+            tab_lo[rel] = fminf(tab_lo[rel], lo);
+            tab_hi[rel] = fmaxf(tab_hi[rel], hi);
+        } else {
+            stat_update(stats, slot_base + rel, shard, lo, hi);
+        }
+    }
+}
+__device__ __forceinline__ void stat_tab_flush(const float* tab_lo, const float* tab_hi, uint32_t* stats, int slot_base, int shard) {
+    for (int i = threadIdx.x; i < I64H_STAT_TAB; i += blockDim.x)
+        if (tab_lo[i] != 0.0f || tab_hi[i] != 0.0f) stat_update(stats, slot_base + i, shard, tab_lo[i], tab_hi[i]);
 }
 
 #endif  // __HIPCC__

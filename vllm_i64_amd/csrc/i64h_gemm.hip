@@ -25,32 +25,45 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #define BK 128
 #define MAX_GROUPS 256
 
+// One grouped GEMM problem (device-side view of i64h_gemm_desc).
 struct GemmI8Args {
-    const int8_t* A;           // [M_total, K]
-    const float* row_scale;    // [M_total]
+    const void* A;             // int8 [M_total, K] (a_fp32 == 0) or fp32 [*, K] (a_fp32 == 1: quantized while staged)
+    const int32_t* a_src_row;  // a_fp32: source row of operand row r (nullptr: r), taken modulo a_src_mod when > 0
+    int a_src_mod;
+    const float* row_scale;    // a_fp32 == 0: [M_total]
+    const int32_t* a_row_slot; // a_fp32 == 1: stat slot of row r = a_slot_base + (a_row_slot ? a_row_slot[r] : 0)
+    int a_slot_base;
     const int8_t* B;           // [G][N][K]
     const float* w_scale;      // [G]
     const int32_t* group_off;  // [G+1] device, or nullptr => one group [0, M_total)
     int G, M_total, N, K;
     float* C;                  // EPI_STORE: [M_total, N]; EPI_SWIGLU: [M_total, N/2]
-    const int32_t* row_slot;   // EPI_SWIGLU stats: per-row slot (nullptr => slot_base for all rows)
-    uint32_t* stats;           // nullptr => no statistics
-    int slot_base;
+    const int32_t* out_row_slot;  // EPI_SWIGLU statistics: slot of row r = out_slot_base + (out_row_slot ? out_row_slot[r] : 0)
+    int out_slot_base;
+    uint32_t* stats;           // stat slots (input parameters for a_fp32, output statistics for EPI_SWIGLU); may be nullptr
+    int want_stats;
+};
+struct GemmI8Pair {
+    GemmI8Args p[2];
+    int nblk0;  // workgroups [0, nblk0) run p[0], the rest p[1]
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * BK + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <int BM, int BN, int EPI>
-__global__ __launch_bounds__(256) void gemm_i8_kernel(GemmI8Args p) {
+template <int BM, int BN, int EPI, int AQ>
+__device__ __forceinline__ void gemm_i8_body(const GemmI8Args& p, const int bid, char* smem) {
     constexpr int WM = BM / 2, WN = BN / 2;      // per-wave sub-tile
     constexpr int FM = WM / 16, FN = WN / 16;    // 16x16 fragments per wave
     constexpr int A_IT = BM * 8 / 256, B_IT = BN * 8 / 256;  // 16-B chunks per thread per tile
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int STAGE = (BM + BN) * BK;  // stage s: A tile at s*STAGE, B tile behind it
-    int* s_info = (int*)(smem + 2 * (BM + BN) * BK);  // 16 B behind the tiles: all LDS in the one dynamic region
+    // behind the two stages: tile info (16 B), then per-row quantization parameters (AQ)
+    int* s_info = (int*)(smem + 2 * STAGE);
+    float* q_inv = (float*)(smem + 2 * STAGE + 16);
+    float* q_scale = q_inv + BM;
+    int* q_zp = (int*)(q_scale + BM);
 
     const int n_tiles = (EPI == EPI_SWIGLU) ? ((p.N / 2) + BN / 2 - 1) / (BN / 2) : (p.N + BN - 1) / BN;
-    const int mt = blockIdx.x / n_tiles, nt = blockIdx.x % n_tiles;
+    const int mt = bid / n_tiles, nt = bid % n_tiles;
     if (threadIdx.x == 0) {  // locate (group, row range) of m-tile mt
         int g = -1, row0 = 0, rows = 0, acc_tiles = 0;
         const int G = p.group_off ? p.G : 1;
@@ -78,15 +91,32 @@ __global__ __launch_bounds__(256) void gemm_i8_kernel(GemmI8Args p) {
     const int8_t* Bg = p.B + (int64_t)g * p.N * K;
     const int I = p.N / 2;
 
-    // global -> register staging assignment: chunk c (16 B) of tile row r
+    if (AQ) {  // quantization parameters of the tile's rows (one Linear call = one stat slot)
+        if (tid < BM) {
+            QParams q;
+            q.scale = 0.0f; q.inv_scale = 0.0f; q.zp = 0;
+            if (tid < rows) q = slot_qparams(p.stats, p.a_slot_base + (p.a_row_slot ? p.a_row_slot[row0 + tid] : 0));
+            q_inv[tid] = q.inv_scale; q_scale[tid] = q.scale; q_zp[tid] = q.zp;
+        }
+        __syncthreads();
+    }
+
+    // global -> register staging assignment: chunk c (16 K-elements) of tile row r
     const int ld_c = tid & 7, ld_r = tid >> 3;  // rows ld_r + 32*i
-    const int8_t* a_ptr[A_IT];
+    const char* a_ptr[A_IT];
     bool a_ok[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int r = ld_r + 32 * i;
         a_ok[i] = r < rows;
-        a_ptr[i] = p.A + (int64_t)(row0 + (a_ok[i] ? r : 0)) * K + ld_c * 16;
+        int64_t src = row0 + (a_ok[i] ? r : 0);
+        if (AQ) {
+            if (p.a_src_row) src = p.a_src_row[src];
+            if (p.a_src_mod > 0) src = src % p.a_src_mod;
+            a_ptr[i] = (const char*)p.A + (src * K + ld_c * 16) * 4;
+        } else {
+            a_ptr[i] = (const char*)p.A + src * K + ld_c * 16;
+        }
     }
     const int8_t* b_ptr[B_IT];
     bool b_ok[B_IT];
@@ -113,18 +143,46 @@ __global__ __launch_bounds__(256) void gemm_i8_kernel(GemmI8Args p) {
         for (int j = 0; j < FN; ++j) acc[i][j] = (v4i){0, 0, 0, 0};
 
     const int KT = (K + BK - 1) / BK;
-    uint4 ra[A_IT], rb[B_IT];
+    uint4 ra[AQ ? 1 : A_IT], rb[B_IT];
+    float4 fa[AQ ? A_IT : 1][4];
     auto gload = [&](int kt) {
         const int kb = kt * BK + ld_c * 16;
         const bool kin = kb < K;  // K is a multiple of 16: a chunk is entirely inside or outside
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) ra[i] = (a_ok[i] && kin) ? *(const uint4*)(a_ptr[i] + kt * BK) : make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < A_IT; ++i) {
+            if (AQ) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    fa[i][e] = (a_ok[i] && kin) ? *(const float4*)(a_ptr[i] + (int64_t)kt * BK * 4 + e * 16) : make_float4(0, 0, 0, 0);
+            } else {
+                ra[i] = (a_ok[i] && kin) ? *(const uint4*)(a_ptr[i] + kt * BK) : make_uint4(0, 0, 0, 0);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) rb[i] = (b_ok[i] && kin) ? *(const uint4*)(b_ptr[i] + kt * BK) : make_uint4(0, 0, 0, 0);
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i) *(uint4*)(smem + buf * STAGE + swz(ld_r + 32 * i, ld_c)) = ra[i];
+        for (int i = 0; i < A_IT; ++i) {
+            uint4 v;
+            if (AQ) {
+                const int r = ld_r + 32 * i;
+                QParams q;
+                q.inv_scale = q_inv[r]; q.zp = q_zp[r]; q.scale = 0.0f;
+                uint32_t w[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float4 f = fa[i][e];
+                    w[e] = (uint32_t)(quantize_u7_signed(f.x, q) & 255) | ((uint32_t)(quantize_u7_signed(f.y, q) & 255) << 8) |
+                           ((uint32_t)(quantize_u7_signed(f.z, q) & 255) << 16) | ((uint32_t)(quantize_u7_signed(f.w, q) & 255) << 24);
+                }
+                // rows outside the tile / K tail must contribute 0, not quantize(0) = -zp + zp = 0: quantize(0) IS 0, fine
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            } else {
+                v = ra[i];
+            }
+            *(uint4*)(smem + buf * STAGE + swz(ld_r + 32 * i, ld_c)) = v;
+        }
 #pragma unroll
         for (int i = 0; i < B_IT; ++i) *(uint4*)(smem + buf * STAGE + BM * BK + swz(ld_r + 32 * i, ld_c)) = rb[i];
     };
@@ -161,7 +219,7 @@ __global__ __launch_bounds__(256) void gemm_i8_kernel(GemmI8Args p) {
             for (int reg = 0; reg < 4; ++reg) {
                 const int r = wm * WM + i * 16 + fq * 4 + reg;
                 if (r >= rows) continue;
-                const float m = p.row_scale[row0 + r] * ws;
+                const float m = (AQ ? q_scale[r] : p.row_scale[row0 + r]) * ws;
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
                     const int c = nt * BN + wn * WN + j * 16 + fr;
@@ -169,16 +227,22 @@ __global__ __launch_bounds__(256) void gemm_i8_kernel(GemmI8Args p) {
                 }
             }
     } else {
-        float rlo[FM][4], rhi[FM][4];
-        int my_slot = -1;
-        bool mixed = false;
+        // statistics of the result are folded per workgroup in LDS (the tile memory is free now), one atomic pair per
+        // slot the tile touched
+        uint32_t* tab_lo = (uint32_t*)smem;
+        uint32_t* tab_hi = tab_lo + I64H_STAT_TAB;
+        const bool st = p.want_stats != 0;
+        if (st) {
+            for (int i = tid; i < I64H_STAT_TAB; i += 256) { tab_lo[i] = I64H_ORDERED_ZERO; tab_hi[i] = I64H_ORDERED_ZERO; }
+            __syncthreads();
+        }
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int r = wm * WM + i * 16 + fq * 4 + reg;
                 const bool rok = r < rows;
-                const float m = rok ? p.row_scale[row0 + r] * ws : 0.0f;
+                const float m = rok ? (AQ ? q_scale[r] : p.row_scale[row0 + r]) * ws : 0.0f;
                 float a = 0.0f, b = 0.0f;
 #pragma unroll
                 for (int j = 0; j < FN / 2; ++j) {
@@ -192,52 +256,244 @@ __global__ __launch_bounds__(256) void gemm_i8_kernel(GemmI8Args p) {
                         b = fmaxf(b, v);
                     }
                 }
-                rlo[i][reg] = a;
-                rhi[i][reg] = b;
-                if (p.stats && rok) {
-                    const int s = p.slot_base + (p.row_slot ? p.row_slot[row0 + r] : 0);
-                    if (my_slot < 0) my_slot = s;
-                    else if (s != my_slot) mixed = true;
+                if (st) {
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) { a = fminf(a, __shfl_xor(a, o)); b = fmaxf(b, __shfl_xor(b, o)); }
+                    if (fr == 0 && rok) {
+                        const int rel = p.out_row_slot ? p.out_row_slot[row0 + r] : 0;
+                        if (rel >= 0 && rel < I64H_STAT_TAB) {
+                            atomicMin(&tab_lo[rel], f32_to_ordered(a));
+                            atomicMax(&tab_hi[rel], f32_to_ordered(b));
+                        } else {
+                            stat_update(p.stats, p.out_slot_base + rel, bid, a, b);
+                        }
+                    }
                 }
             }
-        if (p.stats) {
-            // Rows of one tile nearly always share a stat slot (a tile lies inside one bucket): then one atomic
-            // pair per wave.  Otherwise one pair per row.  Either way min/max are exact and order-free.
-            const unsigned long long have = __ballot(my_slot >= 0);
-            if (have) {
-                const int first = __shfl(my_slot, __ffsll(have) - 1);
-                const bool split = __any(mixed || (my_slot >= 0 && my_slot != first));
-                if (!split) {
-                    float lo = 0.0f, hi = 0.0f;
-#pragma unroll
-                    for (int i = 0; i < FM; ++i)
-#pragma unroll
-                        for (int reg = 0; reg < 4; ++reg) { lo = fminf(lo, rlo[i][reg]); hi = fmaxf(hi, rhi[i][reg]); }
-                    lo = wave_min(lo);
-                    hi = wave_max(hi);
-                    if (lane == 0) {
-                        atomicMin(&p.stats[2 * first], f32_to_ordered(lo));
-                        atomicMax(&p.stats[2 * first + 1], f32_to_ordered(hi));
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < FM; ++i)
-#pragma unroll
-                        for (int reg = 0; reg < 4; ++reg) {
-                            const int r = wm * WM + i * 16 + fq * 4 + reg;
-                            float a = rlo[i][reg], b = rhi[i][reg];
-#pragma unroll
-                            for (int o = 8; o > 0; o >>= 1) { a = fminf(a, __shfl_xor(a, o)); b = fmaxf(b, __shfl_xor(b, o)); }
-                            if (fr == 0 && r < rows) {
-                                const int s = p.slot_base + (p.row_slot ? p.row_slot[row0 + r] : 0);
-                                atomicMin(&p.stats[2 * s], f32_to_ordered(a));
-                                atomicMax(&p.stats[2 * s + 1], f32_to_ordered(b));
-                            }
-                        }
+        if (st) {
+            __syncthreads();
+            for (int i = tid; i < I64H_STAT_TAB; i += 256)
+                if (tab_lo[i] != I64H_ORDERED_ZERO || tab_hi[i] != I64H_ORDERED_ZERO) {
+                    uint32_t* q = p.stats + (int64_t)(p.out_slot_base + i) * I64H_SLOT_WORDS + 2 * (bid & (I64H_NSHARD - 1));
+                    atomicMin(q, tab_lo[i]);
+                    atomicMax(q + 1, tab_hi[i]);
                 }
+        }
+    }
+}
+
+template <int BM, int BN, int EPI, int AQ>
+__global__ __launch_bounds__(256) void gemm_i8_kernel(GemmI8Pair pp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x < pp.nblk0) gemm_i8_body<BM, BN, EPI, AQ>(pp.p[0], blockIdx.x, smem);
+    else gemm_i8_body<BM, BN, EPI, AQ>(pp.p[1], blockIdx.x - pp.nblk0, smem);
+}
+
+// ---- decode-sized problems: weight-streaming kernel with the quantizer in front ---------------------------------------
+// For M <= 64 rows per group the GEMM is a weight stream: every weight byte is used once per workgroup, so B goes
+// straight from global memory into MFMA fragments (16 B per lane per 64-deep K step, many steps in flight, no LDS round
+// trip), while the workgroup's (<= 64) operand rows are gathered, quantized with the parameters of their stat slots and
+// parked in LDS for the whole K (row stride K + 32 bytes: conflict-free ds_read_b128 fragments).
+// Workgroup = 4 waves; wave w owns output columns [16w, 16w+16) of the workgroup's 64 (EPI_SWIGLU: 16 gate columns and
+// their 16 up partners), all row fragments.
+#define SK_BM 16  // operand rows per workgroup: one MFMA row fragment (more, smaller workgroups; each reads 1/4 of a 64-row operand)
+#define SK_MF (SK_BM / 16)
+#define SK_STEPS 8  // K steps (64 deep) whose B fragments are in flight together
+
+template <int EPI, int NW>
+__device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const int bid, char* smem) {
+    constexpr int NF = (EPI == EPI_SWIGLU) ? 2 : 1;  // B fragments per wave per step
+    const int K = p.K, LDA = K + 32;
+    // LDS: A [64][LDA] int8 | info (16 B) | q_inv[64] q_scale[64] q_zp[64]
+    int* s_info = (int*)(smem + SK_BM * LDA);
+    float* q_inv = (float*)(smem + SK_BM * LDA + 16);
+    float* q_scale = q_inv + SK_BM;
+    int* q_zp = (int*)(q_scale + SK_BM);
+
+    const int nout = (EPI == EPI_SWIGLU) ? p.N / 2 : p.N;
+    constexpr int BNB = NW * 16, NT = NW * 64;  // output columns / threads per workgroup
+    const int n_tiles = (nout + BNB - 1) / BNB;
+    const int mt = bid / n_tiles, nt = bid % n_tiles;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) {
+        int g = -1, row0 = 0, rows = 0, acc_tiles = 0;
+        const int G = p.group_off ? p.G : 1;
+        for (int i = 0; i < G; ++i) {
+            const int b = p.group_off ? p.group_off[i] : 0;
+            const int e = p.group_off ? p.group_off[i + 1] : p.M_total;
+            const int tiles = (e - b + SK_BM - 1) / SK_BM;
+            if (mt < acc_tiles + tiles) {
+                g = i;
+                row0 = b + (mt - acc_tiles) * SK_BM;
+                rows = min(SK_BM, e - row0);
+                break;
+            }
+            acc_tiles += tiles;
+        }
+        s_info[0] = g; s_info[1] = row0; s_info[2] = rows;
+    }
+    __syncthreads();
+    const int g = s_info[0], row0 = s_info[1], rows = s_info[2];
+    if (g < 0) return;
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int nsteps = K / 64;  // K % 64 == 0 is required by the launcher
+    const int8_t* Bg = p.B + (int64_t)g * p.N * K;
+    const int I = p.N / 2;
+    // this lane's weight rows (output columns)
+    const int col = nt * BNB + wid * 16 + fr;
+    const bool col_ok = col < nout;
+    const int8_t* bp[NF];
+    bp[0] = Bg + (int64_t)(col_ok ? col : 0) * K + fq * 16;
+    if (NF == 2) bp[1] = Bg + (int64_t)(I + (col_ok ? col : 0)) * K + fq * 16;
+
+    // first batch of weight fragments in flight before anything else
+    v4i bq[NF][SK_STEPS];
+    auto bload = [&](int s0) {
+#pragma unroll
+        for (int s = 0; s < SK_STEPS; ++s) {
+            const int st = min(s0 + s, nsteps - 1);  // clamped: always a valid address, surplus fragments are not used
+#pragma unroll
+            for (int f = 0; f < NF; ++f) bq[f][s] = *(const v4i*)(bp[f] + st * 64);
+        }
+    };
+    bload(0);
+
+    // quantization parameters of the rows, then the operand rows themselves
+    if (tid < SK_BM) {
+        QParams q;
+        q.scale = 0.0f; q.inv_scale = 0.0f; q.zp = 0;
+        if (tid < rows) q = slot_qparams(p.stats, p.a_slot_base + (p.a_row_slot ? p.a_row_slot[row0 + tid] : 0));
+        q_inv[tid] = q.inv_scale; q_scale[tid] = q.scale; q_zp[tid] = q.zp;
+    }
+    __syncthreads();
+    const int mfr = (rows + 15) / 16;          // live row fragments
+    const int cpr = K / 16;                    // 16-element chunks per row
+    const int total_chunks = mfr * 16 * cpr;   // rows padded to whole fragments (padding rows are zero)
+    for (int c0 = tid; c0 < total_chunks; c0 += NT * 4) {
+        float4 f[4][4];
+        int rr[4], kc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * NT;
+            rr[u] = c / cpr;
+            kc[u] = c - rr[u] * cpr;
+            const bool ok = c < total_chunks && rr[u] < rows;
+            int64_t src = row0 + (ok ? rr[u] : 0);
+            if (p.a_src_row) src = p.a_src_row[src];
+            if (p.a_src_mod > 0) src = src % p.a_src_mod;
+            const float* ap = (const float*)p.A + src * K + kc[u] * 16;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f[u][e] = ok ? *(const float4*)(ap + e * 4) : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * NT;
+            if (c >= total_chunks) continue;
+            QParams q;
+            q.inv_scale = q_inv[rr[u]]; q.zp = q_zp[rr[u]]; q.scale = 0.0f;
+            uint32_t w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float4 v = f[u][e];
+                w[e] = (uint32_t)(quantize_u7_signed(v.x, q) & 255) | ((uint32_t)(quantize_u7_signed(v.y, q) & 255) << 8) |
+                       ((uint32_t)(quantize_u7_signed(v.z, q) & 255) << 16) | ((uint32_t)(quantize_u7_signed(v.w, q) & 255) << 24);
+            }
+            *(uint4*)(smem + rr[u] * LDA + kc[u] * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+    __syncthreads();
+
+    v4i acc[SK_MF][NF];
+#pragma unroll
+    for (int i = 0; i < SK_MF; ++i)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) acc[i][f] = (v4i){0, 0, 0, 0};
+    for (int s0 = 0; s0 < nsteps; s0 += SK_STEPS) {
+        v4i bc[NF][SK_STEPS];
+#pragma unroll
+        for (int s = 0; s < SK_STEPS; ++s)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) bc[f][s] = bq[f][s];
+        if (s0 + SK_STEPS < nsteps) bload(s0 + SK_STEPS);  // next batch streams in behind the MFMAs of this one
+#pragma unroll
+        for (int s = 0; s < SK_STEPS; ++s) {
+            if (s0 + s >= nsteps) break;
+#pragma unroll
+            for (int i = 0; i < SK_MF; ++i) {
+                if (i >= mfr) break;
+                const v4i a = *(const v4i*)(smem + (i * 16 + fr) * LDA + (s0 + s) * 64 + fq * 16);
+#pragma unroll
+                for (int f = 0; f < NF; ++f) acc[i][f] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bc[f][s], acc[i][f], 0, 0, 0);
             }
         }
     }
+
+    const float ws = p.w_scale[g];
+    if (EPI == EPI_STORE) {
+#pragma unroll
+        for (int i = 0; i < SK_MF; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = i * 16 + fq * 4 + reg;
+                if (r < rows && col_ok) p.C[(int64_t)(row0 + r) * p.N + col] = (float)acc[i][0][reg] * (q_scale[r] * ws);
+            }
+    } else {
+        __syncthreads();  // A tile no longer needed: reuse its memory for the per-workgroup statistics table
+        uint32_t* tab_lo = (uint32_t*)smem;
+        uint32_t* tab_hi = tab_lo + I64H_STAT_TAB;
+        const bool st = p.want_stats != 0;
+        if (st) {
+            for (int i = tid; i < I64H_STAT_TAB; i += NT) { tab_lo[i] = I64H_ORDERED_ZERO; tab_hi[i] = I64H_ORDERED_ZERO; }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < SK_MF; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = i * 16 + fq * 4 + reg;
+                const bool rok = r < rows;
+                const float m = rok ? q_scale[r] * ws : 0.0f;
+                const float gate = (float)acc[i][0][reg] * m;
+                const float up = (float)acc[i][NF - 1][reg] * m;
+                const float v = (gate / (1.0f + expf(-gate))) * up;
+                float a = 0.0f, b = 0.0f;
+                if (rok && col_ok) {
+                    p.C[(int64_t)(row0 + r) * I + col] = v;
+                    a = fminf(0.0f, v);
+                    b = fmaxf(0.0f, v);
+                }
+                if (st) {
+#pragma unroll
+                    for (int o = 8; o > 0; o >>= 1) { a = fminf(a, __shfl_xor(a, o)); b = fmaxf(b, __shfl_xor(b, o)); }
+                    if (fr == 0 && rok) {
+                        const int rel = p.out_row_slot ? p.out_row_slot[row0 + r] : 0;
+                        if (rel >= 0 && rel < I64H_STAT_TAB) {
+                            atomicMin(&tab_lo[rel], f32_to_ordered(a));
+                            atomicMax(&tab_hi[rel], f32_to_ordered(b));
+                        } else {
+                            stat_update(p.stats, p.out_slot_base + rel, bid, a, b);
+                        }
+                    }
+                }
+            }
+        if (st) {
+            __syncthreads();
+            for (int i = tid; i < I64H_STAT_TAB; i += NT)
+                if (tab_lo[i] != I64H_ORDERED_ZERO || tab_hi[i] != I64H_ORDERED_ZERO) {
+                    uint32_t* q = p.stats + (int64_t)(p.out_slot_base + i) * I64H_SLOT_WORDS + 2 * (bid & (I64H_NSHARD - 1));
+                    atomicMin(q, tab_lo[i]);
+                    atomicMax(q + 1, tab_hi[i]);
+                }
+        }
+    }
+}
+
+template <int EPI, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_i8_skinny_kernel(GemmI8Pair pp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x < pp.nblk0) gemm_i8_skinny_body<EPI, NW>(pp.p[0], blockIdx.x, smem);
+    else gemm_i8_skinny_body<EPI, NW>(pp.p[1], blockIdx.x - pp.nblk0, smem);
 }
 
 // ---- fp32 GEMM on the f32 matrix cores: C[M,N] = A[M,K] @ B[N,K]^T ------------------------------------------------
@@ -367,37 +623,150 @@ __global__ __launch_bounds__(256) void gemm_w8a32_kernel(const float* __restrict
 }
 
 // =====================================================================================================
-template <int BM, int BN, int EPI>
-static int launch_gemm_i8(const GemmI8Args& p, hipStream_t st) {
-    const int G = p.group_off ? p.G : 1;
-    const int n_tiles = (EPI == EPI_SWIGLU) ? ((p.N / 2) + BN / 2 - 1) / (BN / 2) : (p.N + BN - 1) / BN;
-    const int m_tiles = (p.M_total + BM - 1) / BM + G;  // upper bound: every group may add one partial tile
-    const size_t lds = 2 * (BM + BN) * BK + 16;
-    hipLaunchKernelGGL((gemm_i8_kernel<BM, BN, EPI>), dim3((unsigned)(m_tiles * n_tiles)), dim3(256), lds, st, p);
+// host-side descriptor of one grouped problem: mirrors i64h_gemm_desc in include/i64h.h
+struct i64h_gemm_desc {
+    const void* A;
+    int32_t a_fp32;
+    const int32_t* a_src_row;
+    int32_t a_src_mod;
+    const float* row_scale;
+    const int32_t* a_row_slot;
+    int32_t a_slot_base;
+    const int8_t* B;
+    const float* w_scale;
+    const int32_t* group_offsets;
+    int32_t num_groups;
+    int64_t M_total;
+    int32_t N, K;
+    float* C;
+    int32_t epilogue;
+    const int32_t* out_row_slot;
+    int32_t out_slot_base;
+    uint32_t* stats;
+    int32_t want_stats;
+};
+
+static int check_desc(const i64h_gemm_desc* d, const char* who) {
+    I64H_CHECK_ARG(d->M_total >= 0 && d->M_total < (1ll << 31) && d->N > 0 && d->K > 0, "%s: bad sizes", who);
+    I64H_CHECK_ARG(d->K % 16 == 0, "%s: K=%d must be a multiple of 16", who, d->K);
+    I64H_CHECK_ARG(((uintptr_t)d->A | (uintptr_t)d->B) % 16 == 0, "%s: operands must be 16-byte aligned", who);
+    I64H_CHECK_ARG(d->num_groups >= 1 && d->num_groups <= MAX_GROUPS, "%s: %d groups unsupported", who, d->num_groups);
+    I64H_CHECK_ARG(d->epilogue == EPI_STORE || (d->epilogue == EPI_SWIGLU && d->N % 2 == 0), "%s: bad epilogue %d / N=%d", who, d->epilogue, d->N);
+    I64H_CHECK_ARG(!d->a_fp32 || d->stats != nullptr, "%s: fp32 operand needs the stat slots", who);
+    I64H_CHECK_ARG(d->a_fp32 || d->row_scale != nullptr, "%s: int8 operand needs row_scale", who);
+    I64H_CHECK_ARG(!d->want_stats || (d->stats != nullptr && d->epilogue == EPI_SWIGLU), "%s: statistics need the SwiGLU epilogue and stat slots", who);
+    return 0;
+}
+
+static GemmI8Args to_args(const i64h_gemm_desc* d) {
+    GemmI8Args p;
+    p.A = d->A; p.a_src_row = d->a_src_row; p.a_src_mod = d->a_src_mod; p.row_scale = d->row_scale; p.a_row_slot = d->a_row_slot;
+    p.a_slot_base = d->a_slot_base; p.B = d->B; p.w_scale = d->w_scale; p.group_off = d->group_offsets; p.G = d->num_groups;
+    p.M_total = (int)d->M_total; p.N = d->N; p.K = d->K; p.C = d->C; p.out_row_slot = d->out_row_slot; p.out_slot_base = d->out_slot_base;
+    p.stats = d->stats; p.want_stats = d->want_stats;
+    return p;
+}
+
+template <int BM, int BN>
+static int nblocks_of(const i64h_gemm_desc* d) {
+    const int G = d->group_offsets ? d->num_groups : 1;
+    const int n_tiles = (d->epilogue == EPI_SWIGLU) ? ((d->N / 2) + BN / 2 - 1) / (BN / 2) : (d->N + BN - 1) / BN;
+    const int m_tiles = (int)((d->M_total + BM - 1) / BM) + G;  // upper bound: every group may add one partial tile
+    return d->M_total == 0 ? 0 : m_tiles * n_tiles;
+}
+
+template <int BM, int BN, int EPI, int AQ>
+static int launch_pair(const i64h_gemm_desc* a, const i64h_gemm_desc* b, hipStream_t st) {
+    GemmI8Pair pp;
+    pp.p[0] = to_args(a);
+    pp.p[1] = b ? to_args(b) : pp.p[0];
+    pp.nblk0 = nblocks_of<BM, BN>(a);
+    const int total = pp.nblk0 + (b ? nblocks_of<BM, BN>(b) : 0);
+    if (total == 0) return 0;
+    const size_t lds = 2 * (BM + BN) * BK + 16 + 3 * BM * 4;
+    hipLaunchKernelGGL((gemm_i8_kernel<BM, BN, EPI, AQ>), dim3((unsigned)total), dim3(256), lds, st, pp);
     I64H_CHECK_LAUNCH();
     return 0;
 }
 
+static int skinny_blocks(const i64h_gemm_desc* d, int bnb) {
+    const int G = d->group_offsets ? d->num_groups : 1;
+    const int nout = d->epilogue == EPI_SWIGLU ? d->N / 2 : d->N;
+    const int m_tiles = (int)((d->M_total + SK_BM - 1) / SK_BM) + G;
+    return d->M_total == 0 ? 0 : m_tiles * ((nout + bnb - 1) / bnb);
+}
+
+static int g_skinny_waves = 0;  // 0 = default; test/tuning override through i64h_set_skinny_waves
+
+template <int EPI, int NW>
+static int launch_skinny(const i64h_gemm_desc* a, const i64h_gemm_desc* b, hipStream_t st) {
+    GemmI8Pair pp;
+    pp.p[0] = to_args(a);
+    pp.p[1] = b ? to_args(b) : pp.p[0];
+    pp.nblk0 = skinny_blocks(a, NW * 16);
+    const int total = pp.nblk0 + (b ? skinny_blocks(b, NW * 16) : 0);
+    if (total == 0) return 0;
+    const int kmax = b && b->K > a->K ? b->K : a->K;
+    const size_t lds = (size_t)SK_BM * (kmax + 32) + 16 + 3 * SK_BM * 4;
+    hipLaunchKernelGGL((gemm_i8_skinny_kernel<EPI, NW>), dim3((unsigned)total), dim3(NW * 64), lds, st, pp);
+    I64H_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int EPI>
+static int launch_skinny_nw(const i64h_gemm_desc* a, const i64h_gemm_desc* b, hipStream_t st) {
+    const int nw = g_skinny_waves ? g_skinny_waves : 4;
+    if (nw == 4) return launch_skinny<EPI, 4>(a, b, st);
+    if (nw == 16) return launch_skinny<EPI, 16>(a, b, st);
+    return launch_skinny<EPI, 8>(a, b, st);
+}
+
+static bool skinny_ok(const i64h_gemm_desc* d) {
+    // weight-streaming kernel: fp32 operand, K a multiple of 64 that fits LDS, few rows per group
+    return d->a_fp32 && d->K % 64 == 0 && d->K <= 2048 && d->M_total <= 512;
+}
+
 extern "C" {
+
+// tuning knob: waves per workgroup of the weight-streaming kernel (4, 8 or 16; 0 = default)
+int i64h_set_skinny_waves(int32_t waves) {
+    I64H_CHECK_ARG(waves == 0 || waves == 4 || waves == 8 || waves == 16, "set_skinny_waves: %d not in {0,4,8,16}", waves);
+    g_skinny_waves = waves;
+    return 0;
+}
+
+// One launch for up to two grouped problems with the same epilogue and operand kind (e.g. the routed experts and the
+// shared expert of one MoE layer).  b may be NULL.
+int i64h_gemm_i8_pair(const i64h_gemm_desc* a, const i64h_gemm_desc* b, void* stream) {
+    I64H_CHECK_ARG(a != nullptr, "gemm_i8_pair: first problem missing");
+    if (check_desc(a, "gemm_i8_pair[0]")) return 1;
+    if (b) {
+        if (check_desc(b, "gemm_i8_pair[1]")) return 1;
+        I64H_CHECK_ARG(a->epilogue == b->epilogue && a->a_fp32 == b->a_fp32, "gemm_i8_pair: problems must share epilogue and operand kind");
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (skinny_ok(a) && (!b || skinny_ok(b)))
+        return a->epilogue == EPI_STORE ? launch_skinny_nw<EPI_STORE>(a, b, st) : launch_skinny_nw<EPI_SWIGLU>(a, b, st);
+    const int64_t rows = a->M_total / a->num_groups;
+    const bool big = !a->a_fp32 && rows >= 256;  // fp32 operands are meant for small M (quantized per workgroup)
+    if (a->epilogue == EPI_STORE) {
+        if (a->a_fp32) return launch_pair<64, 64, EPI_STORE, 1>(a, b, st);
+        return big ? launch_pair<128, 128, EPI_STORE, 0>(a, b, st) : launch_pair<64, 64, EPI_STORE, 0>(a, b, st);
+    }
+    if (a->a_fp32) return launch_pair<64, 64, EPI_SWIGLU, 1>(a, b, st);
+    return big ? launch_pair<128, 128, EPI_SWIGLU, 0>(a, b, st) : launch_pair<64, 64, EPI_SWIGLU, 0>(a, b, st);
+}
 
 // epilogue: 0 = store fp32 [M_total, N]; 1 = SwiGLU -> fp32 [M_total, N/2] (+ optional statistics)
 int i64h_gemm_i8(const int8_t* A, const float* row_scale, const int8_t* B, const float* w_scale, const int32_t* group_offsets,
                  int32_t num_groups, int64_t M_total, int32_t N, int32_t K, float* C, int32_t epilogue, const int32_t* row_slot,
                  int32_t slot_base, uint32_t* stats, void* stream) {
-    I64H_CHECK_ARG(M_total >= 0 && M_total < (1ll << 31) && N > 0 && K > 0, "gemm_i8: bad sizes");
-    I64H_CHECK_ARG(K % 16 == 0, "gemm_i8: K=%d must be a multiple of 16", K);
-    I64H_CHECK_ARG(((uintptr_t)A | (uintptr_t)B) % 16 == 0, "gemm_i8: operands must be 16-byte aligned");
-    I64H_CHECK_ARG(num_groups >= 1 && num_groups <= MAX_GROUPS, "gemm_i8: %d groups unsupported", num_groups);
-    I64H_CHECK_ARG(epilogue == EPI_STORE || (epilogue == EPI_SWIGLU && N % 2 == 0), "gemm_i8: bad epilogue %d / N=%d", epilogue, N);
-    if (M_total == 0) return 0;
-    GemmI8Args p;
-    p.A = A; p.row_scale = row_scale; p.B = B; p.w_scale = w_scale; p.group_off = group_offsets; p.G = num_groups;
-    p.M_total = (int)M_total; p.N = N; p.K = K; p.C = C; p.row_slot = row_slot; p.stats = stats; p.slot_base = slot_base;
-    hipStream_t st = (hipStream_t)stream;
-    const int64_t avg = M_total / num_groups;
-    const bool big = avg >= 256;
-    if (epilogue == EPI_STORE) return big ? launch_gemm_i8<128, 128, EPI_STORE>(p, st) : launch_gemm_i8<64, 64, EPI_STORE>(p, st);
-    return big ? launch_gemm_i8<128, 128, EPI_SWIGLU>(p, st) : launch_gemm_i8<64, 64, EPI_SWIGLU>(p, st);
+    i64h_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.A = A; d.row_scale = row_scale; d.B = B; d.w_scale = w_scale; d.group_offsets = group_offsets; d.num_groups = num_groups;
+    d.M_total = M_total; d.N = N; d.K = K; d.C = C; d.epilogue = epilogue; d.out_row_slot = row_slot; d.out_slot_base = slot_base;
+    d.stats = stats; d.want_stats = stats != nullptr && epilogue == EPI_SWIGLU;
+    return i64h_gemm_i8_pair(&d, nullptr, stream);
 }
 
 int i64h_gemm_f32(const float* A, const int32_t* a_rows, const float* B, float* C, int64_t M, int32_t N, int32_t K, void* stream) {

@@ -55,86 +55,89 @@ struct MoeCombine {
 
 #define FRN_MAXV 4  // float4 per thread => H <= 4096
 __global__ __launch_bounds__(256) void fused_residual_norm_kernel(const float* __restrict__ h, const float* __restrict__ add,
-                                                                  MoeCombine mc, int n, float* __restrict__ h_out,
+                                                                  MoeCombine mc, int n, int rpb, float* __restrict__ h_out,
                                                                   const float* __restrict__ w, float eps, float* __restrict__ normed,
                                                                   int H, const int32_t* __restrict__ slots, int spr, int slot_base,
                                                                   uint32_t* __restrict__ stats) {
     __shared__ float red[4], rlo[4], rhi[4];
     __shared__ float bc;
-    const int64_t t = blockIdx.x;
+    __shared__ float tab_lo[I64H_STAT_TAB], tab_hi[I64H_STAT_TAB];
+    if (stats) stat_tab_init(tab_lo, tab_hi);
+    __syncthreads();
     const int nv = H / 4;
-    float4 v[FRN_MAXV];
-    float ss = 0.0f;
+    const int64_t t0 = (int64_t)blockIdx.x * rpb;
+    const int64_t t1 = t0 + rpb < n ? t0 + rpb : n;
+    for (int64_t t = t0; t < t1; ++t) {
+        float4 v[FRN_MAXV];
+        float ss = 0.0f;
 #pragma unroll
-    for (int j = 0; j < FRN_MAXV; ++j) {
-        const int i = threadIdx.x + j * 256;
-        if (i < nv) {
-            float4 a = ((const float4*)(h + t * H))[i];
-            if (add) {
-                float4 b = ((const float4*)(add + t * H))[i];
-                a.x = a.x + b.x; a.y = a.y + b.y; a.z = a.z + b.z; a.w = a.w + b.w;
-            }
-            if (mc.rows) {
-                float4 r0 = ((const float4*)(mc.rows + (int64_t)mc.inv[t] * H))[i];
-                float4 o = make_float4(mc.wk[0] * r0.x, mc.wk[0] * r0.y, mc.wk[0] * r0.z, mc.wk[0] * r0.w);
-                for (int k = 1; k < mc.top_k; ++k) {
-                    float4 rk = ((const float4*)(mc.rows + (int64_t)mc.inv[(int64_t)k * n + t] * H))[i];
-                    o.x = o.x + mc.wk[k] * rk.x; o.y = o.y + mc.wk[k] * rk.y;
-                    o.z = o.z + mc.wk[k] * rk.z; o.w = o.w + mc.wk[k] * rk.w;
+        for (int j = 0; j < FRN_MAXV; ++j) {
+            const int i = threadIdx.x + j * 256;
+            if (i < nv) {
+                float4 a = ((const float4*)(h + t * H))[i];
+                if (add) {
+                    float4 b = ((const float4*)(add + t * H))[i];
+                    a.x = a.x + b.x; a.y = a.y + b.y; a.z = a.z + b.z; a.w = a.w + b.w;
                 }
-                if (mc.shared) {
-                    float4 s = ((const float4*)(mc.shared + t * H))[i];
-                    o.x = mc.routed_scale * o.x + mc.shared_scale * s.x; o.y = mc.routed_scale * o.y + mc.shared_scale * s.y;
-                    o.z = mc.routed_scale * o.z + mc.shared_scale * s.z; o.w = mc.routed_scale * o.w + mc.shared_scale * s.w;
-                } else {
-                    o.x = mc.routed_scale * o.x; o.y = mc.routed_scale * o.y; o.z = mc.routed_scale * o.z; o.w = mc.routed_scale * o.w;
+                if (mc.rows) {
+                    float4 r0 = ((const float4*)(mc.rows + (int64_t)mc.inv[t] * H))[i];
+                    float4 o = make_float4(mc.wk[0] * r0.x, mc.wk[0] * r0.y, mc.wk[0] * r0.z, mc.wk[0] * r0.w);
+                    for (int k = 1; k < mc.top_k; ++k) {
+                        float4 rk = ((const float4*)(mc.rows + (int64_t)mc.inv[(int64_t)k * n + t] * H))[i];
+                        o.x = o.x + mc.wk[k] * rk.x; o.y = o.y + mc.wk[k] * rk.y;
+                        o.z = o.z + mc.wk[k] * rk.z; o.w = o.w + mc.wk[k] * rk.w;
+                    }
+                    if (mc.shared) {
+                        float4 s = ((const float4*)(mc.shared + t * H))[i];
+                        o.x = mc.routed_scale * o.x + mc.shared_scale * s.x; o.y = mc.routed_scale * o.y + mc.shared_scale * s.y;
+                        o.z = mc.routed_scale * o.z + mc.shared_scale * s.z; o.w = mc.routed_scale * o.w + mc.shared_scale * s.w;
+                    } else {
+                        o.x = mc.routed_scale * o.x; o.y = mc.routed_scale * o.y; o.z = mc.routed_scale * o.z; o.w = mc.routed_scale * o.w;
+                    }
+                    a.x = a.x + o.x; a.y = a.y + o.y; a.z = a.z + o.z; a.w = a.w + o.w;
                 }
-                a.x = a.x + o.x; a.y = a.y + o.y; a.z = a.z + o.z; a.w = a.w + o.w;
+                if (h_out) ((float4*)(h_out + t * H))[i] = a;
+                v[j] = a;
+                ss = __builtin_fmaf(a.x, a.x, ss); ss = __builtin_fmaf(a.y, a.y, ss);
+                ss = __builtin_fmaf(a.z, a.z, ss); ss = __builtin_fmaf(a.w, a.w, ss);
             }
-            if (h_out) ((float4*)(h_out + t * H))[i] = a;
-            v[j] = a;
-            ss = __builtin_fmaf(a.x, a.x, ss); ss = __builtin_fmaf(a.y, a.y, ss);
-            ss = __builtin_fmaf(a.z, a.z, ss); ss = __builtin_fmaf(a.w, a.w, ss);
         }
-    }
-    if (!normed) return;
-    ss = wave_sum(ss);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
-    __syncthreads();
-    if (threadIdx.x == 0) bc = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)H + eps);
-    __syncthreads();
-    const float rr = bc;
-    float lo = 0.0f, hi = 0.0f;
+        if (!normed) continue;  // uniform for the whole grid
+        ss = wave_sum(ss);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+        __syncthreads();
+        if (threadIdx.x == 0) bc = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)H + eps);
+        __syncthreads();
+        const float rr = bc;
+        float lo = 0.0f, hi = 0.0f;
 #pragma unroll
-    for (int j = 0; j < FRN_MAXV; ++j) {
-        const int i = threadIdx.x + j * 256;
-        if (i < nv) {
-            float4 g = ((const float4*)w)[i];
-            float4 a = v[j];
-            a.x = a.x * rr * g.x; a.y = a.y * rr * g.y; a.z = a.z * rr * g.z; a.w = a.w * rr * g.w;
-            ((float4*)(normed + t * H))[i] = a;
-            lo = fminf(lo, fminf(fminf(a.x, a.y), fminf(a.z, a.w)));
-            hi = fmaxf(hi, fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)));
+        for (int j = 0; j < FRN_MAXV; ++j) {
+            const int i = threadIdx.x + j * 256;
+            if (i < nv) {
+                float4 g = ((const float4*)w)[i];
+                float4 a = v[j];
+                a.x = a.x * rr * g.x; a.y = a.y * rr * g.y; a.z = a.z * rr * g.z; a.w = a.w * rr * g.w;
+                ((float4*)(normed + t * H))[i] = a;
+                lo = fminf(lo, fminf(fminf(a.x, a.y), fminf(a.z, a.w)));
+                hi = fmaxf(hi, fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)));
+            }
         }
-    }
-    if (!stats) return;
-    lo = wave_min(lo);
-    hi = wave_max(hi);
-    if ((threadIdx.x & 63) == 0) {
-        rlo[threadIdx.x >> 6] = lo;
-        rhi[threadIdx.x >> 6] = hi;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        lo = fminf(fminf(rlo[0], rlo[1]), fminf(rlo[2], rlo[3]));
-        hi = fmaxf(fmaxf(rhi[0], rhi[1]), fmaxf(rhi[2], rhi[3]));
-        const int ns = slots ? spr : 1;
-        for (int j = 0; j < ns; ++j) {
-            const int s = slot_base + (slots ? slots[t * spr + j] : 0);
-            atomicMin(&stats[2 * s], f32_to_ordered(lo));
-            atomicMax(&stats[2 * s + 1], f32_to_ordered(hi));
+        if (!stats) continue;  // uniform for the whole grid
+        lo = wave_min(lo);
+        hi = wave_max(hi);
+        if ((threadIdx.x & 63) == 0) {
+            rlo[threadIdx.x >> 6] = lo;
+            rhi[threadIdx.x >> 6] = hi;
         }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            lo = fminf(fminf(rlo[0], rlo[1]), fminf(rlo[2], rlo[3]));
+            hi = fmaxf(fmaxf(rhi[0], rhi[1]), fmaxf(rhi[2], rhi[3]));
+            stat_tab_fold(tab_lo, tab_hi, slots ? slots + t * spr : nullptr, slots ? spr : 1, lo, hi, stats, slot_base, blockIdx.x);
+        }
+        __syncthreads();
     }
+    if (stats && normed) stat_tab_flush(tab_lo, tab_hi, stats, slot_base, blockIdx.x);
 }
 
 // ---- per-head QK RMSNorm + rotate-half RoPE + paged KV write ----------------------------------------------
@@ -359,8 +362,9 @@ int i64h_fused_residual_norm(const float* h, const float* add, const float* moe_
     for (int k = 0; k < 8; ++k) mc.wk[k] = (moe_rows && k < top_k) ? route_weights[k] : 0.0f;
     mc.routed_scale = routed_scale;
     mc.shared_scale = shared_scale;
-    hipLaunchKernelGGL(fused_residual_norm_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, h, add, mc, (int)n, h_out,
-                       norm_weight, eps, normed, (int)H, slots, (int)slots_per_row, (int)slot_base, stats);
+    const int rpb = n > 2048 ? 8 : 1;  // many rows: fold 8 rows per workgroup before touching the global stat slots
+    hipLaunchKernelGGL(fused_residual_norm_kernel, dim3((unsigned)i64h_cdiv(n, rpb)), dim3(256), 0, (hipStream_t)stream, h, add, mc,
+                       (int)n, rpb, h_out, norm_weight, eps, normed, (int)H, slots, (int)slots_per_row, (int)slot_base, stats);
     I64H_CHECK_LAUNCH();
     return 0;
 }

@@ -4,7 +4,8 @@
 // min/max run over every row of the call, one scale for a whole fused weight matrix).  The min/max of a
 // call live in a "stat slot": two uint32 holding order-preserving encodings of float min and max, updated
 // with integer atomicMin/atomicMax (exact, arrival order irrelevant) by whichever kernel produces the
-// activations, and turned into (scale, zero point) by the quantizer below.
+// activations, and turned into (scale, zero point) by the quantizer below.  A slot is sharded (I64H_NSHARD pairs,
+// I64H_SLOT_WORDS words) to spread the atomics; i64h_stats_words_per_slot() tells the host how much to allocate.
 //
 // "sym" = the operator-API scheme of the reference's GPU kernels (per-row symmetric int8).
 #include "i64h_common.h"
@@ -16,35 +17,48 @@ __global__ void stats_reset_kernel(uint32_t* __restrict__ stats, int64_t n_words
 }
 
 // min/max of each row folded into the row's stat slots. slots == nullptr: every row -> slot_base.
-__global__ __launch_bounds__(256) void rows_minmax_kernel(const float* __restrict__ x, int64_t rows, int K,
+// A workgroup handles rows [blockIdx.x * rpb, +rpb) and flushes one atomic pair per slot it touched.
+__global__ __launch_bounds__(256) void rows_minmax_kernel(const float* __restrict__ x, int64_t rows, int K, int rpb,
                                                           const int32_t* __restrict__ slots, int slots_per_row, int slot_base,
                                                           uint32_t* __restrict__ stats) {
     __shared__ float smin[4], smax[4];
-    const int64_t r = blockIdx.x;
-    const float* xr = x + r * K;
-    float lo = 0.0f, hi = 0.0f;
-    for (int i = threadIdx.x; i < K; i += 256) {
-        float v = xr[i];
-        lo = fminf(lo, v);
-        hi = fmaxf(hi, v);
-    }
-    lo = wave_min(lo);
-    hi = wave_max(hi);
-    if ((threadIdx.x & 63) == 0) {
-        smin[threadIdx.x >> 6] = lo;
-        smax[threadIdx.x >> 6] = hi;
-    }
+    __shared__ float tab_lo[I64H_STAT_TAB], tab_hi[I64H_STAT_TAB];
+    stat_tab_init(tab_lo, tab_hi);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        lo = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
-        hi = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
-        const int ns = slots ? slots_per_row : 1;
-        for (int j = 0; j < ns; ++j) {
-            int s = slot_base + (slots ? slots[r * slots_per_row + j] : 0);
-            atomicMin(&stats[2 * s], f32_to_ordered(lo));
-            atomicMax(&stats[2 * s + 1], f32_to_ordered(hi));
+    const int64_t r0 = (int64_t)blockIdx.x * rpb;
+    const int64_t r1 = r0 + rpb < rows ? r0 + rpb : rows;
+    for (int64_t r = r0; r < r1; ++r) {
+        const float* xr = x + r * K;
+        float lo = 0.0f, hi = 0.0f;
+        if ((K & 3) == 0) {
+            for (int i = threadIdx.x * 4; i < K; i += 1024) {
+                float4 v = *(const float4*)(xr + i);
+                lo = fminf(lo, fminf(fminf(v.x, v.y), fminf(v.z, v.w)));
+                hi = fmaxf(hi, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+            }
+        } else {
+            for (int i = threadIdx.x; i < K; i += 256) {
+                float v = xr[i];
+                lo = fminf(lo, v);
+                hi = fmaxf(hi, v);
+            }
         }
+        lo = wave_min(lo);
+        hi = wave_max(hi);
+        if ((threadIdx.x & 63) == 0) {
+            smin[threadIdx.x >> 6] = lo;
+            smax[threadIdx.x >> 6] = hi;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            lo = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
+            hi = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+            stat_tab_fold(tab_lo, tab_hi, slots ? slots + r * slots_per_row : nullptr, slots ? slots_per_row : 1, lo, hi, stats,
+                          slot_base, blockIdx.x);
+        }
+        __syncthreads();
     }
+    stat_tab_flush(tab_lo, tab_hi, stats, slot_base, blockIdx.x);
 }
 
 // Quantize rows with the parameters of their stat slot.
@@ -55,14 +69,17 @@ __global__ __launch_bounds__(256) void quantize_dynamic_kernel(const float* __re
                                                                int src_mod, const int32_t* __restrict__ row_slot, int slot_base,
                                                                const uint32_t* __restrict__ stats, int8_t* __restrict__ a,
                                                                float* __restrict__ row_scale, int32_t* __restrict__ row_zp) {
+    __shared__ QParams sq;
     const int64_t r = blockIdx.x;
     const int64_t sr = src_row ? (int64_t)(src_row[r] % src_mod) : r;
-    const int slot = slot_base + (row_slot ? row_slot[r] : 0);
-    const QParams q = choose_qparams_u7(ordered_to_f32(stats[2 * slot]), ordered_to_f32(stats[2 * slot + 1]));
     if (threadIdx.x == 0) {
-        row_scale[r] = q.scale;
-        if (row_zp) row_zp[r] = q.zp;
+        const int slot = slot_base + (row_slot ? row_slot[r] : 0);
+        sq = slot_qparams(stats, slot);
+        row_scale[r] = sq.scale;
+        if (row_zp) row_zp[r] = sq.zp;
     }
+    __syncthreads();
+    const QParams q = sq;
     const float* xr = x + sr * K;
     int8_t* ar = a + r * K;
     if ((K & 3) == 0) {
@@ -83,7 +100,8 @@ __global__ void qparams_kernel(const uint32_t* __restrict__ stats, int n_slots, 
                                float* __restrict__ lo_hi) {
     int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_slots) return;
-    float lo = ordered_to_f32(stats[2 * s]), hi = ordered_to_f32(stats[2 * s + 1]);
+    float lo, hi;
+    stat_read(stats, s, lo, hi);
     QParams q = choose_qparams_u7(lo, hi);
     scale[s] = q.scale;
     zp[s] = q.zp;
@@ -146,10 +164,13 @@ __global__ void dequant_rows_kernel(const int8_t* __restrict__ q, const float* _
 // =====================================================================================================
 extern "C" {
 
+int i64h_stats_words_per_slot(void) { return I64H_SLOT_WORDS; }
+
 int i64h_stats_reset(uint32_t* stats, int64_t n_slots, void* stream) {
     I64H_CHECK_ARG(n_slots >= 0, "stats_reset: bad slot count");
     if (n_slots == 0) return 0;
-    hipLaunchKernelGGL(stats_reset_kernel, dim3(i64h_cdiv(2 * n_slots, 256)), dim3(256), 0, (hipStream_t)stream, stats, 2 * n_slots);
+    hipLaunchKernelGGL(stats_reset_kernel, dim3(i64h_cdiv(I64H_SLOT_WORDS * n_slots, 256)), dim3(256), 0, (hipStream_t)stream, stats,
+                       (int64_t)I64H_SLOT_WORDS * n_slots);
     I64H_CHECK_LAUNCH();
     return 0;
 }
@@ -158,8 +179,9 @@ int i64h_rows_minmax(const float* x, int64_t rows, int32_t K, const int32_t* slo
                      uint32_t* stats, void* stream) {
     I64H_CHECK_ARG(rows >= 0 && K > 0, "rows_minmax: bad sizes");
     if (rows == 0) return 0;
-    hipLaunchKernelGGL(rows_minmax_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, rows, (int)K, slots,
-                       (int)slots_per_row, (int)slot_base, stats);
+    const int rpb = rows > 2048 ? 16 : 1;  // many rows: fold 16 rows per workgroup before touching the global slots
+    hipLaunchKernelGGL(rows_minmax_kernel, dim3((unsigned)i64h_cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)stream, x, rows, (int)K, rpb,
+                       slots, (int)slots_per_row, (int)slot_base, stats);
     I64H_CHECK_LAUNCH();
     return 0;
 }

@@ -173,11 +173,16 @@ class I64MoEModel:
             self._bufs[key] = _Buffers(self.cfg, n, n_logit_rows, self.device)
         return self._bufs[key]
 
+    FUSE_MAX_ROWS = 256  # up to this many operand rows the quantizer runs inside the GEMM (one launch per Linear call)
+
     def _linear(self, x, pl: PackedLinear, slot: int, xa, xs, out, epilogue=ops.EPI_STORE, stats_slot: Optional[int] = None):
         """One dense dynamic-int8 Linear call: quantize with the call's statistics, int8 GEMM, fp32 rescale."""
-        ops_call = ops.call
         n, K = x.shape
-        ops_call("i64h_quantize_dynamic", ops.ptr(x), n, K, 0, 0, 0, slot, ops.ptr(self.stats), ops.ptr(xa), ops.ptr(xs), 0, ops._stream())
+        if n <= self.FUSE_MAX_ROWS:
+            ops.gemm_i8_pair(ops.gemm_desc(x, pl.w_q, pl.w_s, out, a_slot_base=slot, epilogue=epilogue, out_slot_base=stats_slot or 0,
+                                           stats=self.stats, want_stats=stats_slot is not None))
+            return out
+        ops.call("i64h_quantize_dynamic", ops.ptr(x), n, K, 0, 0, 0, slot, ops.ptr(self.stats), ops.ptr(xa), ops.ptr(xs), 0, ops._stream())
         ops.gemm_i8(xa, xs, pl.w_q, pl.w_s, epilogue=epilogue, slot_base=stats_slot or 0,
                     stats=self.stats if stats_slot is not None else None, out=out)
         return out
@@ -200,10 +205,10 @@ class I64MoEModel:
             B.plan.run(token_ids, self.tables)
         ops.stats_reset(st)
         ops.embedding(token_ids, self.embed, out=B.h)
-        # attention splits: enough workgroups to fill the chip when few rows carry long contexts
+        # attention splits: enough workgroups to fill the chip when few rows carry long contexts (decode)
         splits = 1
-        if max_ctx_hint > 0 and n * cfg.num_kv_heads < 1024:
-            splits = max(1, min(16, 1024 // max(1, n * cfg.num_kv_heads), (max_ctx_hint + 255) // 256))
+        if max_ctx_hint >= 256 and n <= 256:
+            splits = max(1, min(32, 512 // n, max_ctx_hint // 64))
         if splits > 1 and (B.attn_ws is None or B.attn_splits != splits):
             B.attn_ws = torch.empty(ops._lib.load().i64h_paged_attn_workspace_floats(n, cfg.num_heads, cfg.head_dim, splits),
                                     dtype=torch.float32, device=self.device)
@@ -213,7 +218,7 @@ class I64MoEModel:
             base = l * spl
             if inject is not None and l in inject:
                 B.h.copy_(inject[l])
-                ops.stats_reset(st[2 * base: 2 * base + 2])
+                ops.stats_reset(ops.stats_view(st, base))
                 ops.fused_residual_norm(B.h, W["ln1"], eps, h_out=B.h, normed=B.normed, slot_base=base, stats=st)
             if record is not None:
                 record[f"l{l}.in"] = B.h.clone()
@@ -221,11 +226,13 @@ class I64MoEModel:
             ops.qk_norm_rope_kv(B.qkv, W["q_norm"], W["k_norm"], 1e-6, self.rope, positions, slot_ids, self.kv.block_table,
                                 self.kv.k[l], self.kv.v[l], cfg.num_heads, cfg.num_kv_heads, cfg.head_dim, q_out=B.q)
             ops.paged_attn(B.q, self.kv.k[l], self.kv.v[l], self.kv.block_table, ctx_len, slot_ids=slot_ids,
-                           softmax_scale=1.0 / math.sqrt(cfg.head_dim), splits=splits, out=B.attn, workspace=B.attn_ws)
+                           softmax_scale=1.0 / math.sqrt(cfg.head_dim), splits=splits, out=B.attn, workspace=B.attn_ws,
+                           stats=st if splits > 1 else None, stat_slot=base + 1)
             attn2d = B.attn.view(n, H)
             if record is not None:
                 record[f"l{l}.attn_out"] = attn2d.clone()
-            ops.rows_minmax(attn2d, st, slot_base=base + 1)
+            if splits == 1:
+                ops.rows_minmax(attn2d, st, slot_base=base + 1)
             self._linear(attn2d, W["o"], base + 1, B.xa, B.xs, B.o)
             if cfg.is_moe:
                 # h += o ; normed = ln2(h) ; statistics for the shared call and for every (route, expert) bucket
@@ -264,7 +271,23 @@ class I64MoEModel:
         cfg, st, nbk = self.cfg, self.stats, self.nb
         plan = B.plan
         n, R = plan.n, plan.rows
-        if cfg.shared_intermediate_size:
+        shared = bool(cfg.shared_intermediate_size)
+        if R <= self.FUSE_MAX_ROWS and R > 0:
+            # decode-sized step: two launches per layer.  Each holds the routed experts (rows gathered in bucket order, every
+            # (route, expert) bucket quantized with its own statistics) and the shared expert as a second problem.
+            e_gu = ops.gemm_desc(B.normed, W["exp_gu"].w_q, W["exp_gu"].w_s, B.e_inter, a_src_row=plan.perm[l], a_src_mod=n,
+                                 a_row_slot=plan.sorted_bucket[l], a_slot_base=base + 3, group_offsets=plan.expert_offsets[l],
+                                 epilogue=ops.EPI_SWIGLU, out_row_slot=plan.sorted_bucket[l], out_slot_base=base + 4 + nbk, stats=st,
+                                 want_stats=True, m_total=R)
+            s_gu = ops.gemm_desc(B.normed, W["sh_gu"].w_q, W["sh_gu"].w_s, B.sh_inter, a_slot_base=base + 2, epilogue=ops.EPI_SWIGLU,
+                                 out_slot_base=base + 3 + nbk, stats=st, want_stats=True) if shared else None
+            ops.gemm_i8_pair(e_gu, s_gu)
+            e_dn = ops.gemm_desc(B.e_inter, W["exp_dn"].w_q, W["exp_dn"].w_s, B.e_out, a_row_slot=plan.sorted_bucket[l],
+                                 a_slot_base=base + 4 + nbk, group_offsets=plan.expert_offsets[l], stats=st, m_total=R)
+            s_dn = ops.gemm_desc(B.sh_inter, W["sh_dn"].w_q, W["sh_dn"].w_s, B.sh_out, a_slot_base=base + 3 + nbk, stats=st) if shared else None
+            ops.gemm_i8_pair(e_dn, s_dn)
+            return
+        if shared:
             self._linear(B.normed, W["sh_gu"], base + 2, B.xa, B.xs, B.sh_inter, epilogue=ops.EPI_SWIGLU, stats_slot=base + 3 + nbk)
             self._linear(B.sh_inter, W["sh_dn"], base + 3 + nbk, B.sha, B.shs, B.sh_out)
         if R == 0:

@@ -115,13 +115,22 @@ def silu_mul(gate_up: torch.Tensor, inter: int) -> torch.Tensor:
 
 
 # ---- dynamic quantization -----------------------------------------------------------------------------------
+def slot_words() -> int:
+    return _lib.load().i64h_stats_words_per_slot()
+
+
 def stats_alloc(n_slots: int, device) -> torch.Tensor:
-    """uint32 pairs stored in an int32 tensor (torch has no uint32 arithmetic; only the bits matter)."""
-    return torch.empty(2 * n_slots, dtype=torch.int32, device=device)
+    """Stat slots stored in an int32 tensor (torch has no uint32 arithmetic; only the bits matter)."""
+    return torch.empty(slot_words() * n_slots, dtype=torch.int32, device=device)
+
+
+def stats_view(stats: torch.Tensor, first_slot: int, n_slots: int = 1) -> torch.Tensor:
+    w = slot_words()
+    return stats[w * first_slot: w * (first_slot + n_slots)]
 
 
 def stats_reset(stats: torch.Tensor):
-    call("i64h_stats_reset", ptr(stats), stats.numel() // 2, _stream())
+    call("i64h_stats_reset", ptr(stats), stats.numel() // slot_words(), _stream())
 
 
 def rows_minmax(x: torch.Tensor, stats: torch.Tensor, slots: Optional[torch.Tensor] = None, slot_base: int = 0):
@@ -199,6 +208,28 @@ def gemm_i8(a: torch.Tensor, row_scale: torch.Tensor, w: torch.Tensor, w_scale: 
     call("i64h_gemm_i8", ptr(a), ptr(row_scale), ptr(w), ptr(w_scale), ptr(group_offsets), G, M, N, K, ptr(out), epilogue,
          ptr(row_slot), slot_base, ptr(stats), _stream())
     return out
+
+
+def gemm_desc(a: torch.Tensor, w: torch.Tensor, w_scale: torch.Tensor, out: torch.Tensor, *, row_scale=None, a_src_row=None,
+              a_src_mod: int = 0, a_row_slot=None, a_slot_base: int = 0, group_offsets=None, epilogue: int = EPI_STORE,
+              out_row_slot=None, out_slot_base: int = 0, stats=None, want_stats: bool = False, m_total: Optional[int] = None):
+    """Build an i64h_gemm_desc.  a is int8 [M, K] (with row_scale) or fp32 [*, K] (quantized on the fly from the stat slots)."""
+    if w.dim() == 2:
+        w = w.unsqueeze(0)
+    G, N, K = w.shape
+    d = _lib.GemmDesc()
+    d.A, d.a_fp32 = ptr(a), int(a.dtype == torch.float32)
+    d.a_src_row, d.a_src_mod, d.row_scale = ptr(a_src_row), a_src_mod, ptr(row_scale)
+    d.a_row_slot, d.a_slot_base = ptr(a_row_slot), a_slot_base
+    d.B, d.w_scale, d.group_offsets, d.num_groups = ptr(w), ptr(w_scale), ptr(group_offsets), G
+    d.M_total = m_total if m_total is not None else a.shape[0]
+    d.N, d.K, d.C, d.epilogue = N, K, ptr(out), epilogue
+    d.out_row_slot, d.out_slot_base, d.stats, d.want_stats = ptr(out_row_slot), out_slot_base, ptr(stats), int(want_stats)
+    return d
+
+
+def gemm_i8_pair(a_desc, b_desc=None):
+    call("i64h_gemm_i8_pair", ctypes.addressof(a_desc), ctypes.addressof(b_desc) if b_desc is not None else 0, _stream())
 
 
 def gemm_f32(a: torch.Tensor, b: torch.Tensor, a_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -314,7 +345,8 @@ def silu_mul_q7(gate: torch.Tensor, up: torch.Tensor, lut: torch.Tensor) -> torc
 
 # ---- attention --------------------------------------------------------------------------------------------------
 def paged_attn(q, k_cache, v_cache, block_table, ctx_len, slot_ids=None, softmax_scale: Optional[float] = None, splits: int = 1,
-               out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+               out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None,
+               stat_slot: int = 0) -> torch.Tensor:
     _chk(q, torch.float32, "q"), _chk(block_table, torch.int32, "block_table"), _chk(ctx_len, torch.int32, "ctx_len")
     rows, nh, hd = q.shape
     _, block, kvh, hd2 = k_cache.shape
@@ -326,7 +358,8 @@ def paged_attn(q, k_cache, v_cache, block_table, ctx_len, slot_ids=None, softmax
     if splits > 1 and workspace is None:
         workspace = torch.empty(_lib.load().i64h_paged_attn_workspace_floats(rows, nh, hd, splits), dtype=torch.float32, device=q.device)
     call("i64h_paged_attn", ptr(q), ptr(k_cache), ptr(v_cache), KV_DTYPE_CODE[k_cache.dtype], ptr(block_table), block_table.shape[1],
-         ptr(slot_ids), ptr(ctx_len), float(softmax_scale), ptr(out), ptr(workspace), rows, nh, kvh, hd, block, splits, _stream())
+         ptr(slot_ids), ptr(ctx_len), float(softmax_scale), ptr(out), ptr(workspace), rows, nh, kvh, hd, block, splits, ptr(stats),
+         stat_slot, _stream())
     return out
 
 
