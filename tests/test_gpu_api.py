@@ -1,0 +1,125 @@
+"""The reference's operator surface (get_ops / get_i64_cuda_ops / layer functions) on the GPU, written the way the
+reference's own tests use it (tests/test_i64_pipeline.py:35-96, tests/test_competitive_features.py:489-511,
+tests/test_flash_attention.py:65-110, tests/test_new_features.py:422-443)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model_ref as M
+from oracle import ops_ref as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def test_get_ops_surface(dev):
+    from vllm_i64_amd.kernels import get_ops
+    ops = get_ops()
+    assert ops.route_tokens(torch.arange(8, device=dev), 4).tolist() == [0, 1, 2, 3, 0, 1, 2, 3]
+    assert ops.route_tokens(torch.tensor([10, 11, 12, 13], device=dev), 4).tolist() == [2, 3, 0, 1]
+    ids = torch.arange(100000, device=dev)
+    for E in (2, 4, 8, 16):
+        assert torch.equal(ops.route_tokens(ids, E).long(), ids % E)
+    assert torch.bincount(ops.route_tokens(ids, 4).long()).tolist() == [25000] * 4
+    g = torch.Generator().manual_seed(0)
+    hidden = torch.randn(8, 64, generator=g).to(dev)
+    eid = torch.tensor([0, 1, 2, 3, 0, 1, 2, 3], dtype=torch.int32, device=dev)
+    scattered, idx, offsets, counts = ops.scatter_by_expert(hidden, eid, 4)
+    assert counts.tolist() == [2, 2, 2, 2] and offsets.tolist() == [0, 2, 4, 6]
+    assert torch.allclose(ops.gather_by_expert(scattered, idx), hidden, atol=1e-6)
+    s2, i2, o2, c2 = ops.atomic_scatter(hidden, eid, 4)
+    assert torch.equal(ops.gather_by_expert(s2, i2), hidden)
+    e3, s3, m3, o3, c3 = ops.fused_route_scatter(torch.arange(8, device=dev), hidden, 4)
+    assert e3.tolist() == eid.tolist() and torch.equal(ops.gather_by_expert(s3, m3), hidden)
+    for dt, tol in ((torch.float32, 1e-6), (torch.float16, 2e-3), (torch.bfloat16, 2e-2)):
+        gu = torch.randn(19, 64, generator=g).to(dev).to(dt)
+        ref = O.silu_hadamard(gu.float().cpu(), 32)
+        assert torch.allclose(ops.silu_hadamard(gu, 32).float().cpu(), ref, atol=tol, rtol=tol)
+
+
+def test_get_i64_cuda_ops_surface(dev, golden_dir):
+    from vllm_i64_amd.kernels import get_i64_cuda_ops
+    k = get_i64_cuda_ops()
+    assert k is not None
+    k.init_softmax_lut()
+    z = np.load(os.path.join(golden_dir, "ops.npz"))
+    d = lambda n: torch.from_numpy(z[n]).to(dev)
+    assert np.array_equal(k.softmax_integer(d("softmax_in")).cpu().numpy(), z["softmax_out"])
+    assert np.allclose(k.rmsnorm_forward(d("rms_x"), d("rms_w"), 1e-6).cpu().numpy(), z["rms_out"], atol=1e-6, rtol=1e-5)
+    q, s = k.quantize_int8(d("rms_x"))
+    assert np.array_equal(s.cpu().numpy(), z["q8_as"])
+    back = k.dequantize_int8(q, s)
+    assert (back.cpu() - torch.from_numpy(z["rms_x"])).abs().max() <= s.max().item()
+    qw, sw = k.quantize_perchannel_int8(d("rms_x"))
+    assert qw.dtype == torch.int8 and int(qw.min()) >= -128 and int(qw.max()) <= 127      # tests/test_utils.py:104-128
+    assert np.array_equal(k.rope_integer_forward(d("rope_x"), d("rope_cq"), d("rope_sq")).cpu().numpy(), z["rope_int_out"])
+    assert np.allclose(k.rope_forward(d("rope_x"), d("rope_cos"), d("rope_sin")).cpu().numpy(), z["rope_out"], atol=1e-6)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(33, 96, generator=g)
+    w = torch.randn(40, 96, generator=g) * 0.05
+    wq, ws = O.quantize_int8(w)
+    torch.testing.assert_close(k.gemm_dequant_int8(x.to(dev), wq.to(dev), ws.to(dev)).cpu(), O.gemm_dequant_int8(x, wq, ws), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(k.gemm_silu_int8(x.to(dev), wq.to(dev), ws.to(dev), wq.to(dev), ws.to(dev)).cpu(),
+                               O.gemm_silu_int8(x, wq, ws, wq, ws), rtol=1e-4, atol=1e-4)
+
+
+def test_fused_token_routed_forward_float(dev):
+    from vllm_i64_amd.kernels import fused_token_routed_forward
+    g = torch.Generator().manual_seed(4)
+    N, H, I, E = 77, 64, 48, 4
+    x = torch.randn(N, H, generator=g)
+    gu = torch.randn(E, H, 2 * I, generator=g) * 0.1
+    dn = torch.randn(E, I, H, generator=g) * 0.1
+    eid = torch.randint(0, E, (N,), generator=g)
+    ref = torch.zeros(N, H)
+    for e in range(E):
+        m = eid == e
+        t = x[m] @ gu[e]
+        ref[m] = (torch.nn.functional.silu(t[:, :I]) * t[:, I:]) @ dn[e]
+    out = fused_token_routed_forward(x.to(dev), gu.to(dev), dn.to(dev), eid.to(dev), E, I)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-5)
+
+
+def test_layer_functions(dev, golden_dir):
+    from vllm_i64_amd import layers as L
+    z = np.load(os.path.join(golden_dir, "ops.npz"))
+    d = lambda n: torch.from_numpy(z[n]).to(dev)
+    out = L.naive_paged_decode_attention(d("pd_q"), d("pd_k"), d("pd_v"), d("pd_bt"), d("pd_sl"), num_kv_groups=2)
+    assert np.allclose(out.cpu().numpy(), z["pd_out"], atol=2e-6) and not out[2].any()
+    out = L.naive_varlen_attention(d("vl_q"), d("vl_k"), d("vl_v"), [int(t) for t in z["vl_tps"]], 2)
+    assert np.allclose(out.cpu().numpy(), z["vl_out"], atol=2e-6)
+    # multi-sequence isolation (tests/test_flash_attention.py:65-110): a sequence's output does not depend on its neighbours
+    q, k, v = d("vl_q"), d("vl_k"), d("vl_v")
+    alone = L.naive_varlen_attention(q[:17].contiguous(), k[:17].contiguous(), v[:17].contiguous(), [17], 2)
+    assert torch.allclose(alone, out[:17], atol=1e-6)
+    kf, vf = d("vl_k")[:17].contiguous(), d("vl_v")[:17].contiguous()
+    c = L.naive_cached_attention(q[5:9].contiguous(), kf, vf, 2, torch.arange(5, 9, device=dev))
+    assert torch.allclose(c, out[5:9], atol=1e-6)
+    n = L.RMSNorm(d("rms_w"))(d("rms_x"))
+    assert np.allclose(n.cpu().numpy(), z["rms_out"], atol=1e-6, rtol=1e-5)
+    assert np.array_equal(L.softmax_integer(d("softmax_in")).cpu().numpy(), z["softmax_out"])
+    assert np.array_equal(L.silu_multiply_integer(d("smi_gate"), d("smi_up")).cpu().numpy(), z["smi_out"])
+
+
+def test_token_routed_mlp_int8_layer_object(dev, golden_dir):
+    from vllm_i64_amd.config import ModelConfig
+    from vllm_i64_amd.layers import TokenRoutedMLPInt8
+    z = np.load(os.path.join(golden_dir, "moe_layer.npz"))
+    ocfg = M.named_config("tiny-moe")
+    w = M.make_weights(ocfg, seed=0)
+    layer = TokenRoutedMLPInt8(ModelConfig.from_any(ocfg), {"exp_gate_up": w["l1.exp_gate_up"], "exp_down": w["l1.exp_down"],
+                                                           "sh_gate_up": w["l1.sh_gate_up"], "sh_down": w["l1.sh_down"],
+                                                           "table": w["l1.table"]}, device=dev)
+    for n in (1, 64, 300):
+        ids = torch.from_numpy(z[f"tiny-moe_n{n}_ids"]).to(dev)
+        assert np.array_equal(layer.route(ids).cpu().numpy(), z[f"tiny-moe_n{n}_routes"])
+        y = layer(torch.from_numpy(z[f"tiny-moe_n{n}_x"]).to(dev), ids)
+        assert np.abs(y.cpu().numpy() - z[f"tiny-moe_n{n}_y"]).max() <= 1e-2

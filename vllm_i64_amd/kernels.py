@@ -1,0 +1,176 @@
+"""The reference's kernel-library surface on MI355X.
+
+Boundary A  vllm_i64.kernels.kernel_loader.get_ops()            (kernel_loader.py:114-123; ops of csrc/i64_ops_binding.cu:400-407)
+Boundary B  vllm_i64.kernels.cuda.get_i64_cuda_ops()             (cuda/I64_loader.py:98-114; ops of csrc/I64_binding.cu:49-87)
+            vllm_i64.kernels.fused_experts.fused_token_routed_forward (fused_experts.py:29-62)
+Same names, argument meaning and return tuples; every op runs a libi64hip.so kernel on the tensor's device and on
+torch's current stream.  There is no fallback implementation in this package: on a GPU host a missing library raises;
+on a host without a GPU get_i64_cuda_ops() returns None (the reference's "unavailable" contract, I64_loader.py:48-50)
+and get_ops() raises.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib, ops
+
+_LUTS = {}
+
+
+def _exp_lut(device) -> torch.Tensor:
+    """1025-entry table trunc(exp(i/128) * 65536): the table of the reference's Python path (layers/moe.py:44-47),
+    built on the host and uploaded once per device."""
+    key = ("exp", str(device))
+    if key not in _LUTS:
+        idx = torch.arange(-1024, 1, dtype=torch.float32)
+        _LUTS[key] = (torch.exp(idx / 128.0) * 65536.0).to(torch.int32).to(device)
+    return _LUTS[key]
+
+
+def _silu_lut(device) -> torch.Tensor:
+    """2049-entry table round(silu(i/128) * 128) (layers/integer_activations.py:29-35)."""
+    key = ("silu", str(device))
+    if key not in _LUTS:
+        x = torch.arange(-1024, 1025, dtype=torch.float32) / 128.0
+        _LUTS[key] = torch.round(torch.nn.functional.silu(x) * 128.0).to(torch.int32).to(device)
+    return _LUTS[key]
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.float32).contiguous()
+
+
+class HipOps:
+    """Boundary A.  Grouping is a stable counting sort: token order is kept inside an expert (the reference's CUDA kernel
+    orders by atomics, its tests only require gather(scatter(x)) == x)."""
+
+    @staticmethod
+    def route_tokens(token_ids: torch.Tensor, num_experts: int) -> torch.Tensor:
+        return ops.route_tokens(token_ids.to(torch.int64).contiguous(), num_experts)
+
+    @staticmethod
+    def silu_hadamard(gate_up: torch.Tensor, expert_inter: int) -> torch.Tensor:
+        return ops.silu_mul(gate_up.contiguous(), expert_inter)
+
+    @staticmethod
+    def scatter_by_expert(hidden: torch.Tensor, expert_ids: torch.Tensor, num_experts: int):
+        offsets, perm, inv, _ = ops.bucketize(expert_ids.to(torch.int32).contiguous(), num_experts)
+        scattered = ops.gather_rows(hidden.contiguous(), perm)
+        counts = offsets[1:] - offsets[:-1]
+        return scattered, inv, offsets[:num_experts].contiguous(), counts
+
+    @staticmethod
+    def gather_by_expert(expert_out: torch.Tensor, scatter_indices: torch.Tensor) -> torch.Tensor:
+        return ops.gather_rows(expert_out.contiguous(), scatter_indices.to(torch.int32).contiguous())
+
+    @staticmethod
+    def atomic_scatter(hidden: torch.Tensor, expert_ids: torch.Tensor, num_experts: int):
+        return HipOps.scatter_by_expert(hidden, expert_ids, num_experts)
+
+    @staticmethod
+    def fused_route_scatter(token_ids: torch.Tensor, hidden: torch.Tensor, num_experts: int):
+        eid = HipOps.route_tokens(token_ids, num_experts)
+        scattered, smap, offsets, counts = HipOps.scatter_by_expert(hidden, eid, num_experts)
+        return eid, scattered, smap, offsets, counts
+
+
+class I64Ops:
+    """Boundary B (11 ops of the pybind module vllm_i64_gpu_kernels)."""
+
+    @staticmethod
+    def rmsnorm_forward(x, weight, eps):
+        return ops.rmsnorm(_f32(x), _f32(weight), float(eps))
+
+    @staticmethod
+    def rmsnorm_quant_forward(x, weight, eps):
+        return ops.rmsnorm_quant(_f32(x), _f32(weight), float(eps))
+
+    @staticmethod
+    def rope_forward(x, cos, sin):
+        return ops.rope(_f32(x), _f32(cos), _f32(sin))
+
+    @staticmethod
+    def rope_integer_forward(x, cos_q14, sin_q14):
+        return ops.rope_q14(_f32(x), cos_q14.to(torch.int16).contiguous(), sin_q14.to(torch.int16).contiguous())
+
+    @staticmethod
+    def quantize_int8(x):
+        return ops.quant_rows(_f32(x))
+
+    @staticmethod
+    def dequantize_int8(x_int8, scale):
+        return ops.dequant_rows(x_int8.contiguous(), _f32(scale))
+
+    @staticmethod
+    def quantize_perchannel_int8(weight):
+        return ops.quant_rows(_f32(weight))
+
+    @staticmethod
+    def softmax_integer(logits):
+        x = _f32(logits)
+        return ops.softmax_q7(x, _exp_lut(x.device))
+
+    @staticmethod
+    def init_softmax_lut():
+        if torch.cuda.is_available():
+            _exp_lut(torch.device("cuda", torch.cuda.current_device()))
+
+    @staticmethod
+    def silu_multiply_integer(gate, up):
+        g = _f32(gate)
+        return ops.silu_mul_q7(g, _f32(up), _silu_lut(g.device))
+
+    @staticmethod
+    def gemm_dequant_int8(x, w_int8, w_scale):
+        return ops.gemm_w8a32(_f32(x), w_int8.contiguous(), _f32(w_scale))
+
+    @staticmethod
+    def gemm_silu_int8(x, gate_int8, gate_scale, up_int8, up_scale):
+        return ops.gemm_w8a32_swiglu(_f32(x), gate_int8.contiguous(), _f32(gate_scale), up_int8.contiguous(), _f32(up_scale))
+
+
+def get_ops() -> HipOps:
+    if not torch.cuda.is_available():
+        raise _lib.I64HError("get_ops(): no GPU visible; this package has no CPU implementation")
+    _lib.load()
+    return HipOps()
+
+
+def is_cuda_kernels_available() -> bool:
+    return torch.cuda.is_available()
+
+
+def get_i64_cuda_ops() -> Optional[I64Ops]:
+    if not torch.cuda.is_available():
+        return None
+    _lib.load()
+    return I64Ops()
+
+
+def is_i64_cuda_available() -> bool:
+    return torch.cuda.is_available()
+
+
+def fused_token_routed_forward(x: torch.Tensor, gate_up_proj: torch.Tensor, down_proj: torch.Tensor, expert_ids: torch.Tensor,
+                               num_experts: int, intermediate_per_tp: int, bmm_threshold: int = 64) -> torch.Tensor:
+    """Float expert MLP grouped by expert (fused_experts.py:29-150): x [N,H], gate_up_proj [E,H,2I], down_proj [E,I,H],
+    expert_ids long [N].  fp32 math on the f32 matrix cores; one stable grouping, per-expert contractions, un-grouping.
+    Like the reference's chunked mode this reads the per-expert offsets on the host (one synchronisation)."""
+    n = x.shape[0]
+    if n == 0:
+        return x
+    xf = _f32(x)
+    offsets, perm, inv, _ = ops.bucketize(expert_ids.to(torch.int32).contiguous(), num_experts)
+    xs = ops.gather_rows(xf, perm)
+    off = offsets.tolist()
+    out_sorted = torch.empty(n, down_proj.shape[2], dtype=torch.float32, device=x.device)
+    for e in range(num_experts):
+        s, t = off[e], off[e + 1]
+        if s == t:
+            continue
+        gu = ops.gemm_f32(xs[s:t].contiguous(), _f32(gate_up_proj[e].t()))   # [m, 2I]
+        inter = ops.silu_mul(gu, intermediate_per_tp)
+        out_sorted[s:t] = ops.gemm_f32(inter, _f32(down_proj[e].t()))
+    return ops.gather_rows(out_sorted, inv).to(x.dtype)
