@@ -210,6 +210,7 @@ __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* _
     constexpr int LPT = KVH * CPH;      // lanes per token
     constexpr int TPS = 64 / LPT;       // tokens per wave step
     constexpr int NH = KVH * GS;
+    constexpr float LOG2E = 1.4426950408889634f;
     static_assert(64 % LPT == 0, "token row must fit a wave");
     __shared__ float s_m[4][NH], s_l[4][NH], s_o[4][NH][HD];
     const int row = blockIdx.x, sp = blockIdx.y;
@@ -269,9 +270,8 @@ __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* _
                 float a = 0.0f;
 #pragma unroll
                 for (int d = 0; d < 8; ++d) a = __builtin_fmaf(qr[h][d], kf[d], a);
-#pragma unroll
-                for (int o = 1; o < CPH; o <<= 1) a += __shfl_xor(a, o);
-                s[u][h] = live[u] ? a * scale : -INFINITY;
+                a = group_sum(a, CPH);
+                s[u][h] = live[u] ? (a * scale) * LOG2E : -INFINITY;  // scores kept in log2 units: exp2 is one instruction
             }
         }
 #pragma unroll
@@ -279,10 +279,13 @@ __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* _
             float mx = s[0][h];
 #pragma unroll
             for (int u = 1; u < PD_U; ++u) mx = fmaxf(mx, s[u][h]);
+            if (LPT == 32) mx = half_swap_max(mx);
+            else {
 #pragma unroll
-            for (int o = LPT; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+                for (int o = LPT; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            }
             const float mn = fmaxf(m[h], mx);           // identical in the lanes of one kv head
-            const float alpha = (mn == -INFINITY) ? 1.0f : expf(m[h] - mn);
+            const float alpha = (mn == -INFINITY) ? 1.0f : exp2f(m[h] - mn);
             m[h] = mn;
             l[h] *= alpha;
 #pragma unroll
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* _
             rv[u].get(vf);
 #pragma unroll
             for (int h = 0; h < GS; ++h) {
-                const float p = live[u] ? expf(s[u][h] - m[h]) : 0.0f;
+                const float p = live[u] ? exp2f(s[u][h] - m[h]) : 0.0f;
                 l[h] += p;
 #pragma unroll
                 for (int d = 0; d < 8; ++d) acc[h][d] = __builtin_fmaf(p, vf[d], acc[h][d]);
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* _
         if (mm != -INFINITY) {
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
-                const float f = (s_m[w][h] == -INFINITY) ? 0.0f : expf(s_m[w][h] - mm);
+                const float f = (s_m[w][h] == -INFINITY) ? 0.0f : exp2f(s_m[w][h] - mm);
                 lt = __builtin_fmaf(f, s_l[w][h], lt);
                 ot = __builtin_fmaf(f, s_o[w][h][d], ot);
             }
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* _
 // optionally folds min/max of the row into a stat slot
 __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
                                                          float* __restrict__ out, int nh, int HD, int splits, uint32_t* __restrict__ stats,
-                                                         int stat_slot) {
+                                                         int stat_slot, int base2) {
     __shared__ float rlo[4], rhi[4];
     const int64_t row = blockIdx.x;
     float lo = 0.0f, hi = 0.0f;
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict
         if (mm != -INFINITY) {
             for (int s = 0; s < splits; ++s) {
                 const float ms = ml[2 * s];
-                const float f = (ms == -INFINITY) ? 0.0f : expf(ms - mm);
+                const float f = (ms == -INFINITY) ? 0.0f : (base2 ? exp2f(ms - mm) : expf(ms - mm));
                 const float4 po = *(const float4*)(part_o + (head * splits + s) * HD + d);
                 lt = __builtin_fmaf(f, ml[2 * s + 1], lt);
                 ot.x = __builtin_fmaf(f, po.x, ot.x); ot.y = __builtin_fmaf(f, po.y, ot.y);
@@ -486,7 +489,7 @@ int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, in
     I64H_CHECK_LAUNCH();
     if (splits > 1) {
         hipLaunchKernelGGL(attn_merge_kernel, dim3((unsigned)rows), dim3(256), 0, st, part_o, part_ml, out, (int)num_heads, (int)head_dim,
-                           (int)splits, stats, (int)stat_slot);
+                           (int)splits, stats, (int)stat_slot, done ? 1 : 0);
         I64H_CHECK_LAUNCH();
     }
     return 0;

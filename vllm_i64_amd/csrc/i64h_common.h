@@ -96,6 +96,22 @@ __device__ __forceinline__ int wave_max_i(int v) {
     return v;
 }
 
+// Sum / max over aligned groups of 8 adjacent lanes with DPP moves (no LDS traffic): after the call every lane of
+// the group holds the group's result.  quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror.
+#define I64H_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, true))
+__device__ __forceinline__ float group_sum(float v, int lanes) {  // lanes in {1, 2, 4, 8, 16}
+    if (lanes >= 2) v += I64H_DPP(v, 0xB1);
+    if (lanes >= 4) v += I64H_DPP(v, 0x4E);
+    if (lanes >= 8) v += I64H_DPP(v, 0x141);
+    if (lanes >= 16) v += I64H_DPP(v, 0x140);  // row_mirror: lane i <-> 15 - i, the other half of the row
+    return v;
+}
+// max over lanes l and l ^ 32 (both halves of the wave end with the result)
+__device__ __forceinline__ float half_swap_max(float v) {
+    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+
 // Activation quantization parameters of the reference's dynamic int8 Linear (7-bit, asymmetric):
 // restated from the published x86/FBGEMM algorithm; doubles exactly where the CPU code uses them.
 struct QParams {

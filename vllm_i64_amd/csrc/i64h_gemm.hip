@@ -501,7 +501,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_i8_skinny_kernel(GemmI8Pair pp) 
 // a_rows (optional) selects the rows of A to use (e.g. the last token of each sequence).
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, const int32_t* __restrict__ a_rows,
                                                        const float* __restrict__ B, float* __restrict__ C, int M, int N, int K) {
-    __shared__ float sA[64][33], sB[64][33];
+    __shared__ float sA[2][64][33], sB[2][64][33];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
@@ -511,36 +511,59 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
     const int lr = tid >> 3, lc = (tid & 7) * 4;  // 32 rows x 8 float4 per pass, 2 passes
-    for (int k0 = 0; k0 < K; k0 += 32) {
+    const float* ap[2];
+    const float* bp[2];
+    bool aok[2], bok[2];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int r = lr + 32 * ps;
+        aok[ps] = m0 + r < M;
+        bok[ps] = n0 + r < N;
+        const int64_t ar = aok[ps] ? (a_rows ? a_rows[m0 + r] : (m0 + r)) : 0;
+        ap[ps] = A + ar * K + lc;
+        bp[ps] = B + (int64_t)(bok[ps] ? n0 + r : 0) * K + lc;
+    }
+    float4 ra[2], rb[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const bool kin = k0 + lc < K;
+            ra[ps] = (aok[ps] && kin) ? *(const float4*)(ap[ps] + k0) : make_float4(0, 0, 0, 0);
+            rb[ps] = (bok[ps] && kin) ? *(const float4*)(bp[ps] + k0) : make_float4(0, 0, 0, 0);
+        }
+    };
+    auto lstore = [&](int buf) {
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) {
             const int r = lr + 32 * ps;
-            float4 va = make_float4(0, 0, 0, 0), vb = make_float4(0, 0, 0, 0);
-            if (m0 + r < M && k0 + lc < K) {
-                const int64_t ar = a_rows ? a_rows[m0 + r] : (m0 + r);
-                va = *(const float4*)(A + ar * K + k0 + lc);
-            }
-            if (n0 + r < N && k0 + lc < K) vb = *(const float4*)(B + (int64_t)(n0 + r) * K + k0 + lc);
-            sA[r][lc] = va.x; sA[r][lc + 1] = va.y; sA[r][lc + 2] = va.z; sA[r][lc + 3] = va.w;
-            sB[r][lc] = vb.x; sB[r][lc + 1] = vb.y; sB[r][lc + 2] = vb.z; sB[r][lc + 3] = vb.w;
+            sA[buf][r][lc] = ra[ps].x; sA[buf][r][lc + 1] = ra[ps].y; sA[buf][r][lc + 2] = ra[ps].z; sA[buf][r][lc + 3] = ra[ps].w;
+            sB[buf][r][lc] = rb[ps].x; sB[buf][r][lc + 1] = rb[ps].y; sB[buf][r][lc + 2] = rb[ps].z; sB[buf][r][lc + 3] = rb[ps].w;
         }
-        __syncthreads();
-        const int fr = lane & 15, fk = lane >> 4;
+    };
+    const int fr = lane & 15, fk = lane >> 4;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int KT = (K + 31) / 32;
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) gload((kt + 1) * 32);  // next tile in flight behind the MFMAs of this one
 #pragma unroll
         for (int kk = 0; kk < 32; kk += 4) {
             float a[2], b[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = sA[wm * 32 + i * 16 + fr][kk + fk];
+            for (int i = 0; i < 2; ++i) a[i] = sA[cur][wm * 32 + i * 16 + fr][kk + fk];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = sB[wn * 32 + j * 16 + fr][kk + fk];
+            for (int j = 0; j < 2; ++j) b[j] = sB[cur][wn * 32 + j * 16 + fr][kk + fk];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        if (kt + 1 < KT) lstore(cur ^ 1);
         __syncthreads();
     }
-    const int fr = lane & 15, fq = lane >> 4;
+    const int fq = lane >> 4;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll

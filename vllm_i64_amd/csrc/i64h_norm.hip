@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kv_kernel(const float* __res
     const float* cs = rope_tab + (int64_t)pos * hd;
     const int pb = block_table[(int64_t)slot_ids[t] * max_blocks_per_seq + pos / block];
     const int64_t cache_row = ((int64_t)pb * block + pos % block) * kvh;  // in heads
-    for (int head = wid; head < nh + 2 * kvh; head += 4) {
+    for (int head = blockIdx.y * 4 + wid; head < nh + 2 * kvh; head += 4 * gridDim.y) {
         const float* x = row + (int64_t)head * hd;
         if (head >= nh + kvh) {  // V: raw copy into the cache
             if (pb >= 0) {
@@ -284,9 +284,19 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
     const float* xr = x + r * D;
     float bv = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = threadIdx.x; i < D; i += 256) {
-        const float v = xr[i];
-        if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+    if ((D & 3) == 0) {
+        for (int i = threadIdx.x * 4; i < D; i += 1024) {  // ascending i per thread: strict > keeps the first maximum
+            const float4 v = *(const float4*)(xr + i);
+            if (v.x > bv) { bv = v.x; bi = i; }
+            if (v.y > bv) { bv = v.y; bi = i + 1; }
+            if (v.z > bv) { bv = v.z; bi = i + 2; }
+            if (v.w > bv) { bv = v.w; bi = i + 3; }
+        }
+    } else {
+        for (int i = threadIdx.x; i < D; i += 256) {
+            const float v = xr[i];
+            if (v > bv) { bv = v; bi = i; }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -377,7 +387,9 @@ int i64h_qk_norm_rope_kv(const float* qkv, const float* q_norm_w, const float* k
     I64H_CHECK_ARG(n >= 0 && head_dim > 0 && head_dim <= QKR_MAX_HD && head_dim % 2 == 0, "qk_norm_rope_kv: head_dim=%d unsupported", head_dim);
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((unsigned)n), blk(256);
+    // few tokens (decode): one wave per head, heads spread over the grid; many tokens: one workgroup walks a token's heads
+    const int heads = num_heads + 2 * num_kv_heads;
+    dim3 grid((unsigned)n, n <= 1024 ? (unsigned)((heads + 3) / 4) : 1u), blk(256);
 #define LAUNCH_QKR(T)                                                                                                             \
     hipLaunchKernelGGL(qk_norm_rope_kv_kernel<T>, grid, blk, 0, st, qkv, q_norm_w, k_norm_w, qk_eps, rope_tab, positions, slot_ids, \
                        block_table, (int)max_blocks_per_seq, q_out, (T*)k_cache, (T*)v_cache, (int)num_heads, (int)num_kv_heads,     \
