@@ -104,6 +104,25 @@ def bench_gemm():
     print(f"gemm down pair    (experts 8x[~16,448]x1024 + shared [64,1792]x1024): {med:6.1f}/{best:6.1f} us; weights {(E * ei * H + S * H) / 1e6:.2f} MB")
 
 
+def bench_gemm_prefill(only=None):
+    """Prefill-shaped int8 GEMMs (operands already quantized): achieved int8 TOP/s = 2*M*N*K / time."""
+    torch.manual_seed(0)
+    shapes = [("expert gate_up (grouped, SwiGLU)", 32768, 896, 1024, 8, 1), ("expert down (grouped)", 32768, 1024, 448, 8, 0),
+              ("shared gate_up (SwiGLU)", 16384, 3584, 1024, 1, 1), ("shared down", 16384, 1024, 1792, 1, 0),
+              ("qkv", 16384, 1536, 1024, 1, 0), ("square 8192", 8192, 8192, 8192, 1, 0)]
+    for name, M, N, K, G, epi in shapes:
+        if only and only not in name:
+            continue
+        a = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=dev)
+        w = torch.randint(-128, 128, (G, N, K), dtype=torch.int8, device=dev)
+        rs = torch.rand(M, device=dev) * 1e-3
+        ws = torch.rand(G, device=dev) * 1e-2
+        off = (torch.arange(G + 1, device=dev) * (M // G)).to(torch.int32) if G > 1 else None
+        out = torch.empty(M, N // 2 if epi else N, device=dev)
+        med, best = timeit(lambda: ops.gemm_i8(a, rs, w, ws, group_offsets=off, epilogue=epi, out=out), iters=5, warm=2, inner=5)
+        print(f"gemm_i8 {name:34s} M={M} N={N} K={K} G={G}: {med:8.1f} us -> {2 * M * N * K / med / 1e6:7.1f} TOP/s ({2 * M * N * K / med / 1e6 / 5000 * 100:4.1f}% of 5 POP/s)")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what == "gemmw":
@@ -112,7 +131,23 @@ if __name__ == "__main__":
             print(f"--- skinny kernel with {nw} waves per workgroup")
             bench_gemm()
         sys.exit(0)
+    if what == "gemm1":  # one shape, one variant: python tools/kbench.py gemm1 <variant> <name substring> (for counter passes)
+        ops.call("i64h_set_pipe_gemm", int(sys.argv[2]))
+        bench_gemm_prefill(sys.argv[3])
+        sys.exit(0)
+    if what == "ablate":
+        for v in (0, 80, 160, 240, 310):
+            ops.call("i64h_set_pipe_gemm", v)
+            print(f"--- ablation bits {v // 10} (1 no global loads/LDS stores, 2 no fragment reads, 4 no barrier, 8 no C stores, 16 no exp/div)")
+            bench_gemm_prefill("shared gate_up")
+            bench_gemm_prefill("expert gate_up")
+        sys.exit(0)
     if what in ("attn", "all"):
         bench_attn()
     if what in ("gemm", "all"):
         bench_gemm()
+    if what in ("gemmp", "all"):
+        for on in (0, 1):
+            ops.call("i64h_set_pipe_gemm", on)
+            print(f"--- 64-byte stages for short K: {on}")
+            bench_gemm_prefill()

@@ -10,8 +10,10 @@
 //   EPI_SWIGLU: N = 2*I; out[r, j] = silu(C[r, j]) * C[r, I + j]  (fp32 [M_total, I]); the block's weight tile
 //               holds matching gate/up columns so the pair meets in one lane.  Optionally folds min/max of the
 //               result into the stat slot of each row (the next Linear call's quantization statistics).
-// One workgroup = 4 waves (2 x 2), tile BM x BN, BK = 128 bytes, LDS double buffer, XOR-swizzled 16-B chunks
-// (conflict-free ds_read_b128), register-staged global loads issued one tile ahead.
+// One workgroup = 4 waves (2 x 2), tile BM x BN, LDS double buffer of 128- or 64-byte K stages, swizzled 16-B chunks
+// (conflict-free ds_read_b128), register-staged global loads issued one tile ahead.  Measured on MI355X: at the
+// K of this model (448..1792) a tile's fixed prologue/epilogue latency outweighs its MFMA time, and what hides it is
+// occupancy: 64-byte stages (32 KB LDS, <= 128 VGPRs) put four workgroups on a CU.
 //
 // gemm_f32_kernel: C = A[M,K] @ B[N,K]^T in fp32 on v_mfma_f32_16x16x4_f32 (tied lm_head; bit-for-bit a k-ordered
 //   fmaf chain per output).  gemm_w8a32_kernel: fp32 activations x dequantised int8 weights (operator API).
@@ -49,65 +51,93 @@ struct GemmI8Pair {
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * BK + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// 64-byte tile rows: four rows share a 16-bank window, the four 16-B slots of a row are permuted by 0 or 3 so that every
+// ds_read_b128 lane group ({0-3, 12-15, 20-27}, ...) of a 16-row fragment touches all 64 banks once
+__device__ __forceinline__ int swz64(int row, int chunk) { return row * 64 + ((chunk ^ (((row >> 2) & 1) * 3)) << 4); }
+template <int BKT>
+__device__ __forceinline__ int swzt(int row, int chunk) { return BKT == 128 ? swz(row, chunk) : swz64(row, chunk); }
 
-template <int BM, int BN, int EPI, int AQ>
+// BKT = K bytes per LDS stage: 128 (two MFMA K steps per barrier, fragment reads software-pipelined) or 64 (one step per
+// barrier, half the LDS and fewer registers: four 128 x 128 workgroups per CU, which is what hides the per-tile prologue
+// and epilogue of short-K problems).
+template <int BM, int BN, int EPI, int AQ, int NWM = 2, int NWN = 2, int BKT = 128>
 __device__ __forceinline__ void gemm_i8_body(const GemmI8Args& p, const int bid, char* smem) {
-    constexpr int WM = BM / 2, WN = BN / 2;      // per-wave sub-tile
+    constexpr int NT = NWM * NWN * 64;           // threads: NWM x NWN waves
+    constexpr int CPR = BKT / 16;                // 16-B chunks per tile row
+    constexpr int LDR = NT / CPR;                // tile rows one staging pass covers
+    constexpr int WM = BM / NWM, WN = BN / NWN;  // per-wave sub-tile
     constexpr int FM = WM / 16, FN = WN / 16;    // 16x16 fragments per wave
-    constexpr int A_IT = BM * 8 / 256, B_IT = BN * 8 / 256;  // 16-B chunks per thread per tile
-    constexpr int STAGE = (BM + BN) * BK;  // stage s: A tile at s*STAGE, B tile behind it
-    // behind the two stages: tile info (16 B), then per-row quantization parameters (AQ)
+    constexpr int A_IT = BM / LDR, B_IT = BN / LDR;  // 16-B chunks per thread per tile
+    constexpr int STAGE = (BM + BN) * BKT;  // stage s: A tile at s*STAGE, B tile behind it
+    static_assert(BM % LDR == 0 && BN % LDR == 0, "tile rows must divide over the staging passes");
+    // behind the two stages: tile info (16 B), then per-row quantization parameters / rescale factors
     int* s_info = (int*)(smem + 2 * STAGE);
     float* q_inv = (float*)(smem + 2 * STAGE + 16);
     float* q_scale = q_inv + BM;
     int* q_zp = (int*)(q_scale + BM);
 
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int n_tiles = (EPI == EPI_SWIGLU) ? ((p.N / 2) + BN / 2 - 1) / (BN / 2) : (p.N + BN - 1) / BN;
     const int mt = bid / n_tiles, nt = bid % n_tiles;
-    if (threadIdx.x == 0) {  // locate (group, row range) of m-tile mt
-        int g = -1, row0 = 0, rows = 0, acc_tiles = 0;
+    if (wid == 0) {  // locate (group, row range) of m-tile mt: lane i looks at group i, 64 groups per pass
+        int g = -1, row0 = 0, rows = 0, base = 0;
         const int G = p.group_off ? p.G : 1;
-        for (int i = 0; i < G; ++i) {
-            const int b = p.group_off ? p.group_off[i] : 0;
-            const int e = p.group_off ? p.group_off[i + 1] : p.M_total;
-            const int tiles = (e - b + BM - 1) / BM;
-            if (mt < acc_tiles + tiles) {
-                g = i;
-                row0 = b + (mt - acc_tiles) * BM;
-                rows = min(BM, e - row0);
-                break;
+        for (int c0 = 0; c0 < G && g < 0; c0 += 64) {
+            const int i = c0 + lane;
+            int b = 0, e = 0;
+            if (i < G) {
+                b = p.group_off ? p.group_off[i] : 0;
+                e = p.group_off ? p.group_off[i + 1] : p.M_total;
             }
-            acc_tiles += tiles;
+            const int tiles = (e - b + BM - 1) / BM;
+            int incl = tiles;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            const int excl = base + incl - tiles;
+            const unsigned long long hit = __ballot(i < G && mt >= excl && mt < excl + tiles);
+            if (hit) {
+                const int src = __ffsll(hit) - 1;
+                g = c0 + src;
+                row0 = __shfl(b, src) + (mt - __shfl(excl, src)) * BM;
+                rows = min(BM, __shfl(e, src) - row0);
+            }
+            base += __shfl(incl, 63);
         }
-        s_info[0] = g; s_info[1] = row0; s_info[2] = rows;
+        if (lane == 0) { s_info[0] = g; s_info[1] = row0; s_info[2] = rows; }
     }
     __syncthreads();
     const int g = s_info[0], row0 = s_info[1], rows = s_info[2];
     if (g < 0) return;  // grid is an upper bound on the number of m-tiles
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid / NWN, wn = wid % NWN;
     const int K = p.K;
     const int8_t* Bg = p.B + (int64_t)g * p.N * K;
     const int I = p.N / 2;
 
-    if (AQ) {  // quantization parameters of the tile's rows (one Linear call = one stat slot)
-        if (tid < BM) {
+    // per-row parameters of the tile: quantization parameters (one Linear call = one stat slot) or the given row scale;
+    // published by the barrier in front of the main loop
+    for (int r = tid; r < BM; r += NT) {
+        if (AQ) {
             QParams q;
             q.scale = 0.0f; q.inv_scale = 0.0f; q.zp = 0;
-            if (tid < rows) q = slot_qparams(p.stats, p.a_slot_base + (p.a_row_slot ? p.a_row_slot[row0 + tid] : 0));
-            q_inv[tid] = q.inv_scale; q_scale[tid] = q.scale; q_zp[tid] = q.zp;
+            if (r < rows) q = slot_qparams(p.stats, p.a_slot_base + (p.a_row_slot ? p.a_row_slot[row0 + r] : 0));
+            q_inv[r] = q.inv_scale; q_scale[r] = q.scale; q_zp[r] = q.zp;
+        } else {
+            q_scale[r] = r < rows ? p.row_scale[row0 + r] : 0.0f;
         }
-        __syncthreads();
     }
+    if (AQ) __syncthreads();
 
     // global -> register staging assignment: chunk c (16 K-elements) of tile row r
-    const int ld_c = tid & 7, ld_r = tid >> 3;  // rows ld_r + 32*i
+    const int ld_c = tid % CPR, ld_r = tid / CPR;  // rows ld_r + LDR*i
     const char* a_ptr[A_IT];
     bool a_ok[A_IT];
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-        const int r = ld_r + 32 * i;
+        const int r = ld_r + LDR * i;
         a_ok[i] = r < rows;
         int64_t src = row0 + (a_ok[i] ? r : 0);
         if (AQ) {
@@ -122,7 +152,7 @@ __device__ __forceinline__ void gemm_i8_body(const GemmI8Args& p, const int bid,
     bool b_ok[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
-        const int r = ld_r + 32 * i;
+        const int r = ld_r + LDR * i;
         int col;
         if (EPI == EPI_SWIGLU) {  // tile row -> gate column or its up partner (see header)
             const int wc = r / WN, within = r % WN;
@@ -142,31 +172,31 @@ __device__ __forceinline__ void gemm_i8_body(const GemmI8Args& p, const int bid,
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = (v4i){0, 0, 0, 0};
 
-    const int KT = (K + BK - 1) / BK;
+    const int KT = (K + BKT - 1) / BKT;
     uint4 ra[AQ ? 1 : A_IT], rb[B_IT];
     float4 fa[AQ ? A_IT : 1][4];
     auto gload = [&](int kt) {
-        const int kb = kt * BK + ld_c * 16;
+        const int kb = kt * BKT + ld_c * 16;
         const bool kin = kb < K;  // K is a multiple of 16: a chunk is entirely inside or outside
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             if (AQ) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    fa[i][e] = (a_ok[i] && kin) ? *(const float4*)(a_ptr[i] + (int64_t)kt * BK * 4 + e * 16) : make_float4(0, 0, 0, 0);
+                    fa[i][e] = (a_ok[i] && kin) ? *(const float4*)(a_ptr[i] + (int64_t)kt * BKT * 4 + e * 16) : make_float4(0, 0, 0, 0);
             } else {
-                ra[i] = (a_ok[i] && kin) ? *(const uint4*)(a_ptr[i] + kt * BK) : make_uint4(0, 0, 0, 0);
+                ra[i] = (a_ok[i] && kin) ? *(const uint4*)(a_ptr[i] + kt * BKT) : make_uint4(0, 0, 0, 0);
             }
         }
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) rb[i] = (b_ok[i] && kin) ? *(const uint4*)(b_ptr[i] + kt * BK) : make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < B_IT; ++i) rb[i] = (b_ok[i] && kin) ? *(const uint4*)(b_ptr[i] + kt * BKT) : make_uint4(0, 0, 0, 0);
     };
     auto lstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_IT; ++i) {
             uint4 v;
             if (AQ) {
-                const int r = ld_r + 32 * i;
+                const int r = ld_r + LDR * i;
                 QParams q;
                 q.inv_scale = q_inv[r]; q.zp = q_zp[r]; q.scale = 0.0f;
                 uint32_t w[4];
@@ -176,38 +206,74 @@ __device__ __forceinline__ void gemm_i8_body(const GemmI8Args& p, const int bid,
                     w[e] = (uint32_t)(quantize_u7_signed(f.x, q) & 255) | ((uint32_t)(quantize_u7_signed(f.y, q) & 255) << 8) |
                            ((uint32_t)(quantize_u7_signed(f.z, q) & 255) << 16) | ((uint32_t)(quantize_u7_signed(f.w, q) & 255) << 24);
                 }
-                // rows outside the tile / K tail must contribute 0, not quantize(0) = -zp + zp = 0: quantize(0) IS 0, fine
+                // rows outside the tile and the K tail are staged as 0.0f, and quantize(0) - zp is exactly 0
                 v = make_uint4(w[0], w[1], w[2], w[3]);
             } else {
                 v = ra[i];
             }
-            *(uint4*)(smem + buf * STAGE + swz(ld_r + 32 * i, ld_c)) = v;
+            *(uint4*)(smem + buf * STAGE + swzt<BKT>(ld_r + LDR * i, ld_c)) = v;
         }
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) *(uint4*)(smem + buf * STAGE + BM * BK + swz(ld_r + 32 * i, ld_c)) = rb[i];
+        for (int i = 0; i < B_IT; ++i) *(uint4*)(smem + buf * STAGE + BM * BKT + swzt<BKT>(ld_r + LDR * i, ld_c)) = rb[i];
     };
 
-    gload(0);
-    lstore(0);
-    __syncthreads();
     const int fr = lane & 15, fq = lane >> 4;
-    for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < KT) gload(kt + 1);
+    if constexpr (BKT == 128) {
+        // Software pipeline, one barrier per tile.  Every fragment read from LDS is issued one half-tile (FM*FN MFMAs)
+        // before its use; the next tile is written to the other stage between the two halves, and its global loads were
+        // issued a whole tile earlier:
+        //   frag(kt, 1) -> mfma(kt, 0) -> store tile kt+1 -> barrier -> load tile kt+2 -> frag(kt+1, 0) -> mfma(kt, 1)
+        v4i af[2][FM], bf[2][FN];
+        auto fload = [&](int set, int stage, int ks) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+            for (int i = 0; i < FM; ++i) af[set][i] = *(const v4i*)(smem + stage * STAGE + swz(wm * WM + i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+            for (int j = 0; j < FN; ++j) bf[set][j] = *(const v4i*)(smem + stage * STAGE + BM * BK + swz(wn * WN + j * 16 + fr, ks * 4 + fq));
+        };
+        auto mma = [&](int set) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[set][i], bf[set][j], acc[i][j], 0, 0, 0);
+        };
+        gload(0);
+        lstore(0);
+        __syncthreads();
+        if (KT > 1) gload(1);
+        fload(0, 0, 0);
+        for (int kt = 0; kt < KT; ++kt) {
+            const int cur = kt & 1;
+            fload(1, cur, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < KT) lstore(cur ^ 1);
+            __syncthreads();
+            if (kt + 2 < KT) gload(kt + 2);
+            if (kt + 1 < KT) fload(0, cur ^ 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        gload(0);
+        lstore(0);
+        __syncthreads();
+        for (int kt = 0; kt < KT; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < KT) gload(kt + 1);  // next tile in flight behind the MFMAs of this one
             v4i af[FM], bf[FN];
 #pragma unroll
-            for (int i = 0; i < FM; ++i) af[i] = *(const v4i*)(smem + cur * STAGE + swz(wm * WM + i * 16 + fr, ks * 4 + fq));
+            for (int i = 0; i < FM; ++i) af[i] = *(const v4i*)(smem + cur * STAGE + swz64(wm * WM + i * 16 + fr, fq));
 #pragma unroll
-            for (int j = 0; j < FN; ++j) bf[j] = *(const v4i*)(smem + cur * STAGE + BM * BK + swz(wn * WN + j * 16 + fr, ks * 4 + fq));
+            for (int j = 0; j < FN; ++j) bf[j] = *(const v4i*)(smem + cur * STAGE + BM * BKT + swz64(wn * WN + j * 16 + fr, fq));
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
+            if (kt + 1 < KT) lstore(cur ^ 1);
+            __syncthreads();
         }
-        if (kt + 1 < KT) lstore(cur ^ 1);
-        __syncthreads();
     }
 
     // ---- epilogue: D[row = fq*4 + reg][col = fr] per fragment ----
@@ -219,7 +285,7 @@ __device__ __forceinline__ void gemm_i8_body(const GemmI8Args& p, const int bid,
             for (int reg = 0; reg < 4; ++reg) {
                 const int r = wm * WM + i * 16 + fq * 4 + reg;
                 if (r >= rows) continue;
-                const float m = (AQ ? q_scale[r] : p.row_scale[row0 + r]) * ws;
+                const float m = q_scale[r] * ws;
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
                     const int c = nt * BN + wn * WN + j * 16 + fr;
@@ -233,7 +299,7 @@ __device__ __forceinline__ void gemm_i8_body(const GemmI8Args& p, const int bid,
         uint32_t* tab_hi = tab_lo + I64H_STAT_TAB;
         const bool st = p.want_stats != 0;
         if (st) {
-            for (int i = tid; i < I64H_STAT_TAB; i += 256) { tab_lo[i] = I64H_ORDERED_ZERO; tab_hi[i] = I64H_ORDERED_ZERO; }
+            for (int i = tid; i < I64H_STAT_TAB; i += NT) { tab_lo[i] = I64H_ORDERED_ZERO; tab_hi[i] = I64H_ORDERED_ZERO; }
             __syncthreads();
         }
 #pragma unroll
@@ -242,7 +308,7 @@ __device__ __forceinline__ void gemm_i8_body(const GemmI8Args& p, const int bid,
             for (int reg = 0; reg < 4; ++reg) {
                 const int r = wm * WM + i * 16 + fq * 4 + reg;
                 const bool rok = r < rows;
-                const float m = rok ? (AQ ? q_scale[r] : p.row_scale[row0 + r]) * ws : 0.0f;
+                const float m = rok ? q_scale[r] * ws : 0.0f;
                 float a = 0.0f, b = 0.0f;
 #pragma unroll
                 for (int j = 0; j < FN / 2; ++j) {
@@ -272,7 +338,7 @@ __device__ __forceinline__ void gemm_i8_body(const GemmI8Args& p, const int bid,
             }
         if (st) {
             __syncthreads();
-            for (int i = tid; i < I64H_STAT_TAB; i += 256)
+            for (int i = tid; i < I64H_STAT_TAB; i += NT)
                 if (tab_lo[i] != I64H_ORDERED_ZERO || tab_hi[i] != I64H_ORDERED_ZERO) {
                     uint32_t* q = p.stats + (int64_t)(p.out_slot_base + i) * I64H_SLOT_WORDS + 2 * (bid & (I64H_NSHARD - 1));
                     atomicMin(q, tab_lo[i]);
@@ -282,11 +348,20 @@ __device__ __forceinline__ void gemm_i8_body(const GemmI8Args& p, const int bid,
     }
 }
 
-template <int BM, int BN, int EPI, int AQ>
-__global__ __launch_bounds__(256) void gemm_i8_kernel(GemmI8Pair pp) {
+// Workgroup ids are remapped so that the workgroups resident on one XCD (ids congruent mod 8) cover neighbouring tiles and
+// share operand panels in that XCD's L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+    return xcd * q + min(xcd, r) + idx;
+}
+
+// WPE = waves per SIMD the register budget is sized for (= workgroups per CU for these 4-wave workgroups).
+template <int BM, int BN, int EPI, int AQ, int BKT, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void gemm_i8_kernel(GemmI8Pair pp, int nblk_total) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if ((int)blockIdx.x < pp.nblk0) gemm_i8_body<BM, BN, EPI, AQ>(pp.p[0], blockIdx.x, smem);
-    else gemm_i8_body<BM, BN, EPI, AQ>(pp.p[1], blockIdx.x - pp.nblk0, smem);
+    const int bid = blockIdx.x;
+    if (bid < pp.nblk0) gemm_i8_body<BM, BN, EPI, AQ, 2, 2, BKT>(pp.p[0], xcd_remap(bid, pp.nblk0), smem);
+    else gemm_i8_body<BM, BN, EPI, AQ, 2, 2, BKT>(pp.p[1], xcd_remap(bid - pp.nblk0, nblk_total - pp.nblk0), smem);
 }
 
 // ---- decode-sized problems: weight-streaming kernel with the quantizer in front ---------------------------------------
@@ -698,16 +773,16 @@ static int nblocks_of(const i64h_gemm_desc* d) {
     return d->M_total == 0 ? 0 : m_tiles * n_tiles;
 }
 
-template <int BM, int BN, int EPI, int AQ>
+template <int BM, int BN, int EPI, int AQ, int BKT, int WPE>
 static int launch_pair(const i64h_gemm_desc* a, const i64h_gemm_desc* b, hipStream_t st) {
     GemmI8Pair pp;
     pp.p[0] = to_args(a);
-    pp.p[1] = b ? to_args(b) : pp.p[0];
+    pp.p[1] = to_args(b ? b : a);
     pp.nblk0 = nblocks_of<BM, BN>(a);
     const int total = pp.nblk0 + (b ? nblocks_of<BM, BN>(b) : 0);
     if (total == 0) return 0;
-    const size_t lds = 2 * (BM + BN) * BK + 16 + 3 * BM * 4;
-    hipLaunchKernelGGL((gemm_i8_kernel<BM, BN, EPI, AQ>), dim3((unsigned)total), dim3(256), lds, st, pp);
+    const size_t lds = 2 * (BM + BN) * BKT + 16 + 3 * BM * 4;
+    hipLaunchKernelGGL((gemm_i8_kernel<BM, BN, EPI, AQ, BKT, WPE>), dim3((unsigned)total), dim3(256), lds, st, pp, total);
     I64H_CHECK_LAUNCH();
     return 0;
 }
@@ -744,12 +819,20 @@ static int launch_skinny_nw(const i64h_gemm_desc* a, const i64h_gemm_desc* b, hi
     return launch_skinny<EPI, 8>(a, b, st);
 }
 
+static int g_stage64 = 1;  // tuning knob: 0 = 128-byte stages (two workgroups per CU) for every prefill-sized problem
+
 static bool skinny_ok(const i64h_gemm_desc* d) {
     // weight-streaming kernel: fp32 operand, K a multiple of 64 that fits LDS, few rows per group
     return d->a_fp32 && d->K % 64 == 0 && d->K <= 2048 && d->M_total <= 512;
 }
 
 extern "C" {
+
+// tuning knob: 1 (default) = short-K prefill-sized problems use 64-byte stages, four workgroups per CU; 0 = always 128-byte stages
+int i64h_set_pipe_gemm(int32_t on) {
+    g_stage64 = on ? 1 : 0;
+    return 0;
+}
 
 // tuning knob: waves per workgroup of the weight-streaming kernel (4, 8 or 16; 0 = default)
 int i64h_set_skinny_waves(int32_t waves) {
@@ -772,12 +855,17 @@ int i64h_gemm_i8_pair(const i64h_gemm_desc* a, const i64h_gemm_desc* b, void* st
         return a->epilogue == EPI_STORE ? launch_skinny_nw<EPI_STORE>(a, b, st) : launch_skinny_nw<EPI_SWIGLU>(a, b, st);
     const int64_t rows = a->M_total / a->num_groups;
     const bool big = !a->a_fp32 && rows >= 256;  // fp32 operands are meant for small M (quantized per workgroup)
+    // short K: a tile's K loop is a handful of steps, so occupancy (4 workgroups per CU) hides the per-tile prologue and
+    // epilogue; long K: 128-byte stages, fewer barriers
+    const bool s64 = big && g_stage64 && a->K <= 2048;
     if (a->epilogue == EPI_STORE) {
-        if (a->a_fp32) return launch_pair<64, 64, EPI_STORE, 1>(a, b, st);
-        return big ? launch_pair<128, 128, EPI_STORE, 0>(a, b, st) : launch_pair<64, 64, EPI_STORE, 0>(a, b, st);
+        if (a->a_fp32) return launch_pair<64, 64, EPI_STORE, 1, 128, 2>(a, b, st);
+        if (!big) return launch_pair<64, 64, EPI_STORE, 0, 128, 2>(a, b, st);
+        return s64 ? launch_pair<128, 128, EPI_STORE, 0, 64, 4>(a, b, st) : launch_pair<128, 128, EPI_STORE, 0, 128, 2>(a, b, st);
     }
-    if (a->a_fp32) return launch_pair<64, 64, EPI_SWIGLU, 1>(a, b, st);
-    return big ? launch_pair<128, 128, EPI_SWIGLU, 0>(a, b, st) : launch_pair<64, 64, EPI_SWIGLU, 0>(a, b, st);
+    if (a->a_fp32) return launch_pair<64, 64, EPI_SWIGLU, 1, 128, 2>(a, b, st);
+    if (!big) return launch_pair<64, 64, EPI_SWIGLU, 0, 128, 2>(a, b, st);
+    return s64 ? launch_pair<128, 128, EPI_SWIGLU, 0, 64, 4>(a, b, st) : launch_pair<128, 128, EPI_SWIGLU, 0, 128, 2>(a, b, st);
 }
 
 // epilogue: 0 = store fp32 [M_total, N]; 1 = SwiGLU -> fp32 [M_total, N/2] (+ optional statistics)
