@@ -170,9 +170,13 @@ int i64h_advance(int32_t* positions, int32_t* ctx_len, int64_t n, void* stream);
  * Causal GQA attention over the paged cache (num_blocks, block_size, kv_heads, head_dim): row r attends to the first
  * ctx_len[r] cached tokens of sequence slot_ids[r] (NULL: r).  Replaces naive_paged_decode_attention
  * (vllm_i64/layers/attention.py:517-601), naive_cached_attention (190-245) and the model's per-sequence cache loop
- * (model.py:203-236).  workspace: i64h_paged_attn_workspace_floats(...) floats when splits > 1.  With splits > 1 and
- * stats != NULL the merge also folds min/max of the output into stat slot stat_slot (input statistics of o_proj). */
+ * (model.py:203-236).  workspace: i64h_paged_attn_workspace_floats(...) 32-bit words when splits > 1; it starts with
+ * per-row arrival counters that must be zero before the first launch using the buffer (i64h_paged_attn_workspace_init,
+ * once after allocation) and that every launch leaves zero: the splits of a row are merged by the row's last-finishing
+ * workgroup, so launches sharing one workspace must not overlap.  With splits > 1 and stats != NULL the merge also folds
+ * min/max of the output into stat slot stat_slot (input statistics of o_proj). */
 int64_t i64h_paged_attn_workspace_floats(int64_t rows, int32_t num_heads, int32_t head_dim, int32_t splits);
+int i64h_paged_attn_workspace_init(float* workspace, void* stream);
 int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, int32_t kv_dtype, const int32_t* block_table,
                     int32_t max_blocks_per_seq, const int32_t* slot_ids, const int32_t* ctx_len, float softmax_scale, float* out,
                     float* workspace, int64_t rows, int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, int32_t block_size,

@@ -52,7 +52,7 @@ def bench_attn():
         med, best = timeit(lambda: dst.copy_(src))
         print(f"reference: torch device copy of the same bytes {med:7.1f} us -> read {nbytes / med / 1e3:7.1f} GB/s (+ equal write)")
         for splits in (4, 8, 16, 32):
-            ws = torch.empty(ops._lib.load().i64h_paged_attn_workspace_floats(B, nh, hd, splits), device=dev)
+            ws = ops.attn_workspace(B, nh, hd, splits, dev)
             med, best = timeit(lambda: ops.paged_attn(q, kc, vc, bt, cl, splits=splits, out=out, workspace=ws))
             print(f"attn {str(dt)[6:]:9s} splits {splits:2d}: median {med:7.1f} us best {best:7.1f} us -> {nbytes / med / 1e3:7.1f} GB/s (attn+merge)")
 

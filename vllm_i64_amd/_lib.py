@@ -43,6 +43,7 @@ SIGNATURES: Dict[str, str] = {
     "i64h_argmax_rows": "pplip",
     "i64h_advance": "pplp",
     "i64h_paged_attn": "pppipippfppliiiiipip",
+    "i64h_paged_attn_workspace_init": "pp",
     "i64h_gemm_i8_pair": "ppp",
     "i64h_set_skinny_waves": "i",
     "i64h_set_pipe_gemm": "i",

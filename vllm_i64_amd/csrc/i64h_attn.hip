@@ -193,19 +193,79 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(const float* __restrict
     }
 }
 
+// Device-coherent accesses for data handed from one workgroup to another inside a launch: relaxed agent-scope atomics
+// compile to sc1 stores / loads, which are coherent across CUs and XCDs without any cache write-back or invalidate.
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// merge the splits of one query row (all heads) with one workgroup: one float4 of one head per thread and pass;
+// optionally folds min/max of the row into a stat slot
+template <bool COH>
+__device__ __forceinline__ void attn_merge_row(const float* part_o, const float* part_ml, float* __restrict__ out,
+                                               int64_t row, int nh, int HD, int splits, uint32_t* __restrict__ stats, int stat_slot, int base2) {
+    __shared__ float rlo[4], rhi[4];
+    float lo = 0.0f, hi = 0.0f;
+    const int per_head = HD / 4;
+    for (int i = threadIdx.x; i < nh * per_head; i += 256) {
+        const int64_t head = row * nh + i / per_head;
+        const int d = (i % per_head) * 4;
+        const float* ml = part_ml + head * splits * 2;
+        float mm = -INFINITY;
+        for (int s = 0; s < splits; ++s) mm = fmaxf(mm, COH ? ld_agent(ml + 2 * s) : ml[2 * s]);
+        float lt = 0.0f;
+        float4 ot = make_float4(0, 0, 0, 0);
+        if (mm != -INFINITY) {
+            for (int s = 0; s < splits; ++s) {
+                const float ms = COH ? ld_agent(ml + 2 * s) : ml[2 * s];
+                const float f = (ms == -INFINITY) ? 0.0f : (base2 ? exp2f(ms - mm) : expf(ms - mm));
+                const float* pp = part_o + (head * splits + s) * HD + d;
+                const float4 po = COH ? make_float4(ld_agent(pp), ld_agent(pp + 1), ld_agent(pp + 2), ld_agent(pp + 3)) : *(const float4*)pp;
+                lt = __builtin_fmaf(f, COH ? ld_agent(ml + 2 * s + 1) : ml[2 * s + 1], lt);
+                ot.x = __builtin_fmaf(f, po.x, ot.x); ot.y = __builtin_fmaf(f, po.y, ot.y);
+                ot.z = __builtin_fmaf(f, po.z, ot.z); ot.w = __builtin_fmaf(f, po.w, ot.w);
+            }
+        }
+        float4 v = make_float4(0, 0, 0, 0);
+        if (lt > 0.0f) { v.x = ot.x / lt; v.y = ot.y / lt; v.z = ot.z / lt; v.w = ot.w / lt; }
+        *(float4*)(out + head * HD + d) = v;
+        lo = fminf(lo, fminf(fminf(v.x, v.y), fminf(v.z, v.w)));
+        hi = fmaxf(hi, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+    }
+    if (!stats) return;
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+    if ((threadIdx.x & 63) == 0) { rlo[threadIdx.x >> 6] = lo; rhi[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        lo = fminf(fminf(rlo[0], rlo[1]), fminf(rlo[2], rlo[3]));
+        hi = fmaxf(fmaxf(rhi[0], rhi[1]), fmaxf(rhi[2], rhi[3]));
+        stat_update(stats, stat_slot, (int)row, lo, hi);
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                         float* __restrict__ out, int nh, int HD, int splits, uint32_t* __restrict__ stats,
+                                                         int stat_slot, int base2) {
+    attn_merge_row<false>(part_o, part_ml, out, blockIdx.x, nh, HD, splits, stats, stat_slot, base2);
+}
+
 // ---- decode form: one workgroup = (query row, split), ALL kv heads --------------------------------------------------
 // In the cache a token's K (or V) for all kv heads is one contiguous KVH*HD-element row, so a wave-instruction that
 // covers whole token rows is fully coalesced (512-B segments at 4 x 64 bf16) instead of one 128-B piece per token.
 // Lane = (token in step, kv head, 8-dim chunk); a wave step covers TPS = 64 / (KVH*HD/8) tokens; PD_U steps are loaded
 // together and share one online-softmax update.  Waves of a workgroup take interleaved token groups.
+// The splits of a row are merged by whichever of the row's workgroups finishes last: partial results are written with
+// device-coherent stores and drained (vmcnt) before the workgroup's arrival is counted, and read back with
+// device-coherent loads; the counter is left at zero for the next launch.
 #define PD_U 4
 template <int HD, int KVH, int GS, typename KV>
 __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* __restrict__ q, const KV* __restrict__ k_cache,
                                                                   const KV* __restrict__ v_cache, const int32_t* __restrict__ block_table,
                                                                   int max_blocks_per_seq, const int32_t* __restrict__ slot_ids,
                                                                   const int32_t* __restrict__ ctx_len, float scale, float* __restrict__ out,
-                                                                  float* __restrict__ part_o, float* __restrict__ part_ml, int block,
-                                                                  int splits) {
+                                                                  float* part_o, float* part_ml, int block,
+                                                                  int splits, int* __restrict__ arrivals, uint32_t* __restrict__ stats,
+                                                                  int stat_slot) {
     constexpr int CPH = HD / 8;         // chunk lanes per head
     constexpr int LPT = KVH * CPH;      // lanes per token
     constexpr int TPS = 64 / LPT;       // tokens per wave step
@@ -337,58 +397,24 @@ __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* _
         if (splits == 1) {
             out[head * HD + d] = (lt > 0.0f) ? ot / lt : 0.0f;
         } else {
-            part_o[(head * splits + sp) * HD + d] = ot;
+            st_agent(&part_o[(head * splits + sp) * HD + d], ot);
             if (d == 0) {
-                part_ml[(head * splits + sp) * 2] = mm;
-                part_ml[(head * splits + sp) * 2 + 1] = lt;
+                st_agent(&part_ml[(head * splits + sp) * 2], mm);
+                st_agent(&part_ml[(head * splits + sp) * 2 + 1], lt);
             }
         }
     }
-}
-
-// merge the splits: one workgroup per query row (all heads), one float4 of one head per thread and pass;
-// optionally folds min/max of the row into a stat slot
-__global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
-                                                         float* __restrict__ out, int nh, int HD, int splits, uint32_t* __restrict__ stats,
-                                                         int stat_slot, int base2) {
-    __shared__ float rlo[4], rhi[4];
-    const int64_t row = blockIdx.x;
-    float lo = 0.0f, hi = 0.0f;
-    const int per_head = HD / 4;
-    for (int i = threadIdx.x; i < nh * per_head; i += 256) {
-        const int64_t head = row * nh + i / per_head;
-        const int d = (i % per_head) * 4;
-        const float* ml = part_ml + head * splits * 2;
-        float mm = -INFINITY;
-        for (int s = 0; s < splits; ++s) mm = fmaxf(mm, ml[2 * s]);
-        float lt = 0.0f;
-        float4 ot = make_float4(0, 0, 0, 0);
-        if (mm != -INFINITY) {
-            for (int s = 0; s < splits; ++s) {
-                const float ms = ml[2 * s];
-                const float f = (ms == -INFINITY) ? 0.0f : (base2 ? exp2f(ms - mm) : expf(ms - mm));
-                const float4 po = *(const float4*)(part_o + (head * splits + s) * HD + d);
-                lt = __builtin_fmaf(f, ml[2 * s + 1], lt);
-                ot.x = __builtin_fmaf(f, po.x, ot.x); ot.y = __builtin_fmaf(f, po.y, ot.y);
-                ot.z = __builtin_fmaf(f, po.z, ot.z); ot.w = __builtin_fmaf(f, po.w, ot.w);
-            }
-        }
-        float4 v = make_float4(0, 0, 0, 0);
-        if (lt > 0.0f) { v.x = ot.x / lt; v.y = ot.y / lt; v.z = ot.z / lt; v.w = ot.w / lt; }
-        *(float4*)(out + head * HD + d) = v;
-        lo = fminf(lo, fminf(fminf(v.x, v.y), fminf(v.z, v.w)));
-        hi = fmaxf(hi, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
-    }
-    if (!stats) return;
-    lo = wave_min(lo);
-    hi = wave_max(hi);
-    if ((threadIdx.x & 63) == 0) { rlo[threadIdx.x >> 6] = lo; rhi[threadIdx.x >> 6] = hi; }
-    __syncthreads();
+    if (splits == 1 || arrivals == nullptr) return;
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial results have left the CU ...
+    __syncthreads();                                   // ... and so have those of the workgroup's other waves
     if (threadIdx.x == 0) {
-        lo = fminf(fminf(rlo[0], rlo[1]), fminf(rlo[2], rlo[3]));
-        hi = fmaxf(fmaxf(rhi[0], rhi[1]), fmaxf(rhi[2], rhi[3]));
-        stat_update(stats, stat_slot, blockIdx.x, lo, hi);
+        const int seen = __hip_atomic_fetch_add(&arrivals[row], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = seen == splits - 1;
+        if (s_last) __hip_atomic_store(&arrivals[row], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    __syncthreads();
+    if (s_last) attn_merge_row<true>(part_o, part_ml, out, row, NH, HD, splits, stats, stat_slot, 1);
 }
 
 template <int HD, int GS, typename KV>
@@ -424,11 +450,21 @@ static int dispatch_gs(int gs, int kv_dtype, const float* q, const void* kc, con
     return 1;
 }
 
+#define ATTN_ARRIVALS 4096  // rows whose splits can be merged by the last-arriving workgroup
+
 extern "C" {
 
-// Workspace (floats) needed for `splits` > 1: rows*nh*splits*(hd+2).
+// Workspace (32-bit words) needed for `splits` > 1: ATTN_ARRIVALS arrival counters, then rows*nh*splits*(hd+2) floats of
+// partial results.  The counters must be zero before the first launch that uses the workspace
+// (i64h_paged_attn_workspace_init); every launch leaves them zero.
 int64_t i64h_paged_attn_workspace_floats(int64_t rows, int32_t num_heads, int32_t head_dim, int32_t splits) {
-    return splits > 1 ? rows * num_heads * splits * (int64_t)(head_dim + 2) : 0;
+    return splits > 1 ? ATTN_ARRIVALS + rows * num_heads * splits * (int64_t)(head_dim + 2) : 0;
+}
+
+int i64h_paged_attn_workspace_init(float* workspace, void* stream) {
+    I64H_CHECK_ARG(workspace != nullptr, "paged_attn_workspace_init: null workspace");
+    I64H_CHECK_HIP(hipMemsetAsync(workspace, 0, ATTN_ARRIVALS * sizeof(int32_t), (hipStream_t)stream));
+    return 0;
 }
 
 // kv_dtype: 0 fp32, 1 fp16, 2 bf16.  slot_ids == nullptr: row i uses block_table row i.
@@ -446,8 +482,9 @@ int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, in
     if (rows == 0) return 0;
     const int gs = num_heads / num_kv_heads;
     hipStream_t st = (hipStream_t)stream;
-    float* part_o = workspace;
-    float* part_ml = workspace ? workspace + rows * num_heads * splits * (int64_t)head_dim : nullptr;
+    int* arrivals = (workspace && rows <= ATTN_ARRIVALS) ? (int*)workspace : nullptr;
+    float* part_o = workspace ? workspace + ATTN_ARRIVALS : nullptr;
+    float* part_ml = workspace ? part_o + rows * num_heads * splits * (int64_t)head_dim : nullptr;
     int rc = 1;
     // decode form (few rows, long contexts): all kv heads per workgroup, fully coalesced token rows
     bool done = false;
@@ -457,15 +494,15 @@ int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, in
         if (kv_dtype == 0)                                                                                                             \
             hipLaunchKernelGGL((paged_attn_allheads_kernel<HD_, KVH_, GS_, float>), grid, dim3(256), 0, st, q, (const float*)k_cache, \
                                (const float*)v_cache, block_table, max_blocks_per_seq, slot_ids, ctx_len, softmax_scale, out, part_o,   \
-                               part_ml, block_size, splits);                                                                           \
+                               part_ml, block_size, splits, arrivals, stats, stat_slot);                                                \
         else if (kv_dtype == 1)                                                                                                        \
             hipLaunchKernelGGL((paged_attn_allheads_kernel<HD_, KVH_, GS_, __half>), grid, dim3(256), 0, st, q, (const __half*)k_cache, \
                                (const __half*)v_cache, block_table, max_blocks_per_seq, slot_ids, ctx_len, softmax_scale, out, part_o,  \
-                               part_ml, block_size, splits);                                                                           \
+                               part_ml, block_size, splits, arrivals, stats, stat_slot);                                                \
         else                                                                                                                           \
             hipLaunchKernelGGL((paged_attn_allheads_kernel<HD_, KVH_, GS_, __hip_bfloat16>), grid, dim3(256), 0, st, q,                 \
                                (const __hip_bfloat16*)k_cache, (const __hip_bfloat16*)v_cache, block_table, max_blocks_per_seq,         \
-                               slot_ids, ctx_len, softmax_scale, out, part_o, part_ml, block_size, splits);                            \
+                               slot_ids, ctx_len, softmax_scale, out, part_o, part_ml, block_size, splits, arrivals, stats, stat_slot); \
         done = true;                                                                                                                   \
         rc = 0;                                                                                                                        \
     }
@@ -487,7 +524,7 @@ int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, in
 #undef GO
     I64H_CHECK_ARG(rc == 0, "paged_attn: GQA group size %d unsupported (1, 2, 4, 8)", gs);
     I64H_CHECK_LAUNCH();
-    if (splits > 1) {
+    if (splits > 1 && !(done && arrivals)) {
         hipLaunchKernelGGL(attn_merge_kernel, dim3((unsigned)rows), dim3(256), 0, st, part_o, part_ml, out, (int)num_heads, (int)head_dim,
                            (int)splits, stats, (int)stat_slot, done ? 1 : 0);
         I64H_CHECK_LAUNCH();

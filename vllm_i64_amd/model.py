@@ -210,8 +210,7 @@ class I64MoEModel:
         if max_ctx_hint >= 256 and n <= 256:
             splits = max(1, min(32, 512 // n, max_ctx_hint // 64))
         if splits > 1 and (B.attn_ws is None or B.attn_splits != splits):
-            B.attn_ws = torch.empty(ops._lib.load().i64h_paged_attn_workspace_floats(n, cfg.num_heads, cfg.head_dim, splits),
-                                    dtype=torch.float32, device=self.device)
+            B.attn_ws = ops.attn_workspace(n, cfg.num_heads, cfg.head_dim, splits, self.device)
             B.attn_splits = splits
         ops.fused_residual_norm(B.h, self.layers[0]["ln1"], eps, h_out=B.h, normed=B.normed, slot_base=0, stats=st)
         for l, W in enumerate(self.layers):

@@ -344,6 +344,13 @@ def silu_mul_q7(gate: torch.Tensor, up: torch.Tensor, lut: torch.Tensor) -> torc
 
 
 # ---- attention --------------------------------------------------------------------------------------------------
+def attn_workspace(rows: int, num_heads: int, head_dim: int, splits: int, device) -> torch.Tensor:
+    """Workspace of a split attention launch, arrival counters zeroed (i64h_paged_attn_workspace_init)."""
+    ws = torch.empty(max(1, _lib.load().i64h_paged_attn_workspace_floats(rows, num_heads, head_dim, splits)), dtype=torch.float32, device=device)
+    call("i64h_paged_attn_workspace_init", ptr(ws), _stream())
+    return ws
+
+
 def paged_attn(q, k_cache, v_cache, block_table, ctx_len, slot_ids=None, softmax_scale: Optional[float] = None, splits: int = 1,
                out: Optional[torch.Tensor] = None, workspace: Optional[torch.Tensor] = None, stats: Optional[torch.Tensor] = None,
                stat_slot: int = 0) -> torch.Tensor:
@@ -356,7 +363,7 @@ def paged_attn(q, k_cache, v_cache, block_table, ctx_len, slot_ids=None, softmax
     if out is None:
         out = torch.empty_like(q)
     if splits > 1 and workspace is None:
-        workspace = torch.empty(_lib.load().i64h_paged_attn_workspace_floats(rows, nh, hd, splits), dtype=torch.float32, device=q.device)
+        workspace = attn_workspace(rows, nh, hd, splits, q.device)
     call("i64h_paged_attn", ptr(q), ptr(k_cache), ptr(v_cache), KV_DTYPE_CODE[k_cache.dtype], ptr(block_table), block_table.shape[1],
          ptr(slot_ids), ptr(ctx_len), float(softmax_scale), ptr(out), ptr(workspace), rows, nh, kvh, hd, block, splits, ptr(stats),
          stat_slot, _stream())
