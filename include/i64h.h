@@ -120,7 +120,7 @@ typedef struct i64h_gemm_desc {
     int32_t want_stats;
 } i64h_gemm_desc;
 int i64h_gemm_i8_pair(const i64h_gemm_desc* a, const i64h_gemm_desc* b, void* stream);
-int i64h_set_pipe_gemm(int32_t on); /* tuning knob: 0 = register-staged 128x128 kernel instead of the ring-pipelined one */
+int i64h_set_pipe_gemm(int32_t on); /* tuning knob: 0 = 128-byte LDS stages for every prefill-sized problem (default 1: 64-byte stages, four workgroups per CU, when K <= 2048) */
 int i64h_set_skinny_waves(int32_t waves); /* tuning knob of the decode-sized (weight-streaming) kernel: 4, 8, 16 or 0 = default */
 /* C[M, N] = A[a_rows ? a_rows[m] : m, :K] . B[N, K]^T in fp32 (tied lm_head, vllm_i64/models/complexity_deep/model.py:436-437). */
 int i64h_gemm_f32(const float* A, const int32_t* a_rows, const float* B, float* C, int64_t M, int32_t N, int32_t K, void* stream);
@@ -130,6 +130,35 @@ int i64h_gemm_w8a32(const float* x, const int8_t* w, const float* w_scale, float
 int i64h_gemm_w8a32_swiglu(const float* x, const int8_t* gate_w, const float* gate_scale, const int8_t* up_w, const float* up_scale,
                            float* out, int64_t M, int32_t I, int32_t K, void* stream);
 
+/* ---- one MoE layer behind one call --------------------------------------------------------------------------------------
+ * out[n, H] = TokenRoutedMLP(x, token_ids) of the int8 CPU engine: routes = table[:, clamp(ids)], every (route, expert)
+ * bucket and the shared expert are dynamic-int8 Linear calls with their own per-call activation parameters, SwiGLU,
+ * out = routed_scale * sum_k w_k * R_k + shared_scale * shared (vllm_i64/layers/token_routed_mlp.py:113-187 after
+ * _quantize_cpu_dynamic, vllm_i64/core/loader.py:57-76).  The same signature family as fused_token_routed_forward_int8
+ * (vllm_i64/kernels/fused_experts.py:153-163) with the routing table and the shared expert included.
+ * Weights are the fused nn.Linear matrices as int8 with ONE fp32 scale per fused matrix (amax/127.5):
+ * exp_gate_up [E][2*ei][H] + scale [E], exp_down [E][H][ei] + scale [E], shared_gate_up [2*S][H] + scale [1],
+ * shared_down [H][S] + scale [1] (shared_inter = 0: no shared expert).  route_weights is a HOST array of top_k floats.
+ * workspace: i64h_moe_forward_workspace_bytes(n, layer) bytes, 256-byte aligned, contents irrelevant. */
+typedef struct i64h_moe_layer {
+    const int64_t* table; /* [top_k, vocab] int64 */
+    int64_t vocab;
+    int32_t top_k, num_experts, hidden, expert_inter, shared_inter;
+    const int8_t* exp_gate_up;
+    const float* exp_gate_up_scale;
+    const int8_t* exp_down;
+    const float* exp_down_scale;
+    const int8_t* shared_gate_up;
+    const float* shared_gate_up_scale;
+    const int8_t* shared_down;
+    const float* shared_down_scale;
+    const float* route_weights;
+    float routed_scale, shared_scale;
+} i64h_moe_layer;
+int64_t i64h_moe_forward_workspace_bytes(int64_t n, const i64h_moe_layer* layer);
+int i64h_moe_forward(const float* x, const int64_t* token_ids, int64_t n, const i64h_moe_layer* layer, float* out, void* workspace,
+                     int64_t workspace_bytes, void* stream);
+
 /* ---- row kernels -------------------------------------------------------------------------------------------------------
  * nn.Embedding lookup (model.py:415). */
 int i64h_embedding(const int64_t* ids, const float* table, float* out, int64_t n, int32_t H, int64_t V, void* stream);
@@ -138,6 +167,7 @@ int i64h_rmsnorm(const float* x, const float* weight, float* out, int64_t rows, 
 /* Residual update + MoE combine + RMSNorm + call statistics in one pass (decoder-layer glue, model.py:349-363, and
  * the weighted combine of TokenRoutedMLP.forward, token_routed_mlp.py:156-185):
  *   v = h (+ add) (+ routed_scale * sum_k w_k * moe_rows[moe_inv[k*n+t]] (+ shared_scale * moe_shared));  h_out = v;
+ *   h NULL: no residual stream (v = the bare MoE output);
  *   normed = rmsnorm(v) (skipped if normed NULL); min/max(normed row) -> slots (skipped if stats NULL).
  * route_weights is a HOST array of top_k floats. */
 int i64h_fused_residual_norm(const float* h, const float* add, const float* moe_rows, const int32_t* moe_inv, const float* moe_shared,

@@ -123,3 +123,57 @@ def test_token_routed_mlp_int8_layer_object(dev, golden_dir):
         assert np.array_equal(layer.route(ids).cpu().numpy(), z[f"tiny-moe_n{n}_routes"])
         y = layer(torch.from_numpy(z[f"tiny-moe_n{n}_x"]).to(dev), ids)
         assert np.abs(y.cpu().numpy() - z[f"tiny-moe_n{n}_y"]).max() <= 1e-2
+
+
+def _tiny_moe_layer(dev, w):
+    from vllm_i64_amd.config import ModelConfig
+    from vllm_i64_amd.layers import TokenRoutedMLPInt8
+    ocfg = M.named_config("tiny-moe")
+    return ocfg, TokenRoutedMLPInt8(ModelConfig.from_any(ocfg), {"exp_gate_up": w["l1.exp_gate_up"], "exp_down": w["l1.exp_down"],
+                                                                 "sh_gate_up": w["l1.sh_gate_up"], "sh_down": w["l1.sh_down"],
+                                                                 "table": w["l1.table"]}, device=dev)
+
+
+def test_moe_forward_c_entry_matches_oracle_both_paths(dev):
+    """i64h_moe_forward against the oracle's TokenRoutedMLP on fresh inputs: a decode-sized call (quantizer fused into the
+    GEMMs) and a prefill-sized call (separate quantize + grouped GEMM), ragged buckets included."""
+    ocfg = M.named_config("tiny-moe")
+    w = M.make_weights(ocfg, seed=0)
+    _, layer = _tiny_moe_layer(dev, w)
+    bank = M.LinearBank(w, "int8")
+    g = torch.Generator().manual_seed(11)
+    for n in (3, 100, 700):
+        x = torch.randn(n, ocfg.hidden_size, generator=g) * 0.7
+        ids = torch.randint(0, ocfg.vocab_size, (n,), generator=g)
+        ref = M.moe_forward(ocfg, bank, 1, x, ids).numpy()
+        y = layer(x.to(dev), ids.to(dev)).cpu().numpy()
+        # single quantized Linears may flip one LSB on an fp32-rounding tie of the SwiGLU output; bound from the survey's protocol
+        assert np.abs(y - ref).max() <= 1e-2, (n, np.abs(y - ref).max())
+        assert np.abs(y - ref).mean() <= 1e-5, (n, np.abs(y - ref).mean())
+
+
+def test_moe_forward_without_token_ids_routes_cyclic(dev):
+    """token_ids=None: every token goes to experts (0 + k) % E (token_routed_mlp.py:120-130)."""
+    ocfg = M.named_config("tiny-moe")
+    w = M.make_weights(ocfg, seed=0)
+    _, layer = _tiny_moe_layer(dev, w)
+    w2 = dict(w)
+    w2["l1.table"] = (torch.arange(ocfg.top_k) % ocfg.num_experts).view(-1, 1).expand(ocfg.top_k, ocfg.vocab_size).contiguous()
+    bank = M.LinearBank(w2, "int8")
+    x = torch.randn(37, ocfg.hidden_size, generator=torch.Generator().manual_seed(3)) * 0.5
+    ref = M.moe_forward(ocfg, bank, 1, x, torch.zeros(37, dtype=torch.int64)).numpy()
+    y = layer(x.to(dev), None).cpu().numpy()
+    assert np.array_equal(layer.route(None, 37).cpu().numpy(), np.tile((np.arange(ocfg.top_k) % ocfg.num_experts)[:, None], (1, 37)))
+    assert np.abs(y - ref).max() <= 1e-2 and np.abs(y - ref).mean() <= 1e-5
+
+
+def test_moe_forward_rejects_small_workspace(dev):
+    import ctypes
+    from vllm_i64_amd import _lib, ops
+    ocfg = M.named_config("tiny-moe")
+    _, layer = _tiny_moe_layer(dev, M.make_weights(ocfg, seed=0))
+    x = torch.zeros(8, ocfg.hidden_size, device=dev)
+    ids = torch.zeros(8, dtype=torch.int64, device=dev)
+    ws = torch.empty(256, dtype=torch.uint8, device=dev)
+    with pytest.raises(RuntimeError, match="workspace"):
+        ops.call("i64h_moe_forward", ops.ptr(x), ops.ptr(ids), 8, ctypes.addressof(layer._layer), ops.ptr(x), ops.ptr(ws), 256, ops._stream())

@@ -45,6 +45,7 @@ SIGNATURES: Dict[str, str] = {
     "i64h_paged_attn": "pppipippfppliiiiipip",
     "i64h_paged_attn_workspace_init": "pp",
     "i64h_gemm_i8_pair": "ppp",
+    "i64h_moe_forward": "pplppplp",
     "i64h_set_skinny_waves": "i",
     "i64h_set_pipe_gemm": "i",
 }
@@ -59,7 +60,7 @@ class I64HError(RuntimeError):
 
 def exported_symbols():
     return ["i64h_last_error", "i64h_version", "i64h_device_check", "i64h_bucketize_workspace_bytes",
-            "i64h_paged_attn_workspace_floats", "i64h_stats_words_per_slot", *SIGNATURES.keys()]
+            "i64h_paged_attn_workspace_floats", "i64h_stats_words_per_slot", "i64h_moe_forward_workspace_bytes", *SIGNATURES.keys()]
 
 
 class GemmDesc(ctypes.Structure):
@@ -68,6 +69,14 @@ class GemmDesc(ctypes.Structure):
                 ("a_slot_base", _I), ("B", _P), ("w_scale", _P), ("group_offsets", _P), ("num_groups", _I), ("M_total", _L),
                 ("N", _I), ("K", _I), ("C", _P), ("epilogue", _I), ("out_row_slot", _P), ("out_slot_base", _I), ("stats", _P),
                 ("want_stats", _I)]
+
+
+class MoeLayer(ctypes.Structure):
+    """Mirror of i64h_moe_layer (include/i64h.h)."""
+    _fields_ = [("table", _P), ("vocab", _L), ("top_k", _I), ("num_experts", _I), ("hidden", _I), ("expert_inter", _I),
+                ("shared_inter", _I), ("exp_gate_up", _P), ("exp_gate_up_scale", _P), ("exp_down", _P), ("exp_down_scale", _P),
+                ("shared_gate_up", _P), ("shared_gate_up_scale", _P), ("shared_down", _P), ("shared_down_scale", _P),
+                ("route_weights", _P), ("routed_scale", ctypes.c_float), ("shared_scale", ctypes.c_float)]
 
 
 def load() -> ctypes.CDLL:
@@ -91,6 +100,8 @@ def load() -> ctypes.CDLL:
     lib.i64h_paged_attn_workspace_floats.argtypes = [_L, _I, _I, _I]
     lib.i64h_stats_words_per_slot.restype = _I
     lib.i64h_stats_words_per_slot.argtypes = []
+    lib.i64h_moe_forward_workspace_bytes.restype = _L
+    lib.i64h_moe_forward_workspace_bytes.argtypes = [_L, _P]
     for name, sig in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = _I

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void fused_residual_norm_kernel(const float* _
         for (int j = 0; j < FRN_MAXV; ++j) {
             const int i = threadIdx.x + j * 256;
             if (i < nv) {
-                float4 a = ((const float4*)(h + t * H))[i];
+                float4 a = h ? ((const float4*)(h + t * H))[i] : make_float4(0, 0, 0, 0);
                 if (add) {
                     float4 b = ((const float4*)(add + t * H))[i];
                     a.x = a.x + b.x; a.y = a.y + b.y; a.z = a.z + b.z; a.w = a.w + b.w;
@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256) void fused_residual_norm_kernel(const float* _
                     } else {
                         o.x = mc.routed_scale * o.x; o.y = mc.routed_scale * o.y; o.z = mc.routed_scale * o.z; o.w = mc.routed_scale * o.w;
                     }
-                    a.x = a.x + o.x; a.y = a.y + o.y; a.z = a.z + o.z; a.w = a.w + o.w;
+                    if (h || add) { a.x = a.x + o.x; a.y = a.y + o.y; a.z = a.z + o.z; a.w = a.w + o.w; }
+                    else a = o;  // no residual stream: the bare MoE output
                 }
                 if (h_out) ((float4*)(h_out + t * H))[i] = a;
                 v[j] = a;

@@ -92,28 +92,70 @@ silu_multiply_integer = I64Ops.silu_multiply_integer
 
 
 class TokenRoutedMLPInt8:
-    """One token-routed MoE layer with the reference CPU engine's dynamic int8 Linears.
+    """One token-routed MoE layer with the reference CPU engine's dynamic int8 Linears, run by ONE C-ABI call
+    (i64h_moe_forward): table lookup -> (route, expert) buckets -> per-call quantization -> grouped expert GEMMs + shared
+    expert -> weighted combine.  Mirrors TokenRoutedMLP.forward(x, token_ids) (token_routed_mlp.py:154-187).
 
     weights: dict with exp_gate_up [E, 2*ei, H], exp_down [E, H, ei], optional sh_gate_up [2S, H] / sh_down [H, S] (the
     fused nn.Linear weights of materialize_expert_linears / fuse_shared_gate_up, token_routed_mlp.py:189-250) and
     table int64 [top_k, V] (topk_token_to_expert)."""
 
     def __init__(self, cfg: ModelConfig, weights: Dict[str, torch.Tensor], device="cuda:0"):
-        from .model import I64MoEModel
-        one = ModelConfig.from_any(cfg)
-        one.num_layers = 1
-        H, kvw, hd = one.hidden_size, one.num_kv_heads * one.head_dim, one.head_dim
-        w = {"embed": torch.zeros(one.vocab_size, H), "final_norm": torch.ones(H), "l0.ln1": torch.ones(H), "l0.ln2": torch.ones(H),
-             "l0.qkv": torch.zeros(H + 2 * kvw, H), "l0.o": torch.zeros(H, H), "l0.q_norm": torch.ones(hd), "l0.k_norm": torch.ones(hd),
-             "l0.exp_gate_up": weights["exp_gate_up"], "l0.exp_down": weights["exp_down"], "l0.table": weights["table"]}
-        if one.shared_intermediate_size:
-            w["l0.sh_gate_up"], w["l0.sh_down"] = weights["sh_gate_up"], weights["sh_down"]
-        self.model = I64MoEModel(one, w, device=device, max_seqs=1, num_kv_blocks=1)
+        import ctypes
+        from . import _lib
+        from .model import pack_per_tensor
+        cfg = ModelConfig.from_any(cfg)
+        self.cfg, self.device = cfg, torch.device(device)
+        self.table = weights["table"].to(device=self.device, dtype=torch.int64).contiguous()
+        # token_ids=None routes every token to experts (0 + k) % E (token_routed_mlp.py:120-130): a one-entry table
+        self.none_table = (torch.arange(cfg.top_k, dtype=torch.int64) % cfg.num_experts).view(cfg.top_k, 1).to(self.device).contiguous()
+        self.exp_gu = pack_per_tensor(weights["exp_gate_up"], self.device)
+        self.exp_dn = pack_per_tensor(weights["exp_down"], self.device)
+        shared = bool(cfg.shared_intermediate_size)
+        self.sh_gu = pack_per_tensor(weights["sh_gate_up"], self.device) if shared else None
+        self.sh_dn = pack_per_tensor(weights["sh_down"], self.device) if shared else None
+        self._rw = (ctypes.c_float * cfg.top_k)(*cfg.route_weights)
+        L = _lib.MoeLayer()
+        L.table, L.vocab = ops.ptr(self.table), self.table.shape[1]
+        L.top_k, L.num_experts, L.hidden = cfg.top_k, cfg.num_experts, cfg.hidden_size
+        L.expert_inter, L.shared_inter = cfg.expert_inter, cfg.shared_intermediate_size or 0
+        L.exp_gate_up, L.exp_gate_up_scale = ops.ptr(self.exp_gu.w_q), ops.ptr(self.exp_gu.w_s)
+        L.exp_down, L.exp_down_scale = ops.ptr(self.exp_dn.w_q), ops.ptr(self.exp_dn.w_s)
+        if shared:
+            L.shared_gate_up, L.shared_gate_up_scale = ops.ptr(self.sh_gu.w_q), ops.ptr(self.sh_gu.w_s)
+            L.shared_down, L.shared_down_scale = ops.ptr(self.sh_dn.w_q), ops.ptr(self.sh_dn.w_s)
+        L.route_weights = ctypes.addressof(self._rw)
+        L.routed_scale, L.shared_scale = cfg.routed_scale, cfg.shared_scale
+        self._layer = L
+        self._ws: Optional[torch.Tensor] = None
 
-    def route(self, token_ids: torch.Tensor) -> torch.Tensor:
-        return ops.route_lookup(token_ids.to(torch.int64).contiguous(), self.model.tables[0])
+    def route(self, token_ids: Optional[torch.Tensor], num_tokens: Optional[int] = None) -> torch.Tensor:
+        if token_ids is None:
+            return self.none_table.expand(-1, num_tokens).contiguous()
+        return ops.route_lookup(token_ids.to(torch.int64).contiguous(), self.table)
 
-    def forward(self, x: torch.Tensor, token_ids: torch.Tensor) -> torch.Tensor:
-        return self.model.moe_layer(0, x.float().contiguous(), token_ids.to(torch.int64).contiguous()).to(x.dtype)
+    def forward(self, x: torch.Tensor, token_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
+        import ctypes
+        from . import _lib
+        xf = x.float().contiguous()
+        if xf.device.type != "cuda":
+            raise RuntimeError("TokenRoutedMLPInt8 runs on the GPU only (no CPU fallback)")
+        n = xf.shape[0]
+        L = self._layer
+        if token_ids is None:
+            ids = torch.zeros(n, dtype=torch.int64, device=xf.device)
+            L = _lib.MoeLayer.from_buffer_copy(self._layer)
+            L.table, L.vocab = ops.ptr(self.none_table), 1
+        else:
+            ids = token_ids.to(device=xf.device, dtype=torch.int64).contiguous()
+        need = _lib.load().i64h_moe_forward_workspace_bytes(n, ctypes.addressof(L))
+        if need < 0:
+            raise RuntimeError(_lib.load().i64h_last_error().decode())
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(max(need, 256), dtype=torch.uint8, device=xf.device)
+        out = torch.empty_like(xf)
+        ops.call("i64h_moe_forward", ops.ptr(xf), ops.ptr(ids), n, ctypes.addressof(L), ops.ptr(out), ops.ptr(self._ws), self._ws.numel(),
+                 ops._stream())
+        return out.to(x.dtype)
 
     __call__ = forward
