@@ -184,8 +184,18 @@ def main():
     attn_ms = sum(attn_ms) / len(attn_ms)
     attn_bytes = B * ctx_now * cfg.num_kv_heads * cfg.head_dim * 2 * kvb  # K and V rows of every cached token, once
     achieved = attn_bytes / (attn_ms * 1e-3) / 1e9
+    # HBM-side bytes of the same kernel from the counter passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
+    # --pmc WRITE_SIZE in runs of their own; FETCH_SIZE doubled, the gfx950 correction): a profiler cannot run inside this process
+    traffic = None
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as f:
+            for kname, kd in json.load(f)["kernels"].items():
+                if "paged_attn_allheads_kernel" in kname and ("bfloat16" in kname) == (args.kv_dtype == "bf16"):
+                    traffic = int(kd["hbm_read_bytes_corrected"] + kd["hbm_write_bytes"])
+    except Exception:
+        traffic = None
     roofline = {"bound": "hbm", "kernel": "paged_attn_allheads_kernel of one layer (split merge included)", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "avg_launch_ms": round(attn_ms, 4), "algorithmic_bytes_per_launch": attn_bytes, "splits": splits,
                 "share_of_step": round(attn_ms * cfg.num_layers / ms_per_step, 3)}
 

@@ -36,9 +36,10 @@ def flush():
     _junk = torch.empty(512 << 20, dtype=torch.uint8, device=dev).fill_(1)
 
 
-def bench_attn():
-    B, ctx, nh, kvh, hd = 64, 2048, 16, 4, 64
-    for dt in (torch.bfloat16, torch.float32):
+def bench_attn(ctx=2048, dts=(torch.bfloat16, torch.float32), splits_list=(4, 8, 16, 32)):
+    B, nh, kvh, hd = 64, 16, 4, 64
+    print(f"--- context {ctx}")
+    for dt in dts:
         nblk = B * (ctx // 16 + 2)
         kc = torch.randn(nblk, 16, kvh, hd, device=dev).to(dt)
         vc = torch.randn(nblk, 16, kvh, hd, device=dev).to(dt)
@@ -51,7 +52,7 @@ def bench_attn():
         dst = torch.empty_like(src)
         med, best = timeit(lambda: dst.copy_(src))
         print(f"reference: torch device copy of the same bytes {med:7.1f} us -> read {nbytes / med / 1e3:7.1f} GB/s (+ equal write)")
-        for splits in (4, 8, 16, 32):
+        for splits in splits_list:
             ws = ops.attn_workspace(B, nh, hd, splits, dev)
             med, best = timeit(lambda: ops.paged_attn(q, kc, vc, bt, cl, splits=splits, out=out, workspace=ws))
             print(f"attn {str(dt)[6:]:9s} splits {splits:2d}: median {med:7.1f} us best {best:7.1f} us -> {nbytes / med / 1e3:7.1f} GB/s (attn+merge)")
@@ -134,6 +135,10 @@ if __name__ == "__main__":
     if what == "gemm1":  # one shape, one variant: python tools/kbench.py gemm1 <variant> <name substring> (for counter passes)
         ops.call("i64h_set_pipe_gemm", int(sys.argv[2]))
         bench_gemm_prefill(sys.argv[3])
+        sys.exit(0)
+    if what == "attnctx":  # fixed cost vs streaming cost of the decode attention
+        for ctx in (128, 512, 1024, 2048, 4096):
+            bench_attn(ctx, dts=(torch.bfloat16,), splits_list=(2, 4, 8))
         sys.exit(0)
     if what == "ablate":
         for v in (0, 80, 160, 240, 310):

@@ -15,6 +15,8 @@
 #include <math.h>
 
 // 8 consecutive cache elements of one token: raw registers (issued early) and their fp32 view (converted late)
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 template <typename KV> struct Raw8;
 template <> struct Raw8<float> {
     float4 a, b;
@@ -284,17 +286,19 @@ __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* _
     const int t_begin = sp * bps * block;
     const int t_end = min(ctx, (sp + 1) * bps * block);
 
-    float qr[GS][8], acc[GS][8], m[GS], l[GS];
+    // dims are handled in pairs so that the dot products and the value accumulation compile to packed fp32 FMAs
+    v2f qr[GS][4], acc[GS][4];
+    float m[GS], l[GS];
 #pragma unroll
     for (int h = 0; h < GS; ++h) {
         const float* qp = q + ((int64_t)row * NH + kh * GS + h) * HD + ch * 8;
         float4 a = *(const float4*)qp, b = *(const float4*)(qp + 4);
-        qr[h][0] = a.x; qr[h][1] = a.y; qr[h][2] = a.z; qr[h][3] = a.w;
-        qr[h][4] = b.x; qr[h][5] = b.y; qr[h][6] = b.z; qr[h][7] = b.w;
+        qr[h][0] = (v2f){a.x, a.y}; qr[h][1] = (v2f){a.z, a.w};
+        qr[h][2] = (v2f){b.x, b.y}; qr[h][3] = (v2f){b.z, b.w};
         m[h] = -INFINITY;
         l[h] = 0.0f;
 #pragma unroll
-        for (int d = 0; d < 8; ++d) acc[h][d] = 0.0f;
+        for (int d = 0; d < 4; ++d) acc[h][d] = (v2f){0.0f, 0.0f};
     }
     constexpr int TPI = PD_U * TPS;  // tokens per wave iteration
     auto fetch_blocks = [&](int t0, int (&pb)[PD_U]) {
@@ -304,22 +308,32 @@ __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* _
             pb[u] = bt[tc / block];
         }
     };
+    // the K/V rows of iteration i+1 are requested before the math of iteration i (and the block-table entries one
+    // iteration before that), so the loop never waits for a whole memory round trip
     int pbn[PD_U];
-    fetch_blocks(t_begin + wid * TPI, pbn);
-    for (int t0 = t_begin + wid * TPI; t0 < t_end; t0 += 4 * TPI) {
-        Raw8<KV> rk[PD_U], rv[PD_U];
-        bool live[PD_U];
+    Raw8<KV> nk[PD_U], nv[PD_U];
+    bool nlive[PD_U];
+    auto issue = [&](int t0) {
 #pragma unroll
         for (int u = 0; u < PD_U; ++u) {
             const int t = t0 + u * TPS + tl;
             const int tc = max(0, min(t, t_end - 1));
             const int pb = pbn[u];
-            live[u] = t < t_end && pb >= 0;
+            nlive[u] = t < t_end && pb >= 0;
             const int64_t off = ((int64_t)max(pb, 0) * block + (tc % block)) * (KVH * HD) + (lane % LPT) * 8;
-            rk[u].load(k_cache + off);
-            rv[u].load(v_cache + off);
+            nk[u].load(k_cache + off);
+            nv[u].load(v_cache + off);
         }
         fetch_blocks(t0 + 4 * TPI, pbn);
+    };
+    fetch_blocks(t_begin + wid * TPI, pbn);
+    issue(t_begin + wid * TPI);
+    for (int t0 = t_begin + wid * TPI; t0 < t_end; t0 += 4 * TPI) {
+        Raw8<KV> rk[PD_U], rv[PD_U];
+        bool live[PD_U];
+#pragma unroll
+        for (int u = 0; u < PD_U; ++u) { rk[u] = nk[u]; rv[u] = nv[u]; live[u] = nlive[u]; }
+        if (t0 + 4 * TPI < t_end) issue(t0 + 4 * TPI);
         float s[PD_U][GS];
 #pragma unroll
         for (int u = 0; u < PD_U; ++u) {
@@ -327,9 +341,10 @@ __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* _
             rk[u].get(kf);
 #pragma unroll
             for (int h = 0; h < GS; ++h) {
-                float a = 0.0f;
+                v2f a2 = (v2f){0.0f, 0.0f};
 #pragma unroll
-                for (int d = 0; d < 8; ++d) a = __builtin_fmaf(qr[h][d], kf[d], a);
+                for (int d = 0; d < 4; ++d) a2 = __builtin_elementwise_fma(qr[h][d], (v2f){kf[2 * d], kf[2 * d + 1]}, a2);
+                float a = a2.x + a2.y;
                 a = group_sum(a, CPH);
                 s[u][h] = live[u] ? (a * scale) * LOG2E : -INFINITY;  // scores kept in log2 units: exp2 is one instruction
             }
@@ -349,7 +364,7 @@ __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* _
             m[h] = mn;
             l[h] *= alpha;
 #pragma unroll
-            for (int d = 0; d < 8; ++d) acc[h][d] *= alpha;
+            for (int d = 0; d < 4; ++d) acc[h][d] *= alpha;
         }
 #pragma unroll
         for (int u = 0; u < PD_U; ++u) {
@@ -360,7 +375,7 @@ __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* _
                 const float p = live[u] ? exp2f(s[u][h] - m[h]) : 0.0f;
                 l[h] += p;
 #pragma unroll
-                for (int d = 0; d < 8; ++d) acc[h][d] = __builtin_fmaf(p, vf[d], acc[h][d]);
+                for (int d = 0; d < 4; ++d) acc[h][d] = __builtin_elementwise_fma((v2f){p, p}, (v2f){vf[2 * d], vf[2 * d + 1]}, acc[h][d]);
             }
         }
     }
@@ -371,12 +386,18 @@ __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* _
         for (int o = LPT; o < 64; o <<= 1) {
             l[h] += __shfl_xor(l[h], o);
 #pragma unroll
-            for (int d = 0; d < 8; ++d) acc[h][d] += __shfl_xor(acc[h][d], o);
+            for (int d = 0; d < 4; ++d) {
+                acc[h][d].x += __shfl_xor(acc[h][d].x, o);
+                acc[h][d].y += __shfl_xor(acc[h][d].y, o);
+            }
         }
         if (tl == 0) {
             const int head = kh * GS + h;
 #pragma unroll
-            for (int d = 0; d < 8; ++d) s_o[wid][head][ch * 8 + d] = acc[h][d];
+            for (int d = 0; d < 4; ++d) {
+                s_o[wid][head][ch * 8 + 2 * d] = acc[h][d].x;
+                s_o[wid][head][ch * 8 + 2 * d + 1] = acc[h][d].y;
+            }
             if (ch == 0) { s_m[wid][head] = m[h]; s_l[wid][head] = l[h]; }
         }
     }
