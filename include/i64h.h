@@ -121,6 +121,7 @@ typedef struct i64h_gemm_desc {
 } i64h_gemm_desc;
 int i64h_gemm_i8_pair(const i64h_gemm_desc* a, const i64h_gemm_desc* b, void* stream);
 int i64h_set_pipe_gemm(int32_t on); /* tuning knob: 0 = 128-byte LDS stages for every prefill-sized problem (default 1: 64-byte stages, four workgroups per CU, when K <= 2048) */
+int i64h_debug_set_stamps(void* buffer, int64_t capacity_workgroups); /* diagnostics: 8 uint64 per workgroup of s_memtime phase stamps from the decode-sized kernel, launches appended; NULL = off */
 int i64h_set_skinny_waves(int32_t waves); /* tuning knob of the decode-sized (weight-streaming) kernel: 4, 8, 16 or 0 = default */
 /* C[M, N] = A[a_rows ? a_rows[m] : m, :K] . B[N, K]^T in fp32 (tied lm_head, vllm_i64/models/complexity_deep/model.py:436-437). */
 int i64h_gemm_f32(const float* A, const int32_t* a_rows, const float* B, float* C, int64_t M, int32_t N, int32_t K, void* stream);

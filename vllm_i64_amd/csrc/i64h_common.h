@@ -70,6 +70,23 @@ __device__ __forceinline__ void stat_read(const uint32_t* stats, int slot, float
     hi = ordered_to_f32(b);
 }
 
+// the same in two steps, so that a kernel can request the words early and fold them after other loads were issued
+__device__ __forceinline__ void stat_load_raw(const uint32_t* stats, int slot, uint4 (&w)[I64H_SLOT_WORDS / 4]) {
+    const uint4* p = (const uint4*)(stats + (int64_t)slot * I64H_SLOT_WORDS);
+#pragma unroll
+    for (int j = 0; j < I64H_SLOT_WORDS / 4; ++j) w[j] = p[j];
+}
+__device__ __forceinline__ void stat_fold_raw(const uint4 (&w)[I64H_SLOT_WORDS / 4], float& lo, float& hi) {
+    uint32_t a = 0xffffffffu, b = 0u;
+#pragma unroll
+    for (int j = 0; j < I64H_SLOT_WORDS / 4; ++j) {  // words alternate (min, max)
+        a = min(a, min(w[j].x, w[j].z));
+        b = max(b, max(w[j].y, w[j].w));
+    }
+    lo = ordered_to_f32(a);
+    hi = ordered_to_f32(b);
+}
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));

@@ -44,6 +44,7 @@ struct GemmI8Args {
     int out_slot_base;
     uint32_t* stats;           // stat slots (input parameters for a_fp32, output statistics for EPI_SWIGLU); may be nullptr
     int want_stats;
+    unsigned long long* stamps;  // diagnostics: per-workgroup phase timestamps (nullptr = off)
 };
 struct GemmI8Pair {
     GemmI8Args p[2];
@@ -373,11 +374,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void
 // their 16 up partners), all row fragments.
 #define SK_BM 16  // operand rows per workgroup: one MFMA row fragment (more, smaller workgroups; each reads 1/4 of a 64-row operand)
 #define SK_MF (SK_BM / 16)
-#define SK_STEPS 8  // K steps (64 deep) whose B fragments are in flight together
 
 template <int EPI, int NW>
 __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const int bid, char* smem) {
     constexpr int NF = (EPI == EPI_SWIGLU) ? 2 : 1;  // B fragments per wave per step
+    // K steps (64 deep) whose B fragments are in flight together: all of K = 1024 in one batch (half with two fragments per step)
+    constexpr int SK_STEPS = 16 / NF;
     const int K = p.K, LDA = K + 32;
     // LDS: A [64][LDA] int8 | info (16 B) | q_inv[64] q_scale[64] q_zp[64]
     int* s_info = (int*)(smem + SK_BM * LDA);
@@ -390,6 +392,8 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
     const int n_tiles = (nout + BNB - 1) / BNB;
     const int mt = bid / n_tiles, nt = bid % n_tiles;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+#define SK_STAMP(i) do { if (p.stamps && tid == 0) p.stamps[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+    SK_STAMP(0);
     if (tid == 0) {
         int g = -1, row0 = 0, rows = 0, acc_tiles = 0;
         const int G = p.group_off ? p.G : 1;
@@ -422,7 +426,12 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
     bp[0] = Bg + (int64_t)(col_ok ? col : 0) * K + fq * 16;
     if (NF == 2) bp[1] = Bg + (int64_t)(I + (col_ok ? col : 0)) * K + fq * 16;
 
-    // first batch of weight fragments in flight before anything else
+    // the statistics of the rows' Linear calls are requested first: vector loads retire in order, so everything that is
+    // requested before them would have to land before the parameters can be derived
+    uint4 sw[I64H_SLOT_WORDS / 4];
+    if (tid < rows) stat_load_raw(p.stats, p.a_slot_base + (p.a_row_slot ? p.a_row_slot[row0 + tid] : 0), sw);
+
+    // then the first batch of weight fragments
     v4i bq[NF][SK_STEPS];
     auto bload = [&](int s0) {
 #pragma unroll
@@ -433,21 +442,16 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
         }
     };
     bload(0);
+    SK_STAMP(1);
 
-    // quantization parameters of the rows, then the operand rows themselves
-    if (tid < SK_BM) {
-        QParams q;
-        q.scale = 0.0f; q.inv_scale = 0.0f; q.zp = 0;
-        if (tid < rows) q = slot_qparams(p.stats, p.a_slot_base + (p.a_row_slot ? p.a_row_slot[row0 + tid] : 0));
-        q_inv[tid] = q.inv_scale; q_scale[tid] = q.scale; q_zp[tid] = q.zp;
-    }
-    __syncthreads();
+    // the operand rows are requested first (their addresses do not depend on the parameters), then the quantization
+    // parameters of the rows are derived while those loads are in flight
     const int mfr = (rows + 15) / 16;          // live row fragments
     const int cpr = K / 16;                    // 16-element chunks per row
     const int total_chunks = mfr * 16 * cpr;   // rows padded to whole fragments (padding rows are zero)
-    for (int c0 = tid; c0 < total_chunks; c0 += NT * 4) {
-        float4 f[4][4];
-        int rr[4], kc[4];
+    float4 f[4][4];
+    int rr[4], kc[4];
+    auto a_issue = [&](int c0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int c = c0 + u * NT;
@@ -461,6 +465,21 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
 #pragma unroll
             for (int e = 0; e < 4; ++e) f[u][e] = ok ? *(const float4*)(ap + e * 4) : make_float4(0, 0, 0, 0);
         }
+    };
+    a_issue(tid);
+    if (tid < SK_BM) {
+        QParams q;
+        q.scale = 0.0f; q.inv_scale = 0.0f; q.zp = 0;
+        if (tid < rows) {
+            float lo, hi;
+            stat_fold_raw(sw, lo, hi);
+            q = choose_qparams_u7(lo, hi);
+        }
+        q_inv[tid] = q.inv_scale; q_scale[tid] = q.scale; q_zp[tid] = q.zp;
+    }
+    __syncthreads();
+    SK_STAMP(2);
+    for (int c0 = tid; c0 < total_chunks; c0 += NT * 4) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int c = c0 + u * NT;
@@ -476,8 +495,10 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
             }
             *(uint4*)(smem + rr[u] * LDA + kc[u] * 16) = make_uint4(w[0], w[1], w[2], w[3]);
         }
+        if (c0 + NT * 4 < total_chunks) a_issue(c0 + NT * 4);
     }
     __syncthreads();
+    SK_STAMP(3);
 
     v4i acc[SK_MF][NF];
 #pragma unroll
@@ -504,6 +525,7 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
         }
     }
 
+    SK_STAMP(4);
     const float ws = p.w_scale[g];
     if (EPI == EPI_STORE) {
 #pragma unroll
@@ -562,6 +584,9 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
                 }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SK_STAMP(5);
+#undef SK_STAMP
 }
 
 template <int EPI, int NW>
@@ -756,12 +781,15 @@ static int check_desc(const i64h_gemm_desc* d, const char* who) {
     return 0;
 }
 
+static unsigned long long* g_stamps = nullptr;  // diagnostics, see i64h_debug_set_stamps
+static int64_t g_stamp_cap = 0, g_stamp_cur = 0;   // capacity / cursor in workgroups: every launch appends its own block of stamps
 static GemmI8Args to_args(const i64h_gemm_desc* d) {
     GemmI8Args p;
     p.A = d->A; p.a_src_row = d->a_src_row; p.a_src_mod = d->a_src_mod; p.row_scale = d->row_scale; p.a_row_slot = d->a_row_slot;
     p.a_slot_base = d->a_slot_base; p.B = d->B; p.w_scale = d->w_scale; p.group_off = d->group_offsets; p.G = d->num_groups;
     p.M_total = (int)d->M_total; p.N = d->N; p.K = d->K; p.C = d->C; p.out_row_slot = d->out_row_slot; p.out_slot_base = d->out_slot_base;
     p.stats = d->stats; p.want_stats = d->want_stats;
+    p.stamps = nullptr;
     return p;
 }
 
@@ -804,6 +832,10 @@ static int launch_skinny(const i64h_gemm_desc* a, const i64h_gemm_desc* b, hipSt
     pp.nblk0 = skinny_blocks(a, NW * 16);
     const int total = pp.nblk0 + (b ? skinny_blocks(b, NW * 16) : 0);
     if (total == 0) return 0;
+    if (g_stamps && g_stamp_cur + total <= g_stamp_cap) {
+        pp.p[0].stamps = pp.p[1].stamps = g_stamps + g_stamp_cur * 8;
+        g_stamp_cur += total;
+    }
     const int kmax = b && b->K > a->K ? b->K : a->K;
     const size_t lds = (size_t)SK_BM * (kmax + 32) + 16 + 3 * SK_BM * 4;
     hipLaunchKernelGGL((gemm_i8_skinny_kernel<EPI, NW>), dim3((unsigned)total), dim3(NW * 64), lds, st, pp);
@@ -831,6 +863,17 @@ extern "C" {
 // tuning knob: 1 (default) = short-K prefill-sized problems use 64-byte stages, four workgroups per CU; 0 = always 128-byte stages
 int i64h_set_pipe_gemm(int32_t on) {
     g_stage64 = on ? 1 : 0;
+    return 0;
+}
+
+// diagnostics: device buffer of 8 uint64 per workgroup that the weight-streaming kernel fills with s_memtime stamps at its
+// phase boundaries (0 entry, 1 weights requested, 2 row parameters ready, 3 operand rows quantized, 4 K loop done, 5 stores
+// drained); successive launches append (launch i's workgroups follow launch i-1's) until the capacity is used up; NULL
+// switches it off
+int i64h_debug_set_stamps(void* buffer, int64_t capacity_workgroups) {
+    g_stamps = (unsigned long long*)buffer;
+    g_stamp_cap = buffer ? capacity_workgroups : 0;
+    g_stamp_cur = 0;
     return 0;
 }
 
