@@ -177,3 +177,24 @@ def test_moe_forward_rejects_small_workspace(dev):
     ws = torch.empty(256, dtype=torch.uint8, device=dev)
     with pytest.raises(RuntimeError, match="workspace"):
         ops.call("i64h_moe_forward", ops.ptr(x), ops.ptr(ids), 8, ctypes.addressof(layer._layer), ops.ptr(x), ops.ptr(ws), 256, ops._stream())
+
+
+def test_expert_parallel_layer_hip_backend_single_rank(dev):
+    """The expert-parallel layer on the HIP backend at world size 1 (degenerate exchange, real kernels): equals the oracle
+    layer; the exchange itself is rehearsed at world sizes 2 and 4 over gloo in tests/test_cpu_ep.py."""
+    from vllm_i64_amd import ep
+    from vllm_i64_amd.config import ModelConfig
+    ocfg = M.named_config("tiny-moe")
+    cfg = ModelConfig.from_any(ocfg)
+    w = M.make_weights(ocfg, seed=0)
+    be = ep.HipBackend(cfg, {"exp_gate_up": w["l1.exp_gate_up"], "exp_down": w["l1.exp_down"], "sh_gate_up": w["l1.sh_gate_up"],
+                             "sh_down": w["l1.sh_down"]}, dev)
+    layer = ep.ExpertParallelMoE(cfg, w["l1.table"].to(dev), be)
+    bank = M.LinearBank(w, "int8")
+    g = torch.Generator().manual_seed(5)
+    for n in (1, 59, 400):
+        x = torch.randn(n, ocfg.hidden_size, generator=g) * 0.7
+        ids = torch.randint(0, ocfg.vocab_size, (n,), generator=g)
+        ref = M.moe_forward(ocfg, bank, 1, x, ids).numpy()
+        y = layer(x.to(dev), ids.to(dev)).cpu().numpy()
+        assert np.abs(y - ref).max() <= 1e-2 and np.abs(y - ref).mean() <= 1e-5, (n, np.abs(y - ref).max())
