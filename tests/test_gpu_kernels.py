@@ -339,6 +339,56 @@ def test_paged_attention_random(dev, hd, nh, kvh):
         torch.testing.assert_close(out[i], ref, rtol=1e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("nh,kvh,kv_dtype,tol", [(16, 4, torch.float32, 3e-6), (16, 4, torch.bfloat16, 3e-6), (8, 8, torch.float16, 3e-6),
+                                                 (4, 2, torch.float32, 3e-6), (8, 1, torch.bfloat16, 3e-6)])
+def test_prefill_attention_matrix_core_kernel(dev, nh, kvh, kv_dtype, tol):
+    """The 16-row-tile f32 matrix-core kernel (>= 256 rows, head_dim 64): ragged sequences whose boundaries fall inside
+    tiles, a sequence continuing behind a cached prefix, a zero-length row, a random block table; against the oracle's
+    cached attention on the values the cache really holds (rounded to the cache dtype), and against the row-per-workgroup
+    kernel."""
+    ops = _ops()
+    hd = 64
+    g = torch.Generator().manual_seed(nh * 7 + kvh)
+    # (cached prefix, new tokens): rows are the new tokens, ctx = prefix + i + 1
+    seqs = [(0, 150), (0, 1), (90, 77), (0, 40), (33, 3), (0, 129)]
+    nblk = sum((p + t + 15) // 16 for p, t in seqs) + 2
+    kc = torch.empty(nblk, 16, kvh, hd).normal_(0, 1, generator=g).to(kv_dtype)
+    vc = torch.empty(nblk, 16, kvh, hd).normal_(0, 1, generator=g).to(kv_dtype)
+    perm = torch.randperm(nblk, generator=g).to(torch.int32)
+    bt = torch.full((len(seqs), 16), -1, dtype=torch.int32)
+    used, slot, ctx = 0, [], []
+    for s_, (p_, t_) in enumerate(seqs):
+        nb = (p_ + t_ + 15) // 16
+        bt[s_, :nb] = perm[used:used + nb]
+        used += nb
+        slot += [s_] * t_
+        ctx += [p_ + i + 1 for i in range(t_)]
+    ctx[160] = 0  # a row that attends to nothing
+    n = len(slot)
+    assert n >= 256
+    q = torch.empty(n, nh, hd).normal_(0, 1, generator=g)
+    args = (q.to(dev), kc.to(dev), vc.to(dev), bt.to(dev), torch.tensor(ctx, dtype=torch.int32, device=dev))
+    kw = dict(slot_ids=torch.tensor(slot, dtype=torch.int32, device=dev))
+    out = ops.paged_attn(*args, **kw).cpu()
+    ops.call("i64h_set_prefill_attn", 0)
+    try:
+        base = ops.paged_attn(*args, **kw).cpu()
+    finally:
+        ops.call("i64h_set_prefill_attn", 1)
+    assert (out - base).abs().max() <= tol
+    assert torch.equal(out[160], torch.zeros_like(out[160]))
+    kcf, vcf = kc.float(), vc.float()
+    for i in list(range(0, n, 13)) + [149, 150, 151, 227, 228, n - 1]:
+        s_, c_ = slot[i], ctx[i]
+        if c_ == 0:
+            continue
+        nb = (c_ + 15) // 16
+        kf = kcf[bt[s_, :nb].long()].reshape(-1, kvh, hd)[:c_]
+        vf = vcf[bt[s_, :nb].long()].reshape(-1, kvh, hd)[:c_]
+        ref = M.cached_attention(q[i:i + 1], kf, vf, nh // kvh, torch.tensor([c_ - 1]), 1.0 / hd ** 0.5)[0]
+        torch.testing.assert_close(out[i], ref, rtol=1e-5, atol=tol)
+
+
 def test_varlen_prefill_attention_golden(dev, golden_dir):
     """naive_varlen_attention fixture through qk-less cache writes: K/V placed in the paged cache, causal rows."""
     ops = _ops()

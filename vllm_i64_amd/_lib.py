@@ -44,6 +44,7 @@ SIGNATURES: Dict[str, str] = {
     "i64h_advance": "pplp",
     "i64h_paged_attn": "pppipippfppliiiiipip",
     "i64h_paged_attn_workspace_init": "pp",
+    "i64h_set_prefill_attn": "i",
     "i64h_gemm_i8_pair": "ppp",
     "i64h_moe_forward": "pplppplp",
     "i64h_set_skinny_waves": "i",

@@ -16,6 +16,7 @@
 
 // 8 consecutive cache elements of one token: raw registers (issued early) and their fp32 view (converted late)
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 template <typename KV> struct Raw8;
 template <> struct Raw8<float> {
@@ -191,6 +192,169 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(const float* __restrict
                 part_ml[(head * splits + sp) * 2] = mm;
                 part_ml[(head * splits + sp) * 2 + 1] = lt;
             }
+        }
+    }
+}
+
+// ---- prefill form: 16 query rows x all q heads of one kv head per workgroup, flash attention on the f32 matrix cores ----
+// One wave per q head of the GQA group; the waves share the K/V tile (64 tokens of the kv head, converted to fp32) in LDS.
+// Both products are formed transposed so that everything a lane needs stays in that lane:
+//   S^T[token][qrow] = K . Q^T   (A = K rows from LDS, B = Q from registers):  lane (g = l >> 4, c = l & 15) ends up with
+//                                 the scores of query row c for tokens 4g..4g+3 of each 16-token tile;
+//   O^T[dim][qrow]  += V^T . P^T  (A = V^T from LDS, B = P = exactly those score registers, no shuffle):  lane (g, c) ends
+//                                 up with output dims 16g..16g+15 of query row c.
+// so the online-softmax state (m, l, alpha) of query row c lives in the four lanes with l & 15 == c; only the running max
+// crosses lanes (two shuffles per 64 tokens).  v_mfma_f32_16x16x4_f32 sums k = lane >> 4, which lets K's dims and V's dims
+// be assigned to (g, step) so that each lane reads contiguous 16-byte pieces of a token row.
+// Rows are (slot, ctx) pairs like everywhere else; a tile whose rows belong to several sequences is handled in one pass per
+// distinct sequence.  fp32 math throughout (the cache may be bf16 / fp16 / fp32).
+#define PF_TOK 64            // tokens per K/V tile
+#define PF_LDK (64 + 4)      // LDS row stride in floats
+template <int GS, typename KV>
+__global__ __launch_bounds__(GS * 64) void paged_attn_prefill_kernel(const float* __restrict__ q, const KV* __restrict__ k_cache,
+                                                                     const KV* __restrict__ v_cache, const int32_t* __restrict__ block_table,
+                                                                     int max_blocks_per_seq, const int32_t* __restrict__ slot_ids,
+                                                                     const int32_t* __restrict__ ctx_len, float scale, float* __restrict__ out,
+                                                                     int n, int kvh, int block) {
+    constexpr int HD = 64, NT = GS * 64, CPT = (PF_TOK * 8 + NT - 1) / NT;  // 8-element chunks per thread and tensor
+    constexpr float LOG2E = 1.4426950408889634f;
+    __shared__ __attribute__((aligned(16))) float Ks[PF_TOK][PF_LDK];
+    __shared__ __attribute__((aligned(16))) float Vs[PF_TOK][PF_LDK];
+    __shared__ int s_ok[PF_TOK];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int kh = blockIdx.y, head = kh * GS + wid, nh = kvh * GS;
+    const int r = blockIdx.x * 16 + c;            // this lane's query row
+    const bool valid = r < n;
+    const int my_slot = valid ? (slot_ids ? slot_ids[r] : r) : -1;
+    const int my_ctx = valid ? ctx_len[r] : 0;
+    bool done = !valid;
+
+    // Q^T operand: dims 16g..16g+15 of query row c, pre-multiplied by scale * log2(e) (scores live in log2 units)
+    float qv[16];
+    {
+        const float* qp = q + ((int64_t)(valid ? r : 0) * nh + head) * HD + g * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 a = valid ? *(const float4*)(qp + 4 * i) : make_float4(0, 0, 0, 0);
+            qv[4 * i] = a.x * scale * LOG2E; qv[4 * i + 1] = a.y * scale * LOG2E;
+            qv[4 * i + 2] = a.z * scale * LOG2E; qv[4 * i + 3] = a.w * scale * LOG2E;
+        }
+    }
+
+    while (true) {
+        // rows of one sequence per pass: the first unfinished row picks the sequence
+        const unsigned long long pending = __ballot(!done) & 0xffffull;
+        if (!pending) break;
+        const int lead = __ffsll(pending) - 1;
+        const int cur_slot = __shfl(my_slot, lead);
+        const bool active = !done && my_slot == cur_slot;
+        const int lim = active ? my_ctx : 0;      // causal limit of this lane's query row
+        int kv_end = lim;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) kv_end = max(kv_end, __shfl_xor(kv_end, o));
+        kv_end = __shfl(kv_end, 0);
+        const int32_t* bt = block_table + (int64_t)cur_slot * max_blocks_per_seq;
+
+        float m = -INFINITY, lsum = 0.0f;
+        v4f acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = (v4f){0, 0, 0, 0};
+
+        Raw8<KV> rk[CPT], rv[CPT];
+        int rok[CPT];
+        auto gload = [&](int t0) {
+#pragma unroll
+            for (int u = 0; u < CPT; ++u) {
+                const int ci = tid + u * NT;
+                const int t = t0 + (ci >> 3), ch = ci & 7;
+                const int tc = max(0, min(t, kv_end - 1));
+                const int pb = bt[tc / block];
+                rok[u] = (t < kv_end && pb >= 0) ? 1 : 0;
+                const int64_t off = (((int64_t)max(pb, 0) * block + (tc % block)) * kvh + kh) * HD + ch * 8;
+                rk[u].load(k_cache + off);
+                rv[u].load(v_cache + off);
+            }
+        };
+        if (kv_end > 0) gload(0);
+        for (int t0 = 0; t0 < kv_end; t0 += PF_TOK) {
+            __syncthreads();  // every wave is done with the previous tile
+#pragma unroll
+            for (int u = 0; u < CPT; ++u) {
+                const int ci = tid + u * NT;
+                if (ci < PF_TOK * 8) {
+                    const int tt = ci >> 3, ch = ci & 7;
+                    float kf[8], vf[8];
+                    rk[u].get(kf);
+                    rv[u].get(vf);
+                    *(float4*)&Ks[tt][ch * 8] = make_float4(kf[0], kf[1], kf[2], kf[3]);
+                    *(float4*)&Ks[tt][ch * 8 + 4] = make_float4(kf[4], kf[5], kf[6], kf[7]);
+                    *(float4*)&Vs[tt][ch * 8] = make_float4(vf[0], vf[1], vf[2], vf[3]);
+                    *(float4*)&Vs[tt][ch * 8 + 4] = make_float4(vf[4], vf[5], vf[6], vf[7]);
+                    if (ch == 0) s_ok[tt] = rok[u];
+                }
+            }
+            __syncthreads();
+            if (t0 + PF_TOK < kv_end) gload(t0 + PF_TOK);  // next tile in flight behind the math of this one
+
+            // scores of 64 tokens: S^T tile t holds tokens t0 + 16t + 4g + reg of query row c
+            v4f sc[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                sc[t] = (v4f){0, 0, 0, 0};
+                const float* kp = &Ks[16 * t + c][g * 16];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float4 kq = *(const float4*)(kp + 4 * i);
+                    sc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kq.x, qv[4 * i], sc[t], 0, 0, 0);
+                    sc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kq.y, qv[4 * i + 1], sc[t], 0, 0, 0);
+                    sc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kq.z, qv[4 * i + 2], sc[t], 0, 0, 0);
+                    sc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kq.w, qv[4 * i + 3], sc[t], 0, 0, 0);
+                }
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int tt = 16 * t + 4 * g + e;
+                    const bool live = (t0 + tt < lim) && s_ok[tt];
+                    sc[t][e] = live ? sc[t][e] : -INFINITY;
+                    mx = fmaxf(mx, sc[t][e]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mn = fmaxf(m, mx);
+            const float alpha = (mn == -INFINITY) ? 1.0f : exp2f(m - mn);
+            m = mn;
+            lsum *= alpha;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] *= alpha;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pv = (sc[t][e] == -INFINITY) ? 0.0f : exp2f(sc[t][e] - mn);
+                    lsum += pv;
+                    const float4 vq = *(const float4*)&Vs[16 * t + 4 * g + e][c * 4];
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vq.x, pv, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(vq.y, pv, acc[1], 0, 0, 0);
+                    acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(vq.z, pv, acc[2], 0, 0, 0);
+                    acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(vq.w, pv, acc[3], 0, 0, 0);
+                }
+        }
+        // acc[j][e] = O^T[dim = 16g + 4e + j][query row c]; the row's normaliser is spread over its four lanes
+        lsum += __shfl_xor(lsum, 16);
+        lsum += __shfl_xor(lsum, 32);
+        if (active) {
+            float* op = out + ((int64_t)r * nh + head) * HD + g * 16;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float4 o = make_float4(0, 0, 0, 0);
+                if (lsum > 0.0f) o = make_float4(acc[0][e] / lsum, acc[1][e] / lsum, acc[2][e] / lsum, acc[3][e] / lsum);
+                *(float4*)(op + 4 * e) = o;
+            }
+            done = true;
         }
     }
 }
@@ -471,6 +635,8 @@ static int dispatch_gs(int gs, int kv_dtype, const float* q, const void* kc, con
     return 1;
 }
 
+#define PF_MIN_ROWS 256      // from this many rows on, the 16-row-tile matrix-core kernel is used (splits == 1, head_dim 64)
+static int g_prefill_mfma = 1;  // tuning / test knob: 0 = always the row-per-workgroup kernel
 #define ATTN_ARRIVALS 4096  // rows whose splits can be merged by the last-arriving workgroup
 
 extern "C" {
@@ -480,6 +646,11 @@ extern "C" {
 // (i64h_paged_attn_workspace_init); every launch leaves them zero.
 int64_t i64h_paged_attn_workspace_floats(int64_t rows, int32_t num_heads, int32_t head_dim, int32_t splits) {
     return splits > 1 ? ATTN_ARRIVALS + rows * num_heads * splits * (int64_t)(head_dim + 2) : 0;
+}
+
+int i64h_set_prefill_attn(int32_t on) {
+    g_prefill_mfma = on ? 1 : 0;
+    return 0;
 }
 
 int i64h_paged_attn_workspace_init(float* workspace, void* stream) {
@@ -507,6 +678,27 @@ int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, in
     float* part_o = workspace ? workspace + ATTN_ARRIVALS : nullptr;
     float* part_ml = workspace ? part_o + rows * num_heads * splits * (int64_t)head_dim : nullptr;
     int rc = 1;
+    // prefill form (many rows): 16-row tiles on the f32 matrix cores
+    if (splits == 1 && head_dim == 64 && rows >= PF_MIN_ROWS && g_prefill_mfma && (gs == 1 || gs == 2 || gs == 4 || gs == 8)) {
+        dim3 grid((unsigned)((rows + 15) / 16), (unsigned)num_kv_heads);
+#define PF(G, T)                                                                                                                     \
+    hipLaunchKernelGGL((paged_attn_prefill_kernel<G, T>), grid, dim3(G * 64), 0, st, q, (const T*)k_cache, (const T*)v_cache, block_table, \
+                       (int)max_blocks_per_seq, slot_ids, ctx_len, softmax_scale, out, (int)rows, (int)num_kv_heads, (int)block_size)
+#define PFG(G)                                                  \
+    do {                                                        \
+        if (kv_dtype == 0) PF(G, float);                        \
+        else if (kv_dtype == 1) PF(G, __half);                  \
+        else PF(G, __hip_bfloat16);                             \
+    } while (0)
+        if (gs == 1) PFG(1);
+        else if (gs == 2) PFG(2);
+        else if (gs == 4) PFG(4);
+        else PFG(8);
+#undef PFG
+#undef PF
+        I64H_CHECK_LAUNCH();
+        return 0;
+    }
     // decode form (few rows, long contexts): all kv heads per workgroup, fully coalesced token rows
     bool done = false;
 #define AH(HD_, KVH_, GS_)                                                                                                          \
