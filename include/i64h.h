@@ -118,8 +118,13 @@ typedef struct i64h_gemm_desc {
     int32_t out_slot_base;
     uint32_t* stats;
     int32_t want_stats;
+    const float* col_scale;       /* epilogue 0, int8 operand, optional: per-output-channel scale [G][N] replacing w_scale[g] */
 } i64h_gemm_desc;
 int i64h_gemm_i8_pair(const i64h_gemm_desc* a, const i64h_gemm_desc* b, void* stream);
+/* Per-token x per-output-channel rescale, C[r, c] = float(acc) * (row_scale[r] * col_scale[c]): the torch._int_mm branch of
+ * int8_linear_native / int8_fused_gate_up_native (vllm_i64/core/quantization.py:119-176, 219-286). */
+int i64h_gemm_i8_colscale(const int8_t* A, const float* row_scale, const int8_t* B, const float* col_scale, int64_t M, int32_t N, int32_t K,
+                          float* C, void* stream);
 int i64h_set_pipe_gemm(int32_t on); /* tuning knob: 0 = 128-byte LDS stages for every prefill-sized problem (default 1: 64-byte stages, four workgroups per CU, when K <= 2048) */
 int i64h_debug_set_stamps(void* buffer, int64_t capacity_workgroups); /* diagnostics: 8 uint64 per workgroup of s_memtime phase stamps from the decode-sized kernel, launches appended; NULL = off */
 int i64h_set_skinny_waves(int32_t waves); /* tuning knob of the decode-sized (weight-streaming) kernel: 4, 8, 16 or 0 = default */

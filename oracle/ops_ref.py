@@ -130,3 +130,16 @@ def int8_linear_pertoken(x: torch.Tensor, w_q: torch.Tensor, w_scale: torch.Tens
     xq, xs = quantize_int8(x)
     acc = (xq.double() @ w_q.double().t()).to(torch.int64).to(torch.int32)
     return acc.float() * (xs.unsqueeze(1) * w_scale.float().unsqueeze(0))
+
+
+# ---- weight-only int8 expert MLP (kernels/fused_experts.py:153-291; per-INPUT-channel scales) ----
+def fused_token_routed_forward_int8(x, gate_up_int8, gate_up_scale, down_int8, down_scale, expert_ids, num_experts, inter):
+    out = torch.zeros(x.shape[0], down_int8.shape[2])
+    for e in range(num_experts):
+        m = expert_ids == e
+        if not bool(m.any()):
+            continue
+        gu = x[m].float() @ (gate_up_int8[e].float() * gate_up_scale[e].float().unsqueeze(-1))
+        t = F.silu(gu[:, :inter]) * gu[:, inter:]
+        out[m] = t @ (down_int8[e].float() * down_scale[e].float().unsqueeze(-1))
+    return out

@@ -38,7 +38,9 @@ from vllm_i64.layers.moe import softmax_integer  # noqa: E402
 from vllm_i64.layers.integer_activations import silu_multiply_integer  # noqa: E402
 from vllm_i64.layers.rotary import RotaryEmbedding, apply_rotary, apply_rotary_integer  # noqa: E402
 from vllm_i64.layers.rmsnorm import RMSNorm  # noqa: E402
-from vllm_i64.core.quantization import quantize_int8, quantize_activations_int8  # noqa: E402
+from vllm_i64.core.quantization import (quantize_int8, quantize_activations_int8, int8_linear_native,  # noqa: E402
+                                        int8_fused_gate_up_native)
+from vllm_i64.kernels.fused_experts import fused_token_routed_forward_int8  # noqa: E402
 from vllm_i64.layers.attention import naive_paged_decode_attention, naive_varlen_attention  # noqa: E402
 
 
@@ -276,6 +278,31 @@ def gen_ops():
     vv = torch.empty(29, 2, 16).normal_(0, 1, generator=g)
     store.update(vl_q=qv.numpy(), vl_k=kv_.numpy(), vl_v=vv.numpy(), vl_tps=np.array([17, 1, 11]),
                  vl_out=naive_varlen_attention(qv, kv_, vv, [17, 1, 11], 2).numpy())
+    # per-token int8 operator path (core/quantization.py:119-286; on this host the reference takes its torch._int_mm branch)
+    # and the weight-only int8 expert MLP (kernels/fused_experts.py:153-291, both of its modes); own generator so that the
+    # fixtures above keep their values
+    g2 = torch.Generator().manual_seed(43)
+    xl = torch.empty(37, 96).normal_(0, 1, generator=g2)
+    wl = torch.empty(40, 96).normal_(0, 0.05, generator=g2)
+    wlq, wls = quantize_int8(wl)
+    bias = torch.empty(40).normal_(0, 0.1, generator=g2)
+    yl = int8_linear_native(xl, wlq, wls, bias)
+    gate, up = int8_fused_gate_up_native(xl, wlq, wls, 20)
+    assert torch.equal(O.int8_linear_pertoken(xl, wlq, wls) + bias, yl)
+    store.update(iln_x=xl.numpy(), iln_wq=wlq.numpy(), iln_ws=wls.numpy(), iln_bias=bias.numpy(), iln_y=yl.numpy(),
+                 iln_gate=gate.numpy(), iln_up=up.numpy())
+    E, H, I = 4, 64, 48
+    gu8 = torch.randint(-127, 128, (E, H, 2 * I), generator=g2).to(torch.int8)
+    gus = torch.empty(E, H).uniform_(0.0005, 0.002, generator=g2)
+    dn8 = torch.randint(-127, 128, (E, I, H), generator=g2).to(torch.int8)
+    dns = torch.empty(E, I).uniform_(0.0005, 0.002, generator=g2)
+    for n in (9, 130):   # bmm mode (N <= 64) and chunked mode
+        xe = torch.empty(n, H).normal_(0, 1, generator=g2)
+        eid = torch.randint(0, E, (n,), generator=g2)
+        ye = fused_token_routed_forward_int8(xe, gu8, gus, dn8, dns, eid, E, I)
+        assert torch.allclose(O.fused_token_routed_forward_int8(xe, gu8, gus, dn8, dns, eid, E, I), ye, rtol=1e-4, atol=1e-5)
+        store.update({f"fe8_x{n}": xe.numpy(), f"fe8_eid{n}": eid.numpy(), f"fe8_y{n}": ye.numpy()})
+    store.update(fe8_gu=gu8.numpy(), fe8_gus=gus.numpy(), fe8_dn=dn8.numpy(), fe8_dns=dns.numpy())
     np.savez_compressed(os.path.join(HERE, "ops.npz"), **store)
     print("ops fixtures written")
 

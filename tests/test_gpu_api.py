@@ -198,3 +198,28 @@ def test_expert_parallel_layer_hip_backend_single_rank(dev):
         ref = M.moe_forward(ocfg, bank, 1, x, ids).numpy()
         y = layer(x.to(dev), ids.to(dev)).cpu().numpy()
         assert np.abs(y - ref).max() <= 1e-2 and np.abs(y - ref).mean() <= 1e-5, (n, np.abs(y - ref).max())
+
+
+def test_pertoken_int8_operator_path_golden(dev, golden_dir):
+    """int8_linear_native / int8_fused_gate_up_native on the int8 matrix cores: bit-exact against the reference's
+    torch._int_mm branch; fused_token_routed_forward_int8 (weight-only int8 experts) within fp32 reassociation."""
+    from vllm_i64_amd import kernels as K
+    z = np.load(os.path.join(golden_dir, "ops.npz"))
+    d = lambda k: torch.from_numpy(z[k]).to(dev)
+    y = K.int8_linear_native(d("iln_x"), d("iln_wq"), d("iln_ws"), d("iln_bias"))
+    assert np.array_equal(y.cpu().numpy(), z["iln_y"])
+    y3 = K.int8_linear_native(d("iln_x").view(1, 37, 96), d("iln_wq"), d("iln_ws"))
+    assert y3.shape == (1, 37, 40)
+    gate, up = K.int8_fused_gate_up_native(d("iln_x"), d("iln_wq"), d("iln_ws"), 20)
+    assert np.array_equal(gate.cpu().numpy(), z["iln_gate"]) and np.array_equal(up.cpu().numpy(), z["iln_up"])
+    xq, xs = K.quantize_activations_int8(d("iln_x"))
+    gate2, _ = K.int8_fused_gate_up_native(d("iln_x"), d("iln_wq"), d("iln_ws"), 20, x_preq=(xq, xs))
+    assert torch.equal(gate2, gate)
+    # a prefill-sized call goes through the 128 x 128 tiles
+    g = torch.Generator().manual_seed(9)
+    xb = torch.randn(700, 96, generator=g)
+    ref = O.int8_linear_pertoken(xb, torch.from_numpy(z["iln_wq"]), torch.from_numpy(z["iln_ws"]))
+    assert torch.equal(K.int8_linear_native(xb.to(dev), d("iln_wq"), d("iln_ws")).cpu(), ref)
+    for n in (9, 130):
+        out = K.fused_token_routed_forward_int8(d(f"fe8_x{n}"), d("fe8_gu"), d("fe8_gus"), d("fe8_dn"), d("fe8_dns"), d(f"fe8_eid{n}").long(), 4, 48)
+        assert np.allclose(out.cpu().numpy(), z[f"fe8_y{n}"], rtol=1e-4, atol=1e-5)

@@ -169,3 +169,17 @@ def test_bucketize_is_stable_and_complete():
         rows = perm[int(offsets[b]):int(offsets[b + 1])].long()
         assert torch.all(key[rows] == b)
         assert torch.all(rows[1:] > rows[:-1])  # token order preserved inside a bucket
+
+
+def test_oracle_pertoken_int8_ops_match_reference_fixtures(golden_dir):
+    """int8_linear_native / int8_fused_gate_up_native (torch._int_mm branch) and fused_token_routed_forward_int8 fixtures."""
+    import torch
+    from oracle import ops_ref as O
+    z = np.load(os.path.join(golden_dir, "ops.npz"))
+    t = lambda k: torch.from_numpy(z[k])
+    y = O.int8_linear_pertoken(t("iln_x"), t("iln_wq"), t("iln_ws"))
+    assert np.array_equal((y + t("iln_bias")).numpy(), z["iln_y"])
+    assert np.array_equal(y[:, :20].numpy(), z["iln_gate"]) and np.array_equal(y[:, 20:].numpy(), z["iln_up"])
+    for n in (9, 130):
+        out = O.fused_token_routed_forward_int8(t(f"fe8_x{n}"), t("fe8_gu"), t("fe8_gus"), t("fe8_dn"), t("fe8_dns"), t(f"fe8_eid{n}"), 4, 48)
+        assert np.allclose(out.numpy(), z[f"fe8_y{n}"], rtol=1e-4, atol=1e-5)

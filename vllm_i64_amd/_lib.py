@@ -46,6 +46,7 @@ SIGNATURES: Dict[str, str] = {
     "i64h_paged_attn_workspace_init": "pp",
     "i64h_set_prefill_attn": "i",
     "i64h_gemm_i8_pair": "ppp",
+    "i64h_gemm_i8_colscale": "ppppliipp",
     "i64h_moe_forward": "pplppplp",
     "i64h_set_skinny_waves": "i",
     "i64h_debug_set_stamps": "pl",
@@ -70,7 +71,7 @@ class GemmDesc(ctypes.Structure):
     _fields_ = [("A", _P), ("a_fp32", _I), ("a_src_row", _P), ("a_src_mod", _I), ("row_scale", _P), ("a_row_slot", _P),
                 ("a_slot_base", _I), ("B", _P), ("w_scale", _P), ("group_offsets", _P), ("num_groups", _I), ("M_total", _L),
                 ("N", _I), ("K", _I), ("C", _P), ("epilogue", _I), ("out_row_slot", _P), ("out_slot_base", _I), ("stats", _P),
-                ("want_stats", _I)]
+                ("want_stats", _I), ("col_scale", _P)]
 
 
 class MoeLayer(ctypes.Structure):

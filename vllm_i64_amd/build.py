@@ -20,7 +20,8 @@ def _stale(obj: str, src: str) -> bool:
     if not os.path.exists(obj):
         return True
     t = os.path.getmtime(obj)
-    deps = [src, os.path.join(CSRC, "i64h_common.h"), os.path.abspath(__file__)]
+    # every object depends on both headers: the public one carries structs that cross translation units
+    deps = [src, os.path.join(CSRC, "i64h_common.h"), os.path.join(os.path.dirname(HERE), "include", "i64h.h"), os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -37,6 +37,7 @@ struct GemmI8Args {
     int a_slot_base;
     const int8_t* B;           // [G][N][K]
     const float* w_scale;      // [G]
+    const float* col_scale;    // EPI_STORE, optional: per-output-channel scale [G][N] used instead of w_scale[g]
     const int32_t* group_off;  // [G+1] device, or nullptr => one group [0, M_total)
     int G, M_total, N, K;
     float* C;                  // EPI_STORE: [M_total, N]; EPI_SWIGLU: [M_total, N/2]
@@ -290,7 +291,9 @@ __device__ __forceinline__ void gemm_i8_body(const GemmI8Args& p, const int bid,
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
                     const int c = nt * BN + wn * WN + j * 16 + fr;
-                    if (c < p.N) p.C[(int64_t)(row0 + r) * p.N + c] = (float)acc[i][j][reg] * m;
+                    if (c < p.N)
+                        p.C[(int64_t)(row0 + r) * p.N + c] =
+                            (float)acc[i][j][reg] * (p.col_scale ? q_scale[r] * p.col_scale[(int64_t)g * p.N + c] : m);
                 }
             }
     } else {
@@ -767,6 +770,7 @@ struct i64h_gemm_desc {
     int32_t out_slot_base;
     uint32_t* stats;
     int32_t want_stats;
+    const float* col_scale;
 };
 
 static int check_desc(const i64h_gemm_desc* d, const char* who) {
@@ -790,6 +794,7 @@ static GemmI8Args to_args(const i64h_gemm_desc* d) {
     p.M_total = (int)d->M_total; p.N = d->N; p.K = d->K; p.C = d->C; p.out_row_slot = d->out_row_slot; p.out_slot_base = d->out_slot_base;
     p.stats = d->stats; p.want_stats = d->want_stats;
     p.stamps = nullptr;
+    p.col_scale = d->col_scale;
     return p;
 }
 
@@ -920,6 +925,19 @@ int i64h_gemm_i8(const int8_t* A, const float* row_scale, const int8_t* B, const
     d.A = A; d.row_scale = row_scale; d.B = B; d.w_scale = w_scale; d.group_offsets = group_offsets; d.num_groups = num_groups;
     d.M_total = M_total; d.N = N; d.K = K; d.C = C; d.epilogue = epilogue; d.out_row_slot = row_slot; d.out_slot_base = slot_base;
     d.stats = stats; d.want_stats = stats != nullptr && epilogue == EPI_SWIGLU;
+    return i64h_gemm_i8_pair(&d, nullptr, stream);
+}
+
+// Per-token x per-output-channel rescale: C[r, c] = float(sum_k A[r,k] * B[c,k]) * (row_scale[r] * col_scale[c])
+int i64h_gemm_i8_colscale(const int8_t* A, const float* row_scale, const int8_t* B, const float* col_scale, int64_t M, int32_t N, int32_t K,
+                          float* C, void* stream) {
+    i64h_gemm_desc d;
+    memset(&d, 0, sizeof(d));
+    d.A = A; d.row_scale = row_scale; d.B = B; d.w_scale = col_scale; d.num_groups = 1; d.M_total = M; d.N = N; d.K = K; d.C = C;
+    if (int rc = check_desc(&d, "gemm_i8_colscale")) return rc;
+    I64H_CHECK_ARG(col_scale != nullptr, "gemm_i8_colscale: null column scale");
+    if (M == 0) return 0;
+    d.col_scale = col_scale;
     return i64h_gemm_i8_pair(&d, nullptr, stream);
 }
 

@@ -174,3 +174,61 @@ def fused_token_routed_forward(x: torch.Tensor, gate_up_proj: torch.Tensor, down
         inter = ops.silu_mul(gu, intermediate_per_tp)
         out_sorted[s:t] = ops.gemm_f32(inter, _f32(down_proj[e].t()))
     return ops.gather_rows(out_sorted, inv).to(x.dtype)
+
+
+# ---- per-token int8 operator path (vllm_i64/core/quantization.py:103-286, the torch._int_mm branch) -----------------------
+def quantize_activations_int8(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Per-token symmetric int8: s = max(amax|x|, 1e-8) / 127, q = clamp(rint(x / s), -128, 127) (quantization.py:103-116)."""
+    return ops.quant_rows(_f32(x.reshape(-1, x.shape[-1])))
+
+
+def int8_linear_native(x: torch.Tensor, weight_int8: torch.Tensor, weight_scale: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                       x_preq: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> torch.Tensor:
+    """y = x @ W^T with per-token int8 activations and per-output-channel int8 weights on the int8 matrix cores:
+    acc_i32 * (x_scale[m] * w_scale[n]) (+ bias) (quantization.py:119-176)."""
+    shape = x.shape
+    x2 = x.reshape(-1, shape[-1])
+    xq, xs = x_preq if x_preq is not None else quantize_activations_int8(x2)
+    N, K = weight_int8.shape
+    out = torch.empty(x2.shape[0], N, dtype=torch.float32, device=x.device)
+    ops.call("i64h_gemm_i8_colscale", ops.ptr(xq.contiguous()), ops.ptr(_f32(xs)), ops.ptr(weight_int8.contiguous()), ops.ptr(_f32(weight_scale)),
+             x2.shape[0], N, K, ops.ptr(out), ops._stream())
+    if bias is not None:
+        out = out + bias
+    return out.reshape(*shape[:-1], N)
+
+
+def int8_fused_gate_up_native(x: torch.Tensor, fused_int8: torch.Tensor, fused_scale: torch.Tensor, inter_size: int,
+                              x_preq: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """One activation quantization + one int8 GEMM over cat([gate, up]) rows, split at inter_size (quantization.py:219-286)."""
+    out = int8_linear_native(x, fused_int8, fused_scale, None, x_preq)
+    gate, up = out.split(inter_size, dim=-1)
+    return gate, up
+
+
+def fused_token_routed_forward_int8(x: torch.Tensor, gate_up_int8: torch.Tensor, gate_up_scale: torch.Tensor, down_int8: torch.Tensor,
+                                    down_scale: torch.Tensor, expert_ids: torch.Tensor, num_experts: int, intermediate_per_tp: int,
+                                    bmm_threshold: int = 64) -> torch.Tensor:
+    """Weight-only int8 expert MLP (fused_experts.py:153-291): gate_up_int8 [E, H, 2I] with scale [E, H] per INPUT channel,
+    down_int8 [E, I, H] with scale [E, I]; fp32 activations.  x @ (W * s[:, None]) is evaluated as (x * s) @ W: the scaled
+    rows go through the fp32-activation x int8-weight kernel with unit output scales.  Grouping as in the float variant
+    (one host read of the per-expert offsets, like the reference's chunked mode)."""
+    n = x.shape[0]
+    if n == 0:
+        return x
+    xf = _f32(x)
+    E, H, I2 = gate_up_int8.shape
+    offsets, perm, inv, _ = ops.bucketize(expert_ids.to(torch.int32).contiguous(), num_experts)
+    xs = ops.gather_rows(xf, perm)
+    off = offsets.tolist()
+    out_sorted = torch.empty(n, down_int8.shape[2], dtype=torch.float32, device=x.device)
+    ones_gu = torch.ones(I2, dtype=torch.float32, device=x.device)
+    ones_dn = torch.ones(down_int8.shape[2], dtype=torch.float32, device=x.device)
+    for e in range(num_experts):
+        s, t = off[e], off[e + 1]
+        if s == t:
+            continue
+        gu = ops.gemm_w8a32((xs[s:t] * _f32(gate_up_scale[e])).contiguous(), gate_up_int8[e].t().contiguous(), ones_gu)
+        inter = ops.silu_mul(gu, intermediate_per_tp)
+        out_sorted[s:t] = ops.gemm_w8a32((inter * _f32(down_scale[e])).contiguous(), down_int8[e].t().contiguous(), ones_dn)
+    return ops.gather_rows(out_sorted, inv).to(x.dtype)
