@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=32)
     ap.add_argument("--cpu-ctx", type=int, default=128)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--parallelism", default="dp", choices=["dp", "ep"],
+                    help="dp: every rank is an independent replica (default; no data-path collective).  ep: the routed experts are "
+                         "sharded over the ranks, one all-to-all each way per MoE layer (RCCL); runs without the HIP graph")
     return ap.parse_args()
 
 
@@ -110,9 +113,10 @@ def main():
     assert P + args.steps + args.warmup + 2 <= cfg.max_pos, "prompt + decode steps exceed max_pos"
     t0 = time.time()
     weights = synth.make_weights(cfg, seed=0)
-    model = I64MoEModel(cfg, weights, device=dev, kv_dtype=kv_dtype, max_seqs=B)
+    ep_mode = args.parallelism == "ep"
+    model = I64MoEModel(cfg, weights, device=dev, kv_dtype=kv_dtype, max_seqs=B, expert_parallel=ep_mode)
     t_setup = time.time() - t0
-    dec = GreedyDecoder(model, B, use_graph=not args.no_graph)
+    dec = GreedyDecoder(model, B, use_graph=not (args.no_graph or ep_mode))
     total_len = P + args.steps + args.warmup + 2
 
     # ---- prefill (untimed for the headline; its own rate is reported) ----
@@ -240,8 +244,9 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{cfg.name} int8 dynamic-Linear forward, batch {B} per GPU, {P}-token prompts"
                                f"{' (synthetic KV)' if args.synthetic_kv else ' (real prefill)'} + greedy decode, KV cache {args.kv_dtype}",
-                   "global_batch": B * world, "seq_len": P, "parallelism": f"dp{world} (independent replicas, no collective)" if world > 1 else "single GPU",
-                   "kv_dtype": args.kv_dtype, "hip_graph": not args.no_graph},
+                   "global_batch": B * world, "seq_len": P, "parallelism": (f"ep{world} (experts sharded, all-to-all each way per MoE layer)" if ep_mode else
+                                   f"dp{world} (independent replicas, no collective)" if world > 1 else "single GPU"),
+                   "kv_dtype": args.kv_dtype, "hip_graph": not (args.no_graph or ep_mode)},
         "roofline": roofline,
         "roofline_mfma": mfma,
     }

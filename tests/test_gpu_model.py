@@ -154,3 +154,30 @@ def test_graph_decode_matches_eager(dev):
             seq.append(dec.step().clone())
         outs.append((torch.stack(seq).cpu(), dec.tokens.cpu().clone(), dec.positions.cpu().clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+
+
+def test_expert_parallel_model_equals_plain_model_at_one_rank(dev):
+    """The expert-parallel runner (MoE layers through vllm_i64_amd.ep on the HIP backend) at world size 1: same logits as
+    the plain runner on a prefill step and a decode step."""
+    from vllm_i64_amd.config import ModelConfig
+    from vllm_i64_amd.model import I64MoEModel
+    ocfg = M.named_config("tiny-moe")
+    cfg = ModelConfig.from_any(ocfg)
+    w = M.make_weights(ocfg, seed=0)
+    ids = M.make_token_ids(ocfg, 21, seed=7)
+    outs = []
+    for ep_on in (False, True):
+        model = I64MoEModel(cfg, w, device=dev, max_seqs=2, expert_parallel=ep_on)
+        for s in range(2):
+            model.kv.reserve(s, 16)
+        tok = ids[:20].to(dev)
+        pos = torch.cat([torch.arange(12), torch.arange(8)]).to(torch.int32).to(dev)
+        slots = torch.cat([torch.zeros(12), torch.ones(8)]).to(torch.int32).to(dev)
+        lg1 = model.forward(tok, pos, slots, (pos + 1).contiguous()).clone()
+        tok2 = ids[19:21].to(dev)
+        pos2 = torch.tensor([12, 8], dtype=torch.int32, device=dev)
+        lg2 = model.forward(tok2, pos2, torch.tensor([0, 1], dtype=torch.int32, device=dev), (pos2 + 1).contiguous()).clone()
+        outs.append((lg1.cpu(), lg2.cpu()))
+    for a, b in zip(outs[0], outs[1]):
+        assert (a - b).abs().max() <= 1e-5, (a - b).abs().max()
+        assert torch.equal(a.argmax(-1), b.argmax(-1))

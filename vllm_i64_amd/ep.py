@@ -96,6 +96,53 @@ def build_plan(ids_all: torch.Tensor, table: torch.Tensor, rank_sizes: Sequence[
                         expert_offsets=expert_offsets.to(i32), routes=routes)
 
 
+def build_plans(ids_all: torch.Tensor, tables: torch.Tensor, rank_sizes: Sequence[int], rank: int, num_experts: int) -> List[ExchangePlan]:
+    """Plans of all layers of a step (tables int64 [L, top_k, V]) from ONE gather of the ids and ONE device-to-host transfer
+    (the all-to-all split sizes have to be host integers); everything else stays on the device."""
+    L, top_k, V = tables.shape
+    world = len(rank_sizes)
+    assert num_experts % world == 0, "experts must divide over the ranks"
+    local_e = num_experts // world
+    nbl, nb = local_e * top_k, num_experts * top_k
+    dev = ids_all.device
+    n_all = int(sum(rank_sizes))
+    off = int(sum(rank_sizes[:rank]))
+    n = int(rank_sizes[rank])
+    routes_all = tables[:, :, ids_all.clamp(0, V - 1)]                                          # [L, top_k, N_all]
+    bucket_all = routes_all * top_k + torch.arange(top_k, device=dev, dtype=routes_all.dtype).view(1, top_k, 1)
+    src_rank = torch.repeat_interleave(torch.arange(world, device=dev), torch.tensor(list(rank_sizes), device=dev), output_size=n_all)
+    key = (torch.arange(L, device=dev).view(L, 1, 1) * world + src_rank.view(1, 1, n_all)) * nb + bucket_all
+    counts = torch.zeros(L * world * nb, dtype=torch.int64, device=dev)
+    counts.index_add_(0, key.reshape(-1), torch.ones(key.numel(), dtype=torch.int64, device=dev))
+    counts = counts.view(L, world, nb)
+    counts_h = counts.cpu()                                                                     # the one synchronisation
+    plans = []
+    i32 = torch.int32
+    lb_ids = torch.arange(nbl, device=dev)
+    for l in range(L):
+        routes = routes_all[l][:, off:off + n]
+        bucket = bucket_all[l][:, off:off + n].reshape(-1)
+        perm = torch.sort(bucket, stable=True).indices
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(perm.numel(), device=dev)
+        ch = counts_h[l]
+        per_owner = ch.view(world, world, nbl).sum(dim=2)
+        send_splits = [int(v) for v in per_owner[rank].tolist()]
+        recv_splits = [int(v) for v in per_owner[:, rank].tolist()]
+        mine = counts[l][:, rank * nbl:(rank + 1) * nbl]
+        recv_bucket = torch.cat([torch.repeat_interleave(lb_ids, mine[s_], output_size=recv_splits[s_]) for s_ in range(world)])
+        recv_perm = torch.sort(recv_bucket, stable=True).indices
+        recv_inv = torch.empty_like(recv_perm)
+        recv_inv[recv_perm] = torch.arange(recv_perm.numel(), device=dev)
+        per_expert = mine.sum(dim=0).view(local_e, top_k).sum(dim=1)
+        expert_offsets = torch.zeros(local_e + 1, dtype=torch.int64, device=dev)
+        expert_offsets[1:] = torch.cumsum(per_expert, 0)
+        plans.append(ExchangePlan(n=n, rows=int(perm.numel()), perm=perm.to(i32), inv=inv.to(i32), send_splits=send_splits,
+                                  recv_splits=recv_splits, recv_perm=recv_perm.to(i32), recv_inv=recv_inv.to(i32),
+                                  local_bucket=recv_bucket[recv_perm].to(i32), expert_offsets=expert_offsets.to(i32), routes=routes))
+    return plans
+
+
 # ---------------------------------------------------------------------------------------------------------
 # compute backend on the GPU: libi64hip.so
 # ---------------------------------------------------------------------------------------------------------
@@ -175,8 +222,12 @@ class HipBackend:
 class ExpertParallelMoE:
     """out_local = TokenRoutedMLP(concat of all ranks' x, ids)[local rows], experts sharded over the ranks of `group`."""
 
-    def __init__(self, cfg, table: torch.Tensor, backend, group=None):
+    def __init__(self, cfg, table: torch.Tensor, backend, group=None, shared_global_stats: bool = True):
+        """shared_global_stats: all-reduce the (min, max) of the shared expert's two Linear calls so that the layer equals
+        ONE engine over the concatenated batch; False = every rank quantizes its shared-expert calls over its own tokens
+        (each rank an engine of its own for the dense calls, only the expert buckets pooled)."""
         self.cfg, self.backend, self.group = cfg, backend, group
+        self.shared_global_stats = shared_global_stats
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         assert cfg.num_experts % self.world == 0, "experts must divide over the ranks"
@@ -207,18 +258,23 @@ class ExpertParallelMoE:
 
     def _global_minmax(self, x: torch.Tensor, slot: int):
         v = self.backend.call_minmax(x, slot)
-        if self.world > 1:
+        if self.world > 1 and self.shared_global_stats:
             dist.all_reduce(v, op=dist.ReduceOp.MAX, group=self.group)
             self.backend.set_call_minmax(slot, v)
 
-    def forward(self, x: torch.Tensor, token_ids: torch.Tensor) -> torch.Tensor:
+    def gather_ids(self, token_ids: torch.Tensor):
+        """(ids of all ranks, tokens per rank): gather once per step and hand the plans of all layers to forward()."""
+        return self._gather_ids(token_ids.to(torch.int64).contiguous())
+
+    def forward(self, x: torch.Tensor, token_ids: Optional[torch.Tensor], plan: Optional[ExchangePlan] = None) -> torch.Tensor:
         cfg, be = self.cfg, self.backend
         x = x.float().contiguous()
-        ids = token_ids.to(torch.int64).contiguous()
         n = x.shape[0]
         be.begin()
-        ids_all, sizes = self._gather_ids(ids)
-        plan = build_plan(ids_all, self.table.to(ids.device), sizes, self.rank, cfg.num_experts)
+        if plan is None:
+            ids = token_ids.to(torch.int64).contiguous()
+            ids_all, sizes = self._gather_ids(ids)
+            plan = build_plan(ids_all, self.table.to(ids.device), sizes, self.rank, cfg.num_experts)
         self.last_plan = plan
         # dispatch: rows in bucket order are already in destination order
         src_tok = (plan.perm.to(torch.int64) % max(n, 1)).to(torch.int32)

@@ -134,9 +134,22 @@ class _Buffers:
 
 class I64MoEModel:
     def __init__(self, cfg: ModelConfig, weights: Dict[str, torch.Tensor], device="cuda:0", kv_dtype=torch.float32,
-                 max_seqs: int = 64, num_kv_blocks: Optional[int] = None):
+                 max_seqs: int = 64, num_kv_blocks: Optional[int] = None, expert_parallel: bool = False, ep_group=None):
+        """expert_parallel: the routed experts are sharded over the ranks of ep_group (one process per GPU); every rank keeps
+        its own sequences, attention, dense projections and shared expert (an engine of its own for those calls), and each MoE
+        layer exchanges the routed rows with one all-to-all each way (vllm_i64_amd/ep.py)."""
         self.cfg, self.device = cfg, torch.device(device)
         dev = self.device
+        self.ep_layers = None
+        if expert_parallel and cfg.is_moe:
+            import torch.distributed as dist
+            from . import ep as _ep
+            self._ep = _ep
+            ep_rank = dist.get_rank(ep_group) if dist.is_initialized() else 0
+            ep_world = dist.get_world_size(ep_group) if dist.is_initialized() else 1
+            assert cfg.num_experts % ep_world == 0, "experts must divide over the ranks"
+            le = cfg.num_experts // ep_world
+            self.ep_layers = []
         f = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
         self.embed = f(weights["embed"])
         self.final_norm = f(weights["final_norm"])
@@ -146,7 +159,16 @@ class I64MoEModel:
             p = f"l{l}."
             d = dict(ln1=f(weights[p + "ln1"]), ln2=f(weights[p + "ln2"]), q_norm=f(weights[p + "q_norm"]),
                      k_norm=f(weights[p + "k_norm"]), qkv=pack_per_tensor(weights[p + "qkv"], dev), o=pack_per_tensor(weights[p + "o"], dev))
-            if cfg.is_moe:
+            if cfg.is_moe and self.ep_layers is not None:
+                local = {"exp_gate_up": weights[p + "exp_gate_up"][ep_rank * le:(ep_rank + 1) * le],
+                         "exp_down": weights[p + "exp_down"][ep_rank * le:(ep_rank + 1) * le]}
+                if cfg.shared_intermediate_size:
+                    local["sh_gate_up"], local["sh_down"] = weights[p + "sh_gate_up"], weights[p + "sh_down"]
+                table_l = weights[p + "table"].to(torch.int64).to(dev)
+                self.ep_layers.append(_ep.ExpertParallelMoE(cfg, table_l, _ep.HipBackend(cfg, local, dev), ep_group,
+                                                            shared_global_stats=False))
+                tables.append(weights[p + "table"].to(torch.int64))
+            elif cfg.is_moe:
                 d["exp_gu"] = pack_per_tensor(weights[p + "exp_gate_up"], dev)
                 d["exp_dn"] = pack_per_tensor(weights[p + "exp_down"], dev)
                 if cfg.shared_intermediate_size:
@@ -201,7 +223,11 @@ class I64MoEModel:
         H, nbk, spl = cfg.hidden_size, self.nb, self.spl
         eps = cfg.rms_eps
         rw = cfg.route_weights
-        if cfg.is_moe:
+        ep_plans = None
+        if self.ep_layers is not None:
+            ids_all, sizes = self.ep_layers[0].gather_ids(token_ids)
+            ep_plans = self._ep.build_plans(ids_all, self.tables, sizes, self.ep_layers[0].rank, cfg.num_experts)
+        elif cfg.is_moe:
             B.plan.run(token_ids, self.tables)
         ops.stats_reset(st)
         ops.embedding(token_ids, self.embed, out=B.h)
@@ -233,7 +259,15 @@ class I64MoEModel:
             if splits == 1:
                 ops.rows_minmax(attn2d, st, slot_base=base + 1)
             self._linear(attn2d, W["o"], base + 1, B.xa, B.xs, B.o)
-            if cfg.is_moe:
+            if ep_plans is not None:
+                # expert parallel: the layer object gathers its own statistics; its output joins the residual stream
+                ops.fused_residual_norm(B.h, W["ln2"], eps, add=B.o, h_out=B.h, normed=B.normed)
+                moe_out = self.ep_layers[l].forward(B.normed, None, plan=ep_plans[l])
+                nxt = self.layers[l + 1]["ln1"] if l + 1 < cfg.num_layers else self.final_norm
+                last = l + 1 == cfg.num_layers
+                ops.fused_residual_norm(B.h, nxt, eps, add=moe_out, h_out=B.h, normed=B.normed, slot_base=base + spl,
+                                        stats=None if last else st)
+            elif cfg.is_moe:
                 # h += o ; normed = ln2(h) ; statistics for the shared call and for every (route, expert) bucket
                 ops.fused_residual_norm(B.h, W["ln2"], eps, add=B.o, h_out=B.h, normed=B.normed, slots=B.plan.tok_slots[l],
                                         slot_base=base + 2, stats=st)
