@@ -223,3 +223,34 @@ def test_pertoken_int8_operator_path_golden(dev, golden_dir):
     for n in (9, 130):
         out = K.fused_token_routed_forward_int8(d(f"fe8_x{n}"), d("fe8_gu"), d("fe8_gus"), d("fe8_dn"), d("fe8_dns"), d(f"fe8_eid{n}").long(), 4, 48)
         assert np.allclose(out.cpu().numpy(), z[f"fe8_y{n}"], rtol=1e-4, atol=1e-5)
+
+
+def test_i64_ops_pipeline_functions(dev):
+    """The operator-library functions of kernels/i64_ops.py with the reference's own known answers
+    (tests/test_i64_pipeline.py:35-96): mask routing, scatter/gather round trip, grouped expert MLP, full pipeline."""
+    from vllm_i64_amd import kernels as K
+    ids = torch.arange(8, dtype=torch.int64, device=dev)
+    assert K.i64_route_tokens(ids, 4).tolist() == [0, 1, 2, 3, 0, 1, 2, 3]
+    big = torch.arange(100000, dtype=torch.int64, device=dev)
+    for E in (2, 4, 8, 16):
+        r = K.i64_route_tokens(big, E)
+        assert r.dtype == torch.int32 and torch.equal(r.long(), big % E) and torch.bincount(r.long()).tolist() == [100000 // E] * E
+    g = torch.Generator().manual_seed(12)
+    H, ei, E, N = 64, 32, 4, 50
+    x = torch.randn(N, H, generator=g)
+    tok = torch.randint(0, 1000, (N,), generator=g)
+    eid = K.i64_route_tokens(tok.to(dev), E)
+    sc, si, off, cnt = K.i64_scatter(x.to(dev), eid, E)
+    assert torch.equal(K.i64_gather(sc, si).cpu(), x) and int(cnt.sum()) == N
+    assert cnt.tolist() == torch.bincount(eid.long().cpu(), minlength=E).tolist()
+    gu = torch.randn(E, H, 2 * ei, generator=g) * 0.1
+    dn = torch.randn(E, ei, H, generator=g) * 0.1
+    ref = torch.zeros(N, H)
+    e_cpu = eid.long().cpu()
+    for e in range(E):
+        m = e_cpu == e
+        t = x[m] @ gu[e]
+        ref[m] = (torch.nn.functional.silu(t[:, :ei]) * t[:, ei:]) @ dn[e]
+    out_sorted = K.i64_expert_forward(sc, gu.to(dev), dn.to(dev), off, cnt, E)
+    torch.testing.assert_close(K.i64_gather(out_sorted, si).cpu(), ref, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(K.i64_full_pipeline(tok.to(dev), x.to(dev), gu.to(dev), dn.to(dev), E).cpu(), ref, rtol=1e-4, atol=1e-5)

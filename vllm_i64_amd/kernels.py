@@ -232,3 +232,44 @@ def fused_token_routed_forward_int8(x: torch.Tensor, gate_up_int8: torch.Tensor,
         inter = ops.silu_mul(gu, intermediate_per_tp)
         out_sorted[s:t] = ops.gemm_w8a32((inter * _f32(down_scale[e])).contiguous(), down_int8[e].t().contiguous(), ones_dn)
     return ops.gather_rows(out_sorted, inv).to(x.dtype)
+
+
+# ---- operator-library pipeline (vllm_i64/kernels/i64_ops.py:17-193) -------------------------------------------------------
+def i64_route_tokens(token_ids: torch.Tensor, num_experts: int) -> torch.Tensor:
+    """expert = token_id & (E - 1), int32 (i64_ops.py:17-34)."""
+    return HipOps.route_tokens(token_ids, num_experts)
+
+
+def i64_scatter(hidden_states: torch.Tensor, expert_ids: torch.Tensor, num_experts: int):
+    """(scattered, scatter_indices, expert_offsets, expert_counts) as i64_ops.py:37-78; grouping is stable."""
+    return HipOps.scatter_by_expert(hidden_states, expert_ids, num_experts)
+
+
+def i64_gather(expert_output: torch.Tensor, scatter_indices: torch.Tensor) -> torch.Tensor:
+    """expert_output[scatter_indices] (i64_ops.py:81-97)."""
+    return HipOps.gather_by_expert(expert_output, scatter_indices)
+
+
+def i64_expert_forward(scattered: torch.Tensor, gate_up_weights: torch.Tensor, down_weights: torch.Tensor, expert_offsets: torch.Tensor,
+                       expert_counts: torch.Tensor, num_experts: int) -> torch.Tensor:
+    """Expert MLP over rows already grouped by expert (i64_ops.py:100-158, csrc/i64_expert_dispatch.cu:144-233):
+    gate_up_weights [E, H, 2*ei], down_weights [E, ei, H].  fp32 math on the f32 matrix cores; like the reference it reads
+    the per-expert counts on the host."""
+    out = torch.zeros(scattered.shape, dtype=torch.float32, device=scattered.device)
+    ei = down_weights.shape[1]
+    xf = _f32(scattered)
+    off, cnt = expert_offsets.tolist(), expert_counts.tolist()
+    for e in range(num_experts):
+        s, c = int(off[e]), int(cnt[e])
+        if c == 0:
+            continue
+        gu = ops.gemm_f32(xf[s:s + c].contiguous(), _f32(gate_up_weights[e].t()))
+        out[s:s + c] = ops.gemm_f32(ops.silu_mul(gu, ei), _f32(down_weights[e].t()))
+    return out.to(scattered.dtype)
+
+
+def i64_full_pipeline(token_ids: torch.Tensor, hidden_states: torch.Tensor, gate_up_weights: torch.Tensor, down_weights: torch.Tensor,
+                      num_experts: int) -> torch.Tensor:
+    """route -> grouped expert MLP -> original order (i64_ops.py:161-193)."""
+    expert_ids = i64_route_tokens(token_ids, num_experts)
+    return fused_token_routed_forward(hidden_states, gate_up_weights, down_weights, expert_ids.long(), num_experts, down_weights.shape[1])
