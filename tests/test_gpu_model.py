@@ -181,3 +181,36 @@ def test_expert_parallel_model_equals_plain_model_at_one_rank(dev):
     for a, b in zip(outs[0], outs[1]):
         assert (a - b).abs().max() <= 1e-5, (a - b).abs().max()
         assert torch.equal(a.argmax(-1), b.argmax(-1))
+
+
+def test_mixed_prefill_and_decode_batches_teacher_forced(dev):
+    """Engine-shaped steps (vllm_i64/engine/i64_scheduler.py:345-503: chunked prefill, mixed prefill/decode batches):
+    step 1 = first chunk of sequence 0; step 2 = its second chunk + the whole prompt of sequence 1; step 3 = one decode
+    token of sequence 1 + the last chunk of sequence 0.  Every layer of every step is fed the oracle's layer input."""
+    ocfg, w, model = _model("tiny-moe", dev)
+    ids = M.make_token_ids(ocfg, 60, seed=13)
+    bank = M.LinearBank(w, "int8")
+    kv = M.PagedKV(ocfg, 64, 4)
+    for s in range(4):
+        model.kv.free(s)
+    model.kv.reserve(0, 40)
+    model.kv.reserve(1, 16)
+    steps = [  # (token slice, positions, seq ids, tokens per seq)
+        (ids[0:20], list(range(20)), [0], [20]),
+        (torch.cat([ids[20:33], ids[40:49]]), list(range(20, 33)) + list(range(9)), [0, 1], [13, 9]),
+        (torch.cat([ids[49:50], ids[33:40]]), [9] + list(range(33, 40)), [1, 0], [1, 7]),
+    ]
+    for si, (tok, pos, seqs, tps) in enumerate(steps):
+        rec = {}
+        post = torch.tensor(pos)
+        M.model_forward(ocfg, bank, tok, post, kv, seqs, tps, rec)
+        slots = torch.cat([torch.full((t,), s, dtype=torch.int32) for s, t in zip(seqs, tps)]).to(dev)
+        posd = post.to(torch.int32).to(dev)
+        inject = {l: rec[f"l{l}.in"].to(dev) for l in range(ocfg.num_layers)}
+        grec = {}
+        model.forward(tok.to(dev), posd, slots, (posd + 1).contiguous(), record=grec, inject=inject)
+        for l in range(ocfg.num_layers):
+            da = (grec[f"l{l}.attn_out"].cpu() - rec[f"l{l}.attn_out"]).abs()
+            do = (grec[f"l{l}.out"].cpu() - rec[f"l{l}.out"]).abs()
+            assert da.max() <= 1e-5, (si, l, da.max())
+            assert do.max() <= 1e-2 and do.mean() <= 1e-4, (si, l, do.max(), do.mean())
