@@ -214,3 +214,52 @@ def test_mixed_prefill_and_decode_batches_teacher_forced(dev):
             do = (grec[f"l{l}.out"].cpu() - rec[f"l{l}.out"]).abs()
             assert da.max() <= 1e-5, (si, l, da.max())
             assert do.max() <= 1e-2 and do.mean() <= 1e-4, (si, l, do.max(), do.mean())
+
+
+class _EngineLikeCache:
+    """Duck type of the reference's PagedKVCache as the model sees it (core/kv_cache.py:84-107, 248-292)."""
+
+    def __init__(self, cfg, num_blocks, max_seqs, dev, dtype=torch.float32):
+        self.block_size, self.num_kv_heads, self.head_dim = 16, cfg.num_kv_heads, cfg.head_dim
+        shape = (num_blocks, 16, cfg.num_kv_heads, cfg.head_dim)
+        self.k_caches = [torch.zeros(shape, dtype=dtype, device=dev) for _ in range(cfg.num_layers)]
+        self.v_caches = [torch.zeros(shape, dtype=dtype, device=dev) for _ in range(cfg.num_layers)]
+        self.block_table = torch.full((max_seqs, 8), -1, dtype=torch.int32, device=dev)
+        self.seq_lens = torch.zeros(max_seqs, dtype=torch.int32, device=dev)
+        self._free = list(range(num_blocks))[::-1]
+        self.allocations = 0
+
+    def allocate_blocks(self, seq_id, n):
+        have = int((self.block_table[seq_id] >= 0).sum())
+        new = [self._free.pop() for _ in range(n)]
+        self.block_table[seq_id, have:have + n] = torch.tensor(new, dtype=torch.int32, device=self.block_table.device)
+        self.allocations += n
+        return new
+
+
+def test_engine_model_contract_with_engine_owned_cache(dev):
+    """model(token_ids, positions, kv_cache, seq_ids, tokens_per_seq) on a cache the ENGINE owns: same logits as the
+    runner on its own cache over a chunked prefill, a mixed step and a decode step; blocks are allocated through the
+    cache's own allocator and seq_lens follows the reference's write_kv."""
+    from vllm_i64_amd.engine_adapter import EngineModel
+    ocfg, w, model = _model("tiny-moe", dev)
+    ids = M.make_token_ids(ocfg, 60, seed=13)
+    cache = _EngineLikeCache(model.cfg, 32, 4, dev)
+    em = EngineModel(model)
+    for s in range(4):
+        model.kv.free(s)
+    model.kv.reserve(2, 40)
+    model.kv.reserve(0, 16)
+    steps = [  # engine sequence ids 3 and 1 <-> runner slots 2 and 0
+        (ids[0:20], list(range(20)), [3], [20]),
+        (torch.cat([ids[20:33], ids[40:49]]), list(range(20, 33)) + list(range(9)), [3, 1], [13, 9]),
+        (torch.cat([ids[49:50], ids[33:34]]), [9, 33], [1, 3], [1, 1]),
+    ]
+    own = {3: 2, 1: 0}
+    for tok, pos, seqs, tps in steps:
+        lg = em(tok, torch.tensor(pos), cache, seqs, tps)
+        posd = torch.tensor(pos, dtype=torch.int32, device=dev)
+        slots = torch.cat([torch.full((t,), own[s], dtype=torch.int32) for s, t in zip(seqs, tps)]).to(dev)
+        ref = model.forward(tok.to(dev), posd, slots, (posd + 1).contiguous()).clone()
+        assert lg.shape == (len(pos), ocfg.vocab_size) and torch.equal(lg, ref)
+    assert cache.seq_lens.tolist() == [0, 10, 0, 34] and cache.allocations == 3 + 1
