@@ -96,9 +96,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("I64_BENCH_FORCE_DIST") == "1":  # the variable rehearses the N > 1 code path on one GPU
         import torch.distributed as dist_
-        dist_.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist_.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         dist = dist_
 
     from vllm_i64_amd import _lib, ops, synth

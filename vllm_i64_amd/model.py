@@ -419,9 +419,20 @@ class GreedyDecoder:
                 dst.copy_(src)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self._step_body()
+            try:
+                # thread_local: other threads of the process (e.g. a collective library's watchdog) may touch the runtime
+                # while this thread captures
+                with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                    self._step_body()
+            except Exception as e:  # no graph on this platform / in this process: same step, launched eagerly
+                import warnings
+                warnings.warn(f"HIP graph capture of the decode step failed ({e!r}); decoding without a graph")
+                self.graph, self.use_graph = None, False
+                torch.cuda.synchronize()
             for dst, src in zip((self.tokens, self.positions, self.ctx_len), state):
                 dst.copy_(src)
+            if self.graph is None:
+                self._step_body()
+                return self.logits
         self.graph.replay()
         return self.logits
