@@ -59,11 +59,14 @@ __global__ __launch_bounds__(256) void fused_residual_norm_kernel(const float* _
                                                                   const float* __restrict__ w, float eps, float* __restrict__ normed,
                                                                   int H, const int32_t* __restrict__ slots, int spr, int slot_base,
                                                                   uint32_t* __restrict__ stats) {
-    __shared__ float red[4], rlo[4], rhi[4];
-    __shared__ float bc;
+    __shared__ float red[8], rlo[4], rhi[4];
     __shared__ float tab_lo[I64H_STAT_TAB], tab_hi[I64H_STAT_TAB];
-    if (stats) stat_tab_init(tab_lo, tab_hi);
-    __syncthreads();
+    // one row per workgroup (decode): the row's few slots are updated directly, without the per-workgroup table
+    const bool use_tab = stats != nullptr && rpb > 1;
+    if (use_tab) {
+        stat_tab_init(tab_lo, tab_hi);
+        __syncthreads();
+    }
     const int nv = H / 4;
     const int64_t t0 = (int64_t)blockIdx.x * rpb;
     const int64_t t1 = t0 + rpb < n ? t0 + rpb : n;
@@ -105,11 +108,10 @@ __global__ __launch_bounds__(256) void fused_residual_norm_kernel(const float* _
         }
         if (!normed) continue;  // uniform for the whole grid
         ss = wave_sum(ss);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+        if ((threadIdx.x & 63) == 0) red[(t & 1) * 4 + (threadIdx.x >> 6)] = ss;  // two sets: the next row's partials never overtake a reader
         __syncthreads();
-        if (threadIdx.x == 0) bc = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)H + eps);
-        __syncthreads();
-        const float rr = bc;
+        const float* rd = red + (t & 1) * 4;
+        const float rr = rsqrtf((rd[0] + rd[1] + rd[2] + rd[3]) / (float)H + eps);  // every thread, same operands, same result
         float lo = 0.0f, hi = 0.0f;
 #pragma unroll
         for (int j = 0; j < FRN_MAXV; ++j) {
@@ -134,11 +136,16 @@ __global__ __launch_bounds__(256) void fused_residual_norm_kernel(const float* _
         if (threadIdx.x == 0) {
             lo = fminf(fminf(rlo[0], rlo[1]), fminf(rlo[2], rlo[3]));
             hi = fmaxf(fmaxf(rhi[0], rhi[1]), fmaxf(rhi[2], rhi[3]));
-            stat_tab_fold(tab_lo, tab_hi, slots ? slots + t * spr : nullptr, slots ? spr : 1, lo, hi, stats, slot_base, blockIdx.x);
+            if (use_tab) {
+                stat_tab_fold(tab_lo, tab_hi, slots ? slots + t * spr : nullptr, slots ? spr : 1, lo, hi, stats, slot_base, blockIdx.x);
+            } else {
+                const int ns = slots ? spr : 1;
+                for (int j = 0; j < ns; ++j) stat_update(stats, slot_base + (slots ? slots[t * spr + j] : 0), blockIdx.x, lo, hi);
+            }
         }
-        __syncthreads();
+        if (use_tab) __syncthreads();
     }
-    if (stats && normed) stat_tab_flush(tab_lo, tab_hi, stats, slot_base, blockIdx.x);
+    if (use_tab && normed) stat_tab_flush(tab_lo, tab_hi, stats, slot_base, blockIdx.x);
 }
 
 // ---- per-head QK RMSNorm + rotate-half RoPE + paged KV write ----------------------------------------------
