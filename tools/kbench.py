@@ -127,25 +127,18 @@ def bench_gemm_prefill(only=None):
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what == "gemmw":
-        for nw in (4, 8, 16):
+        for nw in (2, 4):
             ops.call("i64h_set_skinny_waves", nw)
             print(f"--- skinny kernel with {nw} waves per workgroup")
             bench_gemm()
         sys.exit(0)
     if what == "gemm1":  # one shape, one variant: python tools/kbench.py gemm1 <variant> <name substring> (for counter passes)
-        ops.call("i64h_set_pipe_gemm", int(sys.argv[2]))
+        ops.call("i64h_set_gemm_stage64", int(sys.argv[2]))
         bench_gemm_prefill(sys.argv[3])
         sys.exit(0)
     if what == "attnctx":  # fixed cost vs streaming cost of the decode attention
         for ctx in (128, 512, 1024, 2048, 4096):
             bench_attn(ctx, dts=(torch.bfloat16,), splits_list=(2, 4, 8))
-        sys.exit(0)
-    if what == "ablate":
-        for v in (0, 80, 160, 240, 310):
-            ops.call("i64h_set_pipe_gemm", v)
-            print(f"--- ablation bits {v // 10} (1 no global loads/LDS stores, 2 no fragment reads, 4 no barrier, 8 no C stores, 16 no exp/div)")
-            bench_gemm_prefill("shared gate_up")
-            bench_gemm_prefill("expert gate_up")
         sys.exit(0)
     if what in ("attn", "all"):
         bench_attn()
@@ -153,6 +146,6 @@ if __name__ == "__main__":
         bench_gemm()
     if what in ("gemmp", "all"):
         for on in (0, 1):
-            ops.call("i64h_set_pipe_gemm", on)
+            ops.call("i64h_set_gemm_stage64", on)
             print(f"--- 64-byte stages for short K: {on}")
             bench_gemm_prefill()

@@ -851,6 +851,7 @@ static int launch_skinny(const i64h_gemm_desc* a, const i64h_gemm_desc* b, hipSt
 template <int EPI>
 static int launch_skinny_nw(const i64h_gemm_desc* a, const i64h_gemm_desc* b, hipStream_t st) {
     const int nw = g_skinny_waves ? g_skinny_waves : 4;
+    if (nw == 2) return launch_skinny<EPI, 2>(a, b, st);
     if (nw == 4) return launch_skinny<EPI, 4>(a, b, st);
     if (nw == 16) return launch_skinny<EPI, 16>(a, b, st);
     return launch_skinny<EPI, 8>(a, b, st);
@@ -866,7 +867,7 @@ static bool skinny_ok(const i64h_gemm_desc* d) {
 extern "C" {
 
 // tuning knob: 1 (default) = short-K prefill-sized problems use 64-byte stages, four workgroups per CU; 0 = always 128-byte stages
-int i64h_set_pipe_gemm(int32_t on) {
+int i64h_set_gemm_stage64(int32_t on) {
     g_stage64 = on ? 1 : 0;
     return 0;
 }
@@ -884,7 +885,7 @@ int i64h_debug_set_stamps(void* buffer, int64_t capacity_workgroups) {
 
 // tuning knob: waves per workgroup of the weight-streaming kernel (4, 8 or 16; 0 = default)
 int i64h_set_skinny_waves(int32_t waves) {
-    I64H_CHECK_ARG(waves == 0 || waves == 4 || waves == 8 || waves == 16, "set_skinny_waves: %d not in {0,4,8,16}", waves);
+    I64H_CHECK_ARG(waves == 0 || waves == 2 || waves == 4 || waves == 8 || waves == 16, "set_skinny_waves: %d not in {0,2,4,8,16}", waves);
     g_skinny_waves = waves;
     return 0;
 }
