@@ -1,0 +1,33 @@
+"""Phase timing inside the decode attention kernel (s_memtime stamps): batch 64, 2048-token contexts, bf16 cache."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vllm_i64_amd import ops
+
+dev = torch.device("cuda:0")
+B, ctx, nh, kvh, hd, splits = 64, int(sys.argv[1]) if len(sys.argv) > 1 else 2048, 16, 4, 64, 8
+nblk = B * (ctx // 16 + 2)
+kc = torch.randn(nblk, 16, kvh, hd, device=dev).to(torch.bfloat16)
+vc = torch.randn(nblk, 16, kvh, hd, device=dev).to(torch.bfloat16)
+bt = torch.randperm(nblk, device=dev).to(torch.int32).view(B, -1).contiguous()
+q = torch.randn(B, nh, hd, device=dev)
+cl = torch.full((B,), ctx, dtype=torch.int32, device=dev)
+out = torch.empty_like(q)
+ws = ops.attn_workspace(B, nh, hd, splits, dev)
+junk = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+for _ in range(3):
+    ops.paged_attn(q, kc, vc, bt, cl, splits=splits, out=out, workspace=ws)
+buf = torch.zeros(B * splits * 8, dtype=torch.int64, device=dev)
+ops.call("i64h_debug_set_attn_stamps", ops.ptr(buf))
+junk.fill_(1)            # cold caches, like inside a decode step
+ops.paged_attn(q, kc, vc, bt, cl, splits=splits, out=out, workspace=ws)
+torch.cuda.synchronize()
+ops.call("i64h_debug_set_attn_stamps", 0)
+st = buf.view(B * splits, 8).cpu().double()
+names = ["entry -> first rows requested", "-> token loop done", "-> partials written", "-> arrival counted"]
+d = st[:, 1:5] - st[:, 0:4]
+print(f"ctx {ctx}: workgroup lifetime median {(st[:, 4] - st[:, 0]).median():.0f} max {(st[:, 4] - st[:, 0]).max():.0f} ticks; "
+      + ", ".join(f"{n} {d[:, j].median():.0f}" for j, n in enumerate(names)))
+last = st[:, 5] > 0
+print(f"last-arriving workgroups: {int(last.sum())}; merge phase median {(st[last, 5] - st[last, 4]).median():.0f} ticks")
+print(f"entry spread {st[:, 0].max() - st[:, 0].min():.0f} ticks; first entry to last stamp {st[:, :6].max() - st[:, 0].min():.0f} ticks")

@@ -363,6 +363,15 @@ __global__ __launch_bounds__(GS * 64) void paged_attn_prefill_kernel(const float
 // compile to sc1 stores / loads, which are coherent across CUs and XCDs without any cache write-back or invalidate.
 __device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// two adjacent floats (8-byte aligned) in one access
+__device__ __forceinline__ float2 ld_agent2(const float* p) {
+    const unsigned long long u = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((uint32_t)u), __uint_as_float((uint32_t)(u >> 32)));
+}
+__device__ __forceinline__ void st_agent2(float* p, float a, float b) {
+    __hip_atomic_store((unsigned long long*)p, (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // merge the splits of one query row (all heads) with one workgroup: one float4 of one head per thread and pass;
 // optionally folds min/max of the row into a stat slot
@@ -377,19 +386,52 @@ __device__ __forceinline__ void attn_merge_row(const float* part_o, const float*
         const int d = (i % per_head) * 4;
         const float* ml = part_ml + head * splits * 2;
         float mm = -INFINITY;
-        for (int s = 0; s < splits; ++s) mm = fmaxf(mm, COH ? ld_agent(ml + 2 * s) : ml[2 * s]);
         float lt = 0.0f;
         float4 ot = make_float4(0, 0, 0, 0);
+        if (COH && splits <= 8) {
+            // every (m, l) pair and partial row of the (up to 8) splits is requested before the first one is used
+            float2 msl[8], pa[8], pb[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int sc = s < splits ? s : 0;
+                const float* pp = part_o + (head * splits + sc) * HD + d;
+                msl[s] = ld_agent2(ml + 2 * sc);
+                pa[s] = ld_agent2(pp);
+                pb[s] = ld_agent2(pp + 2);
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                if (s < splits) mm = fmaxf(mm, msl[s].x);
+            if (mm != -INFINITY) {
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    if (s >= splits) break;
+                    const float f = (msl[s].x == -INFINITY) ? 0.0f : (base2 ? exp2f(msl[s].x - mm) : expf(msl[s].x - mm));
+                    lt = __builtin_fmaf(f, msl[s].y, lt);
+                    ot.x = __builtin_fmaf(f, pa[s].x, ot.x); ot.y = __builtin_fmaf(f, pa[s].y, ot.y);
+                    ot.z = __builtin_fmaf(f, pb[s].x, ot.z); ot.w = __builtin_fmaf(f, pb[s].y, ot.w);
+                }
+            }
+        } else {
+        for (int s = 0; s < splits; ++s) mm = fmaxf(mm, COH ? ld_agent(ml + 2 * s) : ml[2 * s]);  // (m, l) pairs, 8-byte aligned
         if (mm != -INFINITY) {
             for (int s = 0; s < splits; ++s) {
-                const float ms = COH ? ld_agent(ml + 2 * s) : ml[2 * s];
+                const float2 msl = COH ? ld_agent2(ml + 2 * s) : make_float2(ml[2 * s], ml[2 * s + 1]);
+                const float ms = msl.x;
                 const float f = (ms == -INFINITY) ? 0.0f : (base2 ? exp2f(ms - mm) : expf(ms - mm));
                 const float* pp = part_o + (head * splits + s) * HD + d;
-                const float4 po = COH ? make_float4(ld_agent(pp), ld_agent(pp + 1), ld_agent(pp + 2), ld_agent(pp + 3)) : *(const float4*)pp;
-                lt = __builtin_fmaf(f, COH ? ld_agent(ml + 2 * s + 1) : ml[2 * s + 1], lt);
+                float4 po;
+                if (COH) {
+                    const float2 a = ld_agent2(pp), b = ld_agent2(pp + 2);
+                    po = make_float4(a.x, a.y, b.x, b.y);
+                } else {
+                    po = *(const float4*)pp;
+                }
+                lt = __builtin_fmaf(f, msl.y, lt);
                 ot.x = __builtin_fmaf(f, po.x, ot.x); ot.y = __builtin_fmaf(f, po.y, ot.y);
                 ot.z = __builtin_fmaf(f, po.z, ot.z); ot.w = __builtin_fmaf(f, po.w, ot.w);
             }
+        }
         }
         float4 v = make_float4(0, 0, 0, 0);
         if (lt > 0.0f) { v.x = ot.x / lt; v.y = ot.y / lt; v.z = ot.z / lt; v.w = ot.w / lt; }
@@ -431,7 +473,9 @@ __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* _
                                                                   const int32_t* __restrict__ ctx_len, float scale, float* __restrict__ out,
                                                                   float* part_o, float* part_ml, int block,
                                                                   int splits, int* __restrict__ arrivals, uint32_t* __restrict__ stats,
-                                                                  int stat_slot) {
+                                                                  int stat_slot, unsigned long long* __restrict__ stamps) {
+#define PA_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+    PA_STAMP(0);
     constexpr int CPH = HD / 8;         // chunk lanes per head
     constexpr int LPT = KVH * CPH;      // lanes per token
     constexpr int TPS = 64 / LPT;       // tokens per wave step
@@ -492,6 +536,7 @@ __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* _
     };
     fetch_blocks(t_begin + wid * TPI, pbn);
     issue(t_begin + wid * TPI);
+    PA_STAMP(1);
     for (int t0 = t_begin + wid * TPI; t0 < t_end; t0 += 4 * TPI) {
         Raw8<KV> rk[PD_U], rv[PD_U];
         bool live[PD_U];
@@ -543,6 +588,7 @@ __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* _
             }
         }
     }
+    PA_STAMP(2);
     // reduce over the token lanes (same kv head and chunk), then over waves through LDS
 #pragma unroll
     for (int h = 0; h < GS; ++h) {
@@ -566,30 +612,29 @@ __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* _
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < NH * HD; i += 256) {
-        const int h = i / HD, d = i % HD;
+    for (int i = threadIdx.x; i < NH * HD / 2; i += 256) {  // two adjacent dims per thread: 8-byte stores
+        const int h = i / (HD / 2), d = (i % (HD / 2)) * 2;
         float mm = fmaxf(fmaxf(s_m[0][h], s_m[1][h]), fmaxf(s_m[2][h], s_m[3][h]));
-        float lt = 0.0f, ot = 0.0f;
+        float lt = 0.0f, o0 = 0.0f, o1 = 0.0f;
         if (mm != -INFINITY) {
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 const float f = (s_m[w][h] == -INFINITY) ? 0.0f : exp2f(s_m[w][h] - mm);
                 lt = __builtin_fmaf(f, s_l[w][h], lt);
-                ot = __builtin_fmaf(f, s_o[w][h][d], ot);
+                o0 = __builtin_fmaf(f, s_o[w][h][d], o0);
+                o1 = __builtin_fmaf(f, s_o[w][h][d + 1], o1);
             }
         }
         const int64_t head = (int64_t)row * NH + h;
         if (splits == 1) {
-            out[head * HD + d] = (lt > 0.0f) ? ot / lt : 0.0f;
+            *(float2*)(out + head * HD + d) = make_float2((lt > 0.0f) ? o0 / lt : 0.0f, (lt > 0.0f) ? o1 / lt : 0.0f);
         } else {
-            st_agent(&part_o[(head * splits + sp) * HD + d], ot);
-            if (d == 0) {
-                st_agent(&part_ml[(head * splits + sp) * 2], mm);
-                st_agent(&part_ml[(head * splits + sp) * 2 + 1], lt);
-            }
+            st_agent2(&part_o[(head * splits + sp) * HD + d], o0, o1);
+            if (d == 0) st_agent2(&part_ml[(head * splits + sp) * 2], mm, lt);
         }
     }
     if (splits == 1 || arrivals == nullptr) return;
+    PA_STAMP(3);
     __shared__ int s_last;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial results have left the CU ...
     __syncthreads();                                   // ... and so have those of the workgroup's other waves
@@ -599,7 +644,13 @@ __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* _
         if (s_last) __hip_atomic_store(&arrivals[row], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    if (s_last) attn_merge_row<true>(part_o, part_ml, out, row, NH, HD, splits, stats, stat_slot, 1);
+    PA_STAMP(4);
+    if (s_last) {
+        attn_merge_row<true>(part_o, part_ml, out, row, NH, HD, splits, stats, stat_slot, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PA_STAMP(5);
+    }
+#undef PA_STAMP
 }
 
 template <int HD, int GS, typename KV>
@@ -636,6 +687,7 @@ static int dispatch_gs(int gs, int kv_dtype, const float* q, const void* kc, con
 }
 
 #define PF_MIN_ROWS 256      // from this many rows on, the 16-row-tile matrix-core kernel is used (splits == 1, head_dim 64)
+static unsigned long long* g_attn_stamps = nullptr;  // diagnostics, see i64h_debug_set_attn_stamps
 static int g_prefill_mfma = 1;  // tuning / test knob: 0 = always the row-per-workgroup kernel
 #define ATTN_ARRIVALS 4096  // rows whose splits can be merged by the last-arriving workgroup
 
@@ -646,6 +698,14 @@ extern "C" {
 // (i64h_paged_attn_workspace_init); every launch leaves them zero.
 int64_t i64h_paged_attn_workspace_floats(int64_t rows, int32_t num_heads, int32_t head_dim, int32_t splits) {
     return splits > 1 ? ATTN_ARRIVALS + rows * num_heads * splits * (int64_t)(head_dim + 2) : 0;
+}
+
+// diagnostics: device buffer of 8 uint64 per workgroup ((split, row) order) that the decode attention kernel fills with
+// s_memtime stamps (0 entry, 1 first K/V rows requested, 2 token loop done, 3 partial results written, 4 arrival counted,
+// 5 merge stored - last-arriving workgroup only); every launch overwrites it; NULL switches it off
+int i64h_debug_set_attn_stamps(void* buffer) {
+    g_attn_stamps = (unsigned long long*)buffer;
+    return 0;
 }
 
 int i64h_set_prefill_attn(int32_t on) {
@@ -707,15 +767,15 @@ int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, in
         if (kv_dtype == 0)                                                                                                             \
             hipLaunchKernelGGL((paged_attn_allheads_kernel<HD_, KVH_, GS_, float>), grid, dim3(256), 0, st, q, (const float*)k_cache, \
                                (const float*)v_cache, block_table, max_blocks_per_seq, slot_ids, ctx_len, softmax_scale, out, part_o,   \
-                               part_ml, block_size, splits, arrivals, stats, stat_slot);                                                \
+                               part_ml, block_size, splits, arrivals, stats, stat_slot, g_attn_stamps);                                 \
         else if (kv_dtype == 1)                                                                                                        \
             hipLaunchKernelGGL((paged_attn_allheads_kernel<HD_, KVH_, GS_, __half>), grid, dim3(256), 0, st, q, (const __half*)k_cache, \
                                (const __half*)v_cache, block_table, max_blocks_per_seq, slot_ids, ctx_len, softmax_scale, out, part_o,  \
-                               part_ml, block_size, splits, arrivals, stats, stat_slot);                                                \
+                               part_ml, block_size, splits, arrivals, stats, stat_slot, g_attn_stamps);                                 \
         else                                                                                                                           \
             hipLaunchKernelGGL((paged_attn_allheads_kernel<HD_, KVH_, GS_, __hip_bfloat16>), grid, dim3(256), 0, st, q,                 \
                                (const __hip_bfloat16*)k_cache, (const __hip_bfloat16*)v_cache, block_table, max_blocks_per_seq,         \
-                               slot_ids, ctx_len, softmax_scale, out, part_o, part_ml, block_size, splits, arrivals, stats, stat_slot); \
+                               slot_ids, ctx_len, softmax_scale, out, part_o, part_ml, block_size, splits, arrivals, stats, stat_slot, g_attn_stamps); \
         done = true;                                                                                                                   \
         rc = 0;                                                                                                                        \
     }
