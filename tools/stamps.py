@@ -18,27 +18,29 @@ for _ in range(3):
     dec.step()
 cap = 1 << 16
 buf = torch.zeros(cap * 8, dtype=torch.int64, device=dev)
+lib = ops._lib.load()
+marks = []
+orig_pair = ops.gemm_i8_pair
+def pair(a, b=None):
+    orig_pair(a, b)
+    marks.append(int(lib.i64h_debug_stamp_cursor()))
+ops.gemm_i8_pair = pair
 ops.call("i64h_debug_set_stamps", ops.ptr(buf), cap)
 dec.step()
 torch.cuda.synchronize()
 ops.call("i64h_debug_set_stamps", 0, 0)
-st = buf.view(cap, 8).cpu()
-used = int((st[:, 0] != 0).sum())
-st = st[:used]
-# launches are contiguous runs; a new launch starts where the entry stamp drops back to the earliest of a later kernel:
-# split on large jumps of the entry stamp between consecutive workgroups
-entry = st[:, 0]
-bounds = [0]
-for i in range(1, used):
-    if entry[i] - entry[i - 1] > 4000 or entry[i] < entry[i - 1] - 4000:
-        bounds.append(i)
-bounds.append(used)
-names = ["entry->weights requested", "->row parameters", "->rows quantized", "->K loop", "->stores drained"]
-print(f"{used} workgroups, {len(bounds) - 1} launches in the step")
-for li in range(min(len(bounds) - 1, 4 * 12), min(len(bounds) - 1, 4 * 13)):
-    s = st[bounds[li]:bounds[li + 1]]
-    d = (s[:, 1:6] - s[:, 0:5]).float()
-    span = (s[:, 5].max() - s[:, 0].min()).item()
-    print(f"launch {li}: {s.shape[0]:4d} workgroups, span {span:6.0f} ticks; median phase ticks: " +
-          ", ".join(f"{n} {d[:, j].median().item():.0f}" for j, n in enumerate(names)) +
-          f"; workgroup lifetime median {(s[:, 5] - s[:, 0]).float().median().item():.0f}, start spread {(s[:, 0].max() - s[:, 0].min()).item()}")
+st = buf.view(cap, 8).cpu().double()
+names = ["qkv", "o", "gate_up pair", "down pair"]
+phases = [(0, 6, "locate tile"), (6, 7, "request stats"), (7, 1, "request weights"), (1, 2, "row parameters"), (2, 3, "quantize rows"),
+          (3, 4, "K loop"), (4, 5, "stores")]
+for kind in range(4):
+    rows = []
+    for layer in range(4, 20):
+        li = layer * 4 + kind
+        lo, hi = (marks[li - 1] if li else 0), marks[li]
+        rows.append(st[lo:hi])
+    s = torch.cat(rows)
+    s = s[s[:, 5] > 0]
+    life = s[:, 5] - s[:, 0]
+    print(f"{names[kind]:13s} {marks[kind] - (marks[kind - 1] if kind else 0):4d} workgroups/launch, lifetime median {life.median():6.0f} ticks: " +
+          ", ".join(f"{n} {(s[:, b] - s[:, a]).median():.0f}" for a, b, n in phases))

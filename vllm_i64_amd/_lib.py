@@ -64,7 +64,7 @@ class I64HError(RuntimeError):
 
 def exported_symbols():
     return ["i64h_last_error", "i64h_version", "i64h_device_check", "i64h_bucketize_workspace_bytes",
-            "i64h_paged_attn_workspace_floats", "i64h_stats_words_per_slot", "i64h_moe_forward_workspace_bytes", *SIGNATURES.keys()]
+            "i64h_paged_attn_workspace_floats", "i64h_stats_words_per_slot", "i64h_moe_forward_workspace_bytes", "i64h_debug_stamp_cursor", *SIGNATURES.keys()]
 
 
 class GemmDesc(ctypes.Structure):
@@ -104,6 +104,8 @@ def load() -> ctypes.CDLL:
     lib.i64h_paged_attn_workspace_floats.argtypes = [_L, _I, _I, _I]
     lib.i64h_stats_words_per_slot.restype = _I
     lib.i64h_stats_words_per_slot.argtypes = []
+    lib.i64h_debug_stamp_cursor.restype = _L
+    lib.i64h_debug_stamp_cursor.argtypes = []
     lib.i64h_moe_forward_workspace_bytes.restype = _L
     lib.i64h_moe_forward_workspace_bytes.argtypes = [_L, _P]
     for name, sig in SIGNATURES.items():

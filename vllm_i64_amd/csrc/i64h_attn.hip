@@ -224,7 +224,8 @@ __global__ __launch_bounds__(GS * 64) void paged_attn_prefill_kernel(const float
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int kh = blockIdx.y, head = kh * GS + wid, nh = kvh * GS;
-    const int r = blockIdx.x * 16 + c;            // this lane's query row
+    // tiles are taken from the back: later rows of a sequence attend to more tokens, and the longest tiles should start first
+    const int r = (gridDim.x - 1 - blockIdx.x) * 16 + c;  // this lane's query row
     const bool valid = r < n;
     const int my_slot = valid ? (slot_ids ? slot_ids[r] : r) : -1;
     const int my_ctx = valid ? ctx_len[r] : 0;
@@ -300,17 +301,21 @@ __global__ __launch_bounds__(GS * 64) void paged_attn_prefill_kernel(const float
             // scores of 64 tokens: S^T tile t holds tokens t0 + 16t + 4g + reg of query row c
             v4f sc[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                sc[t] = (v4f){0, 0, 0, 0};
-                const float* kp = &Ks[16 * t + c][g * 16];
+            for (int t = 0; t < 4; ++t) sc[t] = (v4f){0, 0, 0, 0};
+            // the four token tiles are interleaved: consecutive MFMAs never wait on each other's accumulator
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float4 kq = *(const float4*)(kp + 4 * i);
-                    sc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kq.x, qv[4 * i], sc[t], 0, 0, 0);
-                    sc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kq.y, qv[4 * i + 1], sc[t], 0, 0, 0);
-                    sc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kq.z, qv[4 * i + 2], sc[t], 0, 0, 0);
-                    sc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kq.w, qv[4 * i + 3], sc[t], 0, 0, 0);
-                }
+            for (int i = 0; i < 4; ++i) {
+                float4 kq[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) kq[t] = *(const float4*)(&Ks[16 * t + c][g * 16 + 4 * i]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) sc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kq[t].x, qv[4 * i], sc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) sc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kq[t].y, qv[4 * i + 1], sc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) sc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kq[t].z, qv[4 * i + 2], sc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) sc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kq[t].w, qv[4 * i + 3], sc[t], 0, 0, 0);
             }
             float mx = -INFINITY;
 #pragma unroll

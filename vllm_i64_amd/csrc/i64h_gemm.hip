@@ -417,6 +417,7 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
     __syncthreads();
     const int g = s_info[0], row0 = s_info[1], rows = s_info[2];
     if (g < 0) return;
+    SK_STAMP(6);
 
     const int fr = lane & 15, fq = lane >> 4;
     const int nsteps = K / 64;  // K % 64 == 0 is required by the launcher
@@ -434,6 +435,7 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
     uint4 sw[I64H_SLOT_WORDS / 4];
     if (tid < rows) stat_load_raw(p.stats, p.a_slot_base + (p.a_row_slot ? p.a_row_slot[row0 + tid] : 0), sw);
 
+    SK_STAMP(7);
     // then the first batch of weight fragments
     v4i bq[NF][SK_STEPS];
     auto bload = [&](int s0) {
@@ -874,7 +876,7 @@ int i64h_set_gemm_stage64(int32_t on) {
 
 // diagnostics: device buffer of 8 uint64 per workgroup that the weight-streaming kernel fills with s_memtime stamps at its
 // phase boundaries (0 entry, 1 weights requested, 2 row parameters ready, 3 operand rows quantized, 4 K loop done, 5 stores
-// drained); successive launches append (launch i's workgroups follow launch i-1's) until the capacity is used up; NULL
+// drained, 6 tile located, 7 statistics requested); successive launches append (launch i's workgroups follow launch i-1's) until the capacity is used up; NULL
 // switches it off
 int i64h_debug_set_stamps(void* buffer, int64_t capacity_workgroups) {
     g_stamps = (unsigned long long*)buffer;
@@ -882,6 +884,8 @@ int i64h_debug_set_stamps(void* buffer, int64_t capacity_workgroups) {
     g_stamp_cur = 0;
     return 0;
 }
+
+int64_t i64h_debug_stamp_cursor(void) { return g_stamp_cur; }  // workgroups stamped so far
 
 // tuning knob: waves per workgroup of the weight-streaming kernel (4, 8 or 16; 0 = default)
 int i64h_set_skinny_waves(int32_t waves) {
