@@ -58,6 +58,24 @@ def bench_attn(ctx=2048, dts=(torch.bfloat16, torch.float32), splits_list=(4, 8,
             print(f"attn {str(dt)[6:]:9s} splits {splits:2d}: median {med:7.1f} us best {best:7.1f} us -> {nbytes / med / 1e3:7.1f} GB/s (attn+merge)")
 
 
+def bench_attn_prefill(seqs=8, P=2048):
+    """Prefill attention of one chunk (seqs x P causal rows, bf16 cache): time and fp32 FLOP/s (4 * ctx * hd per row and head)."""
+    nh, kvh, hd = 16, 4, 64
+    n = seqs * P
+    nblk = seqs * (P // 16)
+    kc = torch.randn(nblk, 16, kvh, hd, device=dev).to(torch.bfloat16)
+    vc = torch.randn(nblk, 16, kvh, hd, device=dev).to(torch.bfloat16)
+    bt = torch.randperm(nblk, device=dev).to(torch.int32).view(seqs, -1).contiguous()
+    q = torch.randn(n, nh, hd, device=dev)
+    pos = torch.arange(P, dtype=torch.int32, device=dev).repeat(seqs)
+    slots = torch.arange(seqs, dtype=torch.int32, device=dev).repeat_interleave(P)
+    ctx = (pos + 1).contiguous()
+    out = torch.empty_like(q)
+    flop = 4.0 * float(ctx.sum().item()) * hd * nh
+    med, best = timeit(lambda: ops.paged_attn(q, kc, vc, bt, ctx, slot_ids=slots, out=out), iters=5, warm=2, inner=3)
+    print(f"prefill attention {seqs} x {P} rows: {med:8.1f} us -> {flop / med / 1e6:6.1f} TFLOP/s ({flop / med / 1e6 / 157.3 * 100:4.1f}% of the f32 MFMA peak)")
+
+
 def bench_gemm():
     n, H = 64, 1024
     stats = ops.stats_alloc(64, dev)
@@ -135,6 +153,9 @@ if __name__ == "__main__":
     if what == "gemm1":  # one shape, one variant: python tools/kbench.py gemm1 <variant> <name substring> (for counter passes)
         ops.call("i64h_set_gemm_stage64", int(sys.argv[2]))
         bench_gemm_prefill(sys.argv[3])
+        sys.exit(0)
+    if what == "attnp":
+        bench_attn_prefill()
         sys.exit(0)
     if what == "attnctx":  # fixed cost vs streaming cost of the decode attention
         for ctx in (128, 512, 1024, 2048, 4096):

@@ -16,6 +16,11 @@ FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=o
          "-I", os.path.join(os.path.dirname(HERE), "include"), "-I", CSRC]
 
 
+# per-file extras.  MFMA accumulators that element-wise code reads right after the matrix instructions (softmax on the
+# scores, rescaling of the output tile) stay in ordinary VGPRs instead of being copied out of the accumulator registers.
+EXTRA = {"i64h_attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}  # measured: no gain for the int8 GEMMs
+
+
 def _stale(obj: str, src: str) -> bool:
     if not os.path.exists(obj):
         return True
@@ -34,7 +39,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         if force or _stale(obj, src):
-            jobs.append([hipcc, *FLAGS, "-c", src, "-o", obj])
+            jobs.append([hipcc, *FLAGS, *EXTRA.get(s, []), "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

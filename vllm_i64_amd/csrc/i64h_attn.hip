@@ -256,6 +256,10 @@ __global__ __launch_bounds__(GS * 64) void paged_attn_prefill_kernel(const float
         for (int o = 1; o < 16; o <<= 1) kv_end = max(kv_end, __shfl_xor(kv_end, o));
         kv_end = __shfl(kv_end, 0);
         const int32_t* bt = block_table + (int64_t)cur_slot * max_blocks_per_seq;
+        int lim_min = active ? lim : 0x7fffffff;  // a tile below every active row's limit needs no causal mask
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) lim_min = min(lim_min, __shfl_xor(lim_min, o));
+        lim_min = __shfl(lim_min, 0);
 
         float m = -INFINITY, lsum = 0.0f;
         v4f acc[4];
@@ -280,10 +284,12 @@ __global__ __launch_bounds__(GS * 64) void paged_attn_prefill_kernel(const float
         if (kv_end > 0) gload(0);
         for (int t0 = 0; t0 < kv_end; t0 += PF_TOK) {
             __syncthreads();  // every wave is done with the previous tile
+            int all_ok = 1;
 #pragma unroll
             for (int u = 0; u < CPT; ++u) {
                 const int ci = tid + u * NT;
                 if (ci < PF_TOK * 8) {
+                    all_ok &= rok[u];
                     const int tt = ci >> 3, ch = ci & 7;
                     float kf[8], vf[8];
                     rk[u].get(kf);
@@ -295,7 +301,8 @@ __global__ __launch_bounds__(GS * 64) void paged_attn_prefill_kernel(const float
                     if (ch == 0) s_ok[tt] = rok[u];
                 }
             }
-            __syncthreads();
+            // whole tile inside the sequence, every block present and below every active row's causal limit: no masks
+            const bool plain = __syncthreads_and(all_ok) && (t0 + PF_TOK <= lim_min);
             if (t0 + PF_TOK < kv_end) gload(t0 + PF_TOK);  // next tile in flight behind the math of this one
 
             // scores of 64 tokens: S^T tile t holds tokens t0 + 16t + 4g + reg of query row c
@@ -318,28 +325,36 @@ __global__ __launch_bounds__(GS * 64) void paged_attn_prefill_kernel(const float
                 for (int t = 0; t < 4; ++t) sc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kq[t].w, qv[4 * i + 3], sc[t], 0, 0, 0);
             }
             float mx = -INFINITY;
+            if (plain) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t) mx = fmaxf(mx, fmaxf(fmaxf(sc[t][0], sc[t][1]), fmaxf(sc[t][2], sc[t][3])));
+            } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int tt = 16 * t + 4 * g + e;
-                    const bool live = (t0 + tt < lim) && s_ok[tt];
-                    sc[t][e] = live ? sc[t][e] : -INFINITY;
-                    mx = fmaxf(mx, sc[t][e]);
-                }
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int tt = 16 * t + 4 * g + e;
+                        const bool live = (t0 + tt < lim) && s_ok[tt];
+                        sc[t][e] = live ? sc[t][e] : -INFINITY;
+                        mx = fmaxf(mx, sc[t][e]);
+                    }
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float mn = fmaxf(m, mx);
-            const float alpha = (mn == -INFINITY) ? 1.0f : exp2f(m - mn);
-            m = mn;
-            lsum *= alpha;
+            if (__ballot(mn != m)) {  // some row's running maximum moved: rescale (rare after the first tiles)
+                const float alpha = (mn == -INFINITY) ? 1.0f : exp2f(m - mn);
+                lsum *= alpha;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] *= alpha;
+                for (int j = 0; j < 4; ++j) acc[j] *= alpha;
+            }
+            m = mn;
+            const float mref = (mn == -INFINITY) ? 0.0f : mn;  // exp2(-inf - 0) = 0 for masked scores, no per-element test
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float pv = (sc[t][e] == -INFINITY) ? 0.0f : exp2f(sc[t][e] - mn);
+                    const float pv = __builtin_amdgcn_exp2f(sc[t][e] - mref);
                     lsum += pv;
                     const float4 vq = *(const float4*)&Vs[16 * t + 4 * g + e][c * 4];
                     acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(vq.x, pv, acc[0], 0, 0, 0);
