@@ -209,7 +209,10 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(const float* __restrict
 // Rows are (slot, ctx) pairs like everywhere else; a tile whose rows belong to several sequences is handled in one pass per
 // distinct sequence.  fp32 math throughout (the cache may be bf16 / fp16 / fp32).
 #define PF_TOK 64            // tokens per K/V tile
-#define PF_LDK (64 + 4)      // LDS row stride in floats
+#define PF_LDK 64            // LDS row stride in floats: unpadded, so that a V row read by 16 lanes covers all 64 banks once
+// K rows are read by fragments (lane = (token row c, dim group g)); no padding makes all four ds_read_b128 lane groups
+// conflict-free, this permutation of the row's sixteen 16-byte units by the token row does
+__device__ __forceinline__ int pf_kswz(int token, int unit) { return (unit ^ (((token & 3) << 2) | ((token >> 2) & 3))) * 4; }
 template <int GS, typename KV>
 __global__ __launch_bounds__(GS * 64) void paged_attn_prefill_kernel(const float* __restrict__ q, const KV* __restrict__ k_cache,
                                                                      const KV* __restrict__ v_cache, const int32_t* __restrict__ block_table,
@@ -294,8 +297,8 @@ __global__ __launch_bounds__(GS * 64) void paged_attn_prefill_kernel(const float
                     float kf[8], vf[8];
                     rk[u].get(kf);
                     rv[u].get(vf);
-                    *(float4*)&Ks[tt][ch * 8] = make_float4(kf[0], kf[1], kf[2], kf[3]);
-                    *(float4*)&Ks[tt][ch * 8 + 4] = make_float4(kf[4], kf[5], kf[6], kf[7]);
+                    *(float4*)&Ks[tt][pf_kswz(tt, 2 * ch)] = make_float4(kf[0], kf[1], kf[2], kf[3]);
+                    *(float4*)&Ks[tt][pf_kswz(tt, 2 * ch + 1)] = make_float4(kf[4], kf[5], kf[6], kf[7]);
                     *(float4*)&Vs[tt][ch * 8] = make_float4(vf[0], vf[1], vf[2], vf[3]);
                     *(float4*)&Vs[tt][ch * 8 + 4] = make_float4(vf[4], vf[5], vf[6], vf[7]);
                     if (ch == 0) s_ok[tt] = rok[u];
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(GS * 64) void paged_attn_prefill_kernel(const float
             for (int i = 0; i < 4; ++i) {
                 float4 kq[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) kq[t] = *(const float4*)(&Ks[16 * t + c][g * 16 + 4 * i]);
+                for (int t = 0; t < 4; ++t) kq[t] = *(const float4*)(&Ks[16 * t + c][pf_kswz(c, 4 * g + i)]);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) sc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kq[t].x, qv[4 * i], sc[t], 0, 0, 0);
 #pragma unroll
