@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=32)
     ap.add_argument("--cpu-ctx", type=int, default=128)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--zipf", type=float, default=0.0, help="prompt ids from a Zipf(s) distribution instead of uniform (bucket skew)")
     ap.add_argument("--parallelism", default="dp", choices=["dp", "ep"],
                     help="dp: every rank is an independent replica (default; no data-path collective).  ep: the routed experts are "
                          "sharded over the ranks, one all-to-all each way per MoE layer (RCCL); runs without the HIP graph")
@@ -123,7 +124,7 @@ def main():
 
     # ---- prefill (untimed for the headline; its own rate is reported) ----
     prefill_tps = None
-    ids = synth.make_token_ids(cfg, B * P, seed=7 + rank).view(B, P)
+    ids = synth.make_token_ids(cfg, B * P, seed=7 + rank, zipf=args.zipf).view(B, P)
     if args.synthetic_kv:
         g = torch.Generator(device=dev).manual_seed(5)
         for l in range(cfg.num_layers):
@@ -248,7 +249,8 @@ def main():
                                f"{' (synthetic KV)' if args.synthetic_kv else ' (real prefill)'} + greedy decode, KV cache {args.kv_dtype}",
                    "global_batch": B * world, "seq_len": P, "parallelism": (f"ep{world} (experts sharded, all-to-all each way per MoE layer)" if ep_mode else
                                    f"dp{world} (independent replicas, no collective)" if world > 1 else "single GPU"),
-                   "kv_dtype": args.kv_dtype, "hip_graph": not (args.no_graph or ep_mode)},
+                   "kv_dtype": args.kv_dtype, "hip_graph": not (args.no_graph or ep_mode),
+                   "prompt_ids": f"zipf({args.zipf})" if args.zipf > 0 else "uniform"},
         "roofline": roofline,
         "roofline_mfma": mfma,
     }

@@ -66,6 +66,13 @@ def make_weights(cfg: ModelConfig, seed: int = 0, std: float = 0.02) -> Dict[str
     return w
 
 
-def make_token_ids(cfg: ModelConfig, n: int, seed: int = 7) -> torch.Tensor:
+def make_token_ids(cfg: ModelConfig, n: int, seed: int = 7, zipf: float = 0.0) -> torch.Tensor:
+    """Uniform ids (the benchmark protocol), or with zipf > 0 a Zipf(zipf) distribution over a fixed random permutation of
+    the vocabulary (skewed (route, expert) buckets)."""
     g = torch.Generator().manual_seed(seed)
-    return torch.randint(0, cfg.vocab_size, (n,), generator=g, dtype=torch.long)
+    if zipf <= 0.0:
+        return torch.randint(0, cfg.vocab_size, (n,), generator=g, dtype=torch.long)
+    ranks = torch.arange(1, cfg.vocab_size + 1, dtype=torch.float64)
+    p = ranks.pow(-zipf)
+    order = torch.randperm(cfg.vocab_size, generator=torch.Generator().manual_seed(99))
+    return order[torch.multinomial(p / p.sum(), n, replacement=True, generator=g)]
