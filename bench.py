@@ -36,7 +36,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--prompt-len", type=int, default=2048)
-    ap.add_argument("--kv-dtype", default="bf16", choices=["bf16", "fp32", "fp16"])
+    ap.add_argument("--kv-dtype", default="bf16", choices=["bf16", "fp32", "fp16", "fp8", "fp8_e5m2"],
+                    help="KV cache storage; fp8 / fp8_e5m2 = the reference's kv_cache_dtype casts (core/kv_cache.py:69-75)")
     ap.add_argument("--config", default="trhash500m-synth")
     ap.add_argument("--prefill-chunk-seqs", type=int, default=8)
     ap.add_argument("--synthetic-kv", action="store_true", help="fill the KV cache with random values instead of a real prefill")
@@ -111,7 +112,8 @@ def main():
         raise SystemExit(lib.i64h_last_error().decode())
 
     cfg = get_config(args.config)
-    kv_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "fp16": torch.float16}[args.kv_dtype]
+    kv_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "fp16": torch.float16, "fp8": torch.float8_e4m3fn,
+                "fp8_e5m2": torch.float8_e5m2}[args.kv_dtype]
     B, P = args.batch, args.prompt_len
     assert P + args.steps + args.warmup + 2 <= cfg.max_pos, "prompt + decode steps exceed max_pos"
     t0 = time.time()
@@ -174,7 +176,7 @@ def main():
 
     # ---- roofline of the dominant kernel: paged-KV attention of one layer, timed with HIP events on the launch stream ----
     ctx_now = P + args.warmup + args.steps
-    kvb = {torch.bfloat16: 2, torch.float16: 2, torch.float32: 4}[kv_dtype]
+    kvb = {torch.bfloat16: 2, torch.float16: 2, torch.float32: 4, torch.float8_e4m3fn: 1, torch.float8_e5m2: 1}[kv_dtype]
     Bf = model.buffers(B, B)
     splits = Bf.attn_splits
     evs = []

@@ -183,7 +183,8 @@ int i64h_fused_residual_norm(const float* h, const float* add, const float* moe_
                              int32_t slots_per_row, int32_t slot_base, uint32_t* stats, void* stream);
 /* Per-head QK RMSNorm + rotate-half RoPE on the fused qkv projection, q to q_out, K/V into the paged cache
  * (model.py:172-184,212-219; core/kv_cache.py:294-316).  rope_tab [max_pos, head_dim] = cos(head_dim/2) | sin(head_dim/2).
- * kv_dtype 0 fp32, 1 fp16, 2 bf16.  q_norm_w / k_norm_w NULL = no QK norm. */
+ * kv_dtype 0 fp32, 1 fp16, 2 bf16, 3 fp8 e4m3fn, 4 fp8 e5m2 (one byte per element, the plain cast of the reference's
+ * kv_cache_dtype "fp8" / "fp8_e5m2", core/kv_cache.py:69-75).  q_norm_w / k_norm_w NULL = no QK norm. */
 int i64h_qk_norm_rope_kv(const float* qkv, const float* q_norm_w, const float* k_norm_w, float qk_eps, const float* rope_tab,
                          const int32_t* positions, const int32_t* slot_ids, const int32_t* block_table, int32_t max_blocks_per_seq,
                          float* q_out, void* k_cache, void* v_cache, int32_t kv_dtype, int64_t n, int32_t num_heads, int32_t num_kv_heads,

@@ -441,6 +441,62 @@ def test_qk_norm_rope_kv(dev):
         assert torch.equal(vc[pb, pos[t] % 16], v[t])
 
 
+@pytest.mark.parametrize("f8", [torch.float8_e4m3fn, torch.float8_e5m2])
+def test_fp8_kv_cache_cast_and_attention(dev, f8):
+    """8-bit float KV storage (the reference's kv_cache_dtype "fp8" / "fp8_e5m2" = a plain torch cast, core/kv_cache.py:69-75):
+    the V path of the cache write is the bare cast and must give torch's bytes for every input, special values included;
+    K bytes match the cast of the oracle's normed + rotated K up to one 8-bit step where fp32 rounding differs; attention
+    over the 8-bit cache matches the oracle on the dequantized values (decode and matrix-core prefill kernels)."""
+    ops = _ops()
+    from vllm_i64_amd.model import rope_table
+    g = torch.Generator().manual_seed(61)
+    nh, kvh, hd = 8, 2, 64
+    n = 300
+    qkv = torch.empty(n, (nh + 2 * kvh) * hd).normal_(0, 1.5, generator=g)
+    v_in = qkv[:, (nh + kvh) * hd:].clone()
+    specials = torch.tensor([0.0, -0.0, 447.9, 448.0, 463.9, 464.0, 465.0, 480.0, 1e4, 6e4, 7e4, float("inf"), float("-inf"), float("nan"),
+                             2.0 ** -6, 2.0 ** -7, 2.0 ** -9, 2.0 ** -10, 1.5 * 2.0 ** -9, 2.0 ** -14, 2.0 ** -16, 2.0 ** -17, 1e-8, -3.3, 0.0195])
+    v_in.view(-1)[:specials.numel()] = specials
+    v_in.view(-1)[200:4296] = torch.arange(4096).float() * 0.12 - 240.0     # a dense sweep across many binades and ties
+    qkv[:, (nh + kvh) * hd:] = v_in
+    qw, kw = torch.rand(hd, generator=g) + 0.5, torch.rand(hd, generator=g) + 0.5
+    pos = torch.arange(n, dtype=torch.int32)
+    slot = torch.zeros(n, dtype=torch.int32)
+    nblk = (n + 15) // 16
+    bt = torch.randperm(nblk, generator=g).to(torch.int32).view(1, -1)
+    kc = torch.zeros(nblk, 16, kvh, hd, dtype=f8, device=dev)
+    vc = torch.zeros(nblk, 16, kvh, hd, dtype=f8, device=dev)
+    tab = rope_table(512, hd, 10000.0)
+    qo = ops.qk_norm_rope_kv(qkv.to(dev), qw.to(dev), kw.to(dev), 1e-6, tab.to(dev), pos.to(dev), slot.to(dev), bt.to(dev), kc, vc,
+                             nh, kvh, hd)
+    q, k, v = qkv.split((nh * hd, kvh * hd, kvh * hd), dim=-1)
+    k, v = k.reshape(n, kvh, hd), v.reshape(n, kvh, hd)
+    cos, sin = M.rope_cos_sin(pos, hd, 10000.0)
+    kr = M.apply_rope(M.rmsnorm(k, kw, 1e-6), cos, sin)
+    kcb, vcb = kc.cpu().view(torch.uint8), vc.cpu().view(torch.uint8)
+    rows = bt[0, (pos // 16).long()].long()
+    got_v = vcb[rows, (pos % 16).long()]
+    assert torch.equal(got_v, v.to(f8).view(torch.uint8))                    # the bare cast, bit for bit
+    got_k = kcb[rows, (pos % 16).long()].to(torch.int16)
+    want_k = kr.to(f8).view(torch.uint8).to(torch.int16)
+    assert (got_k - want_k).abs().max() <= 1 and (got_k != want_k).float().mean() < 1e-3
+    # attention over the 8-bit cache: decode rows (split kernel) and all rows (matrix-core prefill kernel)
+    kf = kc.cpu().float()[rows, (pos % 16).long()]
+    vf = vc.cpu().float()[rows, (pos % 16).long()]
+    vf = torch.nan_to_num(vf, nan=0.0, posinf=0.0, neginf=0.0)               # the special values above live only in V: drop them for the check
+    vc2 = vf.to(f8).to(dev)
+    vc.view(torch.uint8)[rows.to(dev), (pos % 16).long().to(dev)] = vc2.view(torch.uint8)
+    vf = vc2.cpu().float()
+    ctx = (pos + 1).contiguous()
+    out_all = ops.paged_attn(qo, kc, vc, bt.to(dev), ctx.to(dev), slot_ids=slot.to(dev)).cpu()
+    sel = torch.tensor([299, 150, 17], dtype=torch.long)
+    out_dec = ops.paged_attn(qo[sel.to(dev)].contiguous(), kc, vc, bt.to(dev), ctx[sel].to(dev), slot_ids=slot[sel].to(dev), splits=4).cpu()
+    for j, i in enumerate(sel.tolist()):
+        ref = M.cached_attention(qo[i:i + 1].cpu(), kf[:i + 1], vf[:i + 1], nh // kvh, torch.tensor([i]), 1.0 / hd ** 0.5)[0]
+        torch.testing.assert_close(out_all[i], ref, rtol=1e-5, atol=5e-6)
+        torch.testing.assert_close(out_dec[j], ref, rtol=1e-5, atol=5e-6)
+
+
 def test_fused_residual_norm(dev):
     ops = _ops()
     g = torch.Generator().manual_seed(41)

@@ -40,6 +40,29 @@ template <> struct Raw8<__hip_bfloat16> {
         }
     }
 };
+// 8-bit float cache: 8 elements = 8 bytes; exact conversion by the hardware (OCP e4m3fn / e5m2 on gfx950)
+template <> struct Raw8<F8E4> {
+    uint2 r;
+    __device__ __forceinline__ void load(const F8E4* p) { r = *(const uint2*)p; }
+    __device__ __forceinline__ void zero() { r = make_uint2(0, 0); }
+    __device__ __forceinline__ void get(float (&o)[8]) const {
+        o[0] = __builtin_amdgcn_cvt_f32_fp8(r.x, 0); o[1] = __builtin_amdgcn_cvt_f32_fp8(r.x, 1);
+        o[2] = __builtin_amdgcn_cvt_f32_fp8(r.x, 2); o[3] = __builtin_amdgcn_cvt_f32_fp8(r.x, 3);
+        o[4] = __builtin_amdgcn_cvt_f32_fp8(r.y, 0); o[5] = __builtin_amdgcn_cvt_f32_fp8(r.y, 1);
+        o[6] = __builtin_amdgcn_cvt_f32_fp8(r.y, 2); o[7] = __builtin_amdgcn_cvt_f32_fp8(r.y, 3);
+    }
+};
+template <> struct Raw8<F8E5> {
+    uint2 r;
+    __device__ __forceinline__ void load(const F8E5* p) { r = *(const uint2*)p; }
+    __device__ __forceinline__ void zero() { r = make_uint2(0, 0); }
+    __device__ __forceinline__ void get(float (&o)[8]) const {
+        o[0] = __builtin_amdgcn_cvt_f32_bf8(r.x, 0); o[1] = __builtin_amdgcn_cvt_f32_bf8(r.x, 1);
+        o[2] = __builtin_amdgcn_cvt_f32_bf8(r.x, 2); o[3] = __builtin_amdgcn_cvt_f32_bf8(r.x, 3);
+        o[4] = __builtin_amdgcn_cvt_f32_bf8(r.y, 0); o[5] = __builtin_amdgcn_cvt_f32_bf8(r.y, 1);
+        o[6] = __builtin_amdgcn_cvt_f32_bf8(r.y, 2); o[7] = __builtin_amdgcn_cvt_f32_bf8(r.y, 3);
+    }
+};
 template <> struct Raw8<__half> {
     uint4 r;
     __device__ __forceinline__ void load(const __half* p) { r = *(const uint4*)p; }
@@ -690,7 +713,9 @@ static int dispatch_kv(int kv_dtype, const float* q, const void* kc, const void*
                        int splits, hipStream_t st) {
     if (kv_dtype == 0) launch_pa<HD, GS, float>(q, kc, vc, bt, mbps, slot_ids, ctx_len, scale, out, part_o, part_ml, n, nh, kvh, block, splits, st);
     else if (kv_dtype == 1) launch_pa<HD, GS, __half>(q, kc, vc, bt, mbps, slot_ids, ctx_len, scale, out, part_o, part_ml, n, nh, kvh, block, splits, st);
-    else launch_pa<HD, GS, __hip_bfloat16>(q, kc, vc, bt, mbps, slot_ids, ctx_len, scale, out, part_o, part_ml, n, nh, kvh, block, splits, st);
+    else if (kv_dtype == 2) launch_pa<HD, GS, __hip_bfloat16>(q, kc, vc, bt, mbps, slot_ids, ctx_len, scale, out, part_o, part_ml, n, nh, kvh, block, splits, st);
+    else if (kv_dtype == 3) launch_pa<HD, GS, F8E4>(q, kc, vc, bt, mbps, slot_ids, ctx_len, scale, out, part_o, part_ml, n, nh, kvh, block, splits, st);
+    else launch_pa<HD, GS, F8E5>(q, kc, vc, bt, mbps, slot_ids, ctx_len, scale, out, part_o, part_ml, n, nh, kvh, block, splits, st);
     return 0;
 }
 
@@ -742,7 +767,7 @@ int i64h_paged_attn_workspace_init(float* workspace, void* stream) {
     return 0;
 }
 
-// kv_dtype: 0 fp32, 1 fp16, 2 bf16.  slot_ids == nullptr: row i uses block_table row i.
+// kv_dtype: 0 fp32, 1 fp16, 2 bf16, 3 fp8 e4m3fn, 4 fp8 e5m2.  slot_ids == nullptr: row i uses block_table row i.
 int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, int32_t kv_dtype, const int32_t* block_table,
                     int32_t max_blocks_per_seq, const int32_t* slot_ids, const int32_t* ctx_len, float softmax_scale, float* out,
                     float* workspace, int64_t rows, int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
@@ -750,7 +775,7 @@ int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, in
     I64H_CHECK_ARG(rows >= 0 && rows < (1ll << 31), "paged_attn: bad row count");
     I64H_CHECK_ARG(stats == nullptr || splits > 1, "paged_attn: output statistics are produced by the split merge (splits > 1)");
     I64H_CHECK_ARG(num_kv_heads > 0 && num_heads % num_kv_heads == 0, "paged_attn: heads %d not a multiple of kv heads %d", num_heads, num_kv_heads);
-    I64H_CHECK_ARG(kv_dtype >= 0 && kv_dtype <= 2, "paged_attn: unknown kv dtype %d", kv_dtype);
+    I64H_CHECK_ARG(kv_dtype >= 0 && kv_dtype <= 4, "paged_attn: unknown kv dtype %d", kv_dtype);
     I64H_CHECK_ARG(splits >= 1 && splits <= 64, "paged_attn: splits=%d out of range", splits);
     I64H_CHECK_ARG(splits == 1 || workspace != nullptr, "paged_attn: splits > 1 needs a workspace");
     I64H_CHECK_ARG(block_size > 0, "paged_attn: bad block size");
@@ -771,7 +796,9 @@ int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, in
     do {                                                        \
         if (kv_dtype == 0) PF(G, float);                        \
         else if (kv_dtype == 1) PF(G, __half);                  \
-        else PF(G, __hip_bfloat16);                             \
+        else if (kv_dtype == 2) PF(G, __hip_bfloat16);          \
+        else if (kv_dtype == 3) PF(G, F8E4);                    \
+        else PF(G, F8E5);                                       \
     } while (0)
         if (gs == 1) PFG(1);
         else if (gs == 2) PFG(2);
@@ -784,29 +811,27 @@ int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, in
     }
     // decode form (few rows, long contexts): all kv heads per workgroup, fully coalesced token rows
     bool done = false;
-#define AH(HD_, KVH_, GS_)                                                                                                          \
-    if (!done && splits > 1 && head_dim == HD_ && num_kv_heads == KVH_ && gs == GS_) {                                                 \
-        dim3 grid((unsigned)rows, (unsigned)splits);                                                                                   \
-        if (kv_dtype == 0)                                                                                                             \
-            hipLaunchKernelGGL((paged_attn_allheads_kernel<HD_, KVH_, GS_, float>), grid, dim3(256), 0, st, q, (const float*)k_cache, \
-                               (const float*)v_cache, block_table, max_blocks_per_seq, slot_ids, ctx_len, softmax_scale, out, part_o,   \
-                               part_ml, block_size, splits, arrivals, stats, stat_slot, g_attn_stamps);                                 \
-        else if (kv_dtype == 1)                                                                                                        \
-            hipLaunchKernelGGL((paged_attn_allheads_kernel<HD_, KVH_, GS_, __half>), grid, dim3(256), 0, st, q, (const __half*)k_cache, \
-                               (const __half*)v_cache, block_table, max_blocks_per_seq, slot_ids, ctx_len, softmax_scale, out, part_o,  \
-                               part_ml, block_size, splits, arrivals, stats, stat_slot, g_attn_stamps);                                 \
-        else                                                                                                                           \
-            hipLaunchKernelGGL((paged_attn_allheads_kernel<HD_, KVH_, GS_, __hip_bfloat16>), grid, dim3(256), 0, st, q,                 \
-                               (const __hip_bfloat16*)k_cache, (const __hip_bfloat16*)v_cache, block_table, max_blocks_per_seq,         \
-                               slot_ids, ctx_len, softmax_scale, out, part_o, part_ml, block_size, splits, arrivals, stats, stat_slot, g_attn_stamps); \
-        done = true;                                                                                                                   \
-        rc = 0;                                                                                                                        \
+#define AH_T(HD_, KVH_, GS_, T)                                                                                                       \
+    hipLaunchKernelGGL((paged_attn_allheads_kernel<HD_, KVH_, GS_, T>), grid, dim3(256), 0, st, q, (const T*)k_cache, (const T*)v_cache, \
+                       block_table, max_blocks_per_seq, slot_ids, ctx_len, softmax_scale, out, part_o, part_ml, block_size, splits,      \
+                       arrivals, stats, stat_slot, g_attn_stamps)
+#define AH(HD_, KVH_, GS_)                                                                       \
+    if (!done && splits > 1 && head_dim == HD_ && num_kv_heads == KVH_ && gs == GS_) {            \
+        dim3 grid((unsigned)rows, (unsigned)splits);                                              \
+        if (kv_dtype == 0) AH_T(HD_, KVH_, GS_, float);                                           \
+        else if (kv_dtype == 1) AH_T(HD_, KVH_, GS_, __half);                                     \
+        else if (kv_dtype == 2) AH_T(HD_, KVH_, GS_, __hip_bfloat16);                             \
+        else if (kv_dtype == 3) AH_T(HD_, KVH_, GS_, F8E4);                                       \
+        else AH_T(HD_, KVH_, GS_, F8E5);                                                          \
+        done = true;                                                                              \
+        rc = 0;                                                                                   \
     }
     AH(64, 4, 4)
     AH(32, 2, 2)
     AH(16, 2, 2)
     AH(128, 4, 2)
 #undef AH
+#undef AH_T
     if (!done) {
 #define GO(H) rc = dispatch_gs<H>(gs, kv_dtype, q, k_cache, v_cache, block_table, max_blocks_per_seq, slot_ids, ctx_len, softmax_scale, out, part_o, part_ml, (int)rows, num_heads, num_kv_heads, block_size, splits, st)
     switch (head_dim) {

@@ -129,6 +129,49 @@ __device__ __forceinline__ float half_swap_max(float v) {
     return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
 }
 
+// ---- 8-bit float KV storage (the reference's kv_cache_dtype "fp8" / "fp8_e5m2": a plain cast, vllm_i64/core/kv_cache.py:69-75) ----
+// One byte per element.  fp32 -> fp8 follows the cast torch performs (round to nearest even; e4m3fn has no infinity:
+// magnitudes that round beyond 448 become NaN; e5m2 overflows to infinity); fp8 -> fp32 is exact (hardware conversion,
+// gfx950 implements the OCP formats).
+struct F8E4 { uint8_t v; };
+struct F8E5 { uint8_t v; };
+__device__ __forceinline__ uint8_t f32_to_e4m3fn(float x) {
+    uint32_t f = __float_as_uint(x);
+    const uint32_t sign = f & 0x80000000u;
+    f ^= sign;
+    uint32_t r;
+    if (f >= 0x43f00000u) {                 // >= 480 (also inf / nan): NaN
+        r = 0x7f;
+    } else if (f < (121u << 23)) {          // below 2^-6: subnormal result, rounded by a float add
+        const float t = __uint_as_float(f) + __uint_as_float(141u << 23);
+        r = __float_as_uint(t) - (141u << 23);
+    } else {
+        const uint32_t odd = (f >> 20) & 1u;
+        f += ((uint32_t)(7 - 127) << 23) + 0x7ffffu;
+        f += odd;
+        r = f >> 20;
+    }
+    return (uint8_t)(r | (sign >> 24));
+}
+__device__ __forceinline__ uint8_t f32_to_e5m2(float x) {
+    uint32_t f = __float_as_uint(x);
+    const uint32_t sign = f & 0x80000000u;
+    f ^= sign;
+    uint32_t r;
+    if (f >= (143u << 23)) {                // >= 65536: infinity, or NaN for a NaN
+        r = f > (255u << 23) ? 0x7f : 0x7c;
+    } else if (f < (113u << 23)) {          // below 2^-14: subnormal result
+        const float t = __uint_as_float(f) + __uint_as_float(134u << 23);
+        r = __float_as_uint(t) - (134u << 23);
+    } else {
+        const uint32_t odd = (f >> 21) & 1u;
+        f += ((uint32_t)(15 - 127) << 23) + 0xfffffu;
+        f += odd;
+        r = f >> 21;
+    }
+    return (uint8_t)(r | (sign >> 24));
+}
+
 // Activation quantization parameters of the reference's dynamic int8 Linear (7-bit, asymmetric):
 // restated from the published x86/FBGEMM algorithm; doubles exactly where the CPU code uses them.
 struct QParams {

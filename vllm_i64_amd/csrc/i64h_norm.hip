@@ -158,6 +158,8 @@ __device__ __forceinline__ KV to_kv(float v);
 template <> __device__ __forceinline__ float to_kv<float>(float v) { return v; }
 template <> __device__ __forceinline__ __hip_bfloat16 to_kv<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
 template <> __device__ __forceinline__ __half to_kv<__half>(float v) { return __float2half(v); }
+template <> __device__ __forceinline__ F8E4 to_kv<F8E4>(float v) { return F8E4{f32_to_e4m3fn(v)}; }
+template <> __device__ __forceinline__ F8E5 to_kv<F8E5>(float v) { return F8E5{f32_to_e5m2(v)}; }
 
 #define QKR_MAX_HD 256
 template <typename KV>
@@ -387,7 +389,7 @@ int i64h_fused_residual_norm(const float* h, const float* add, const float* moe_
     return 0;
 }
 
-// kv_dtype: 0 = fp32, 1 = fp16, 2 = bf16
+// kv_dtype: 0 = fp32, 1 = fp16, 2 = bf16, 3 = fp8 e4m3fn, 4 = fp8 e5m2
 int i64h_qk_norm_rope_kv(const float* qkv, const float* q_norm_w, const float* k_norm_w, float qk_eps, const float* rope_tab,
                          const int32_t* positions, const int32_t* slot_ids, const int32_t* block_table, int32_t max_blocks_per_seq,
                          float* q_out, void* k_cache, void* v_cache, int32_t kv_dtype, int64_t n, int32_t num_heads, int32_t num_kv_heads,
@@ -405,6 +407,8 @@ int i64h_qk_norm_rope_kv(const float* qkv, const float* q_norm_w, const float* k
     if (kv_dtype == 0) LAUNCH_QKR(float);
     else if (kv_dtype == 1) LAUNCH_QKR(__half);
     else if (kv_dtype == 2) LAUNCH_QKR(__hip_bfloat16);
+    else if (kv_dtype == 3) LAUNCH_QKR(F8E4);
+    else if (kv_dtype == 4) LAUNCH_QKR(F8E5);
     else I64H_CHECK_ARG(false, "qk_norm_rope_kv: unknown kv dtype %d", kv_dtype);
 #undef LAUNCH_QKR
     I64H_CHECK_LAUNCH();

@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from ._lib import call, ptr
 
-KV_DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+KV_DTYPE_CODE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.float8_e4m3fn: 3, torch.float8_e5m2: 4}
 EPI_STORE, EPI_SWIGLU = 0, 1
 
 
