@@ -121,6 +121,15 @@ typedef struct i64h_gemm_desc {
     const float* col_scale;       /* epilogue 0, int8 operand, optional: per-output-channel scale [G][N] replacing w_scale[g] */
 } i64h_gemm_desc;
 int i64h_gemm_i8_pair(const i64h_gemm_desc* a, const i64h_gemm_desc* b, void* stream);
+/* Decode-sized fused form (fp32 operand quantized in the kernel from its stat slot, one group, <= 512 rows, K % 64 == 0,
+ * 256 <= K <= 2048): qkv projection + per-head QK RMSNorm + rotate-half RoPE + paged-KV write in one launch (arguments as
+ * i64h_qk_norm_rope_kv; head_dim 64; d->C is not written).  No counterpart in the reference: it stands for the pair
+ * (quantized qkv nn.Linear, QK norm / rotary / cache write) of the decoder layer
+ * (vllm_i64/models/complexity_deep/model.py:165-184) without the kernel boundary and the fp32 qkv round trip in between. */
+int i64h_gemm_i8_qkv_rope_kv(const i64h_gemm_desc* d, const float* q_norm_w, const float* k_norm_w, float qk_eps, const float* rope_tab,
+                             const int32_t* positions, const int32_t* slot_ids, const int32_t* block_table, int32_t max_blocks_per_seq,
+                             float* q_out, void* k_cache, void* v_cache, int32_t kv_dtype, int32_t num_heads, int32_t num_kv_heads,
+                             int32_t head_dim, int32_t block_size, void* stream);
 /* Per-token x per-output-channel rescale, C[r, c] = float(acc) * (row_scale[r] * col_scale[c]): the torch._int_mm branch of
  * int8_linear_native / int8_fused_gate_up_native (vllm_i64/core/quantization.py:119-176, 219-286). */
 int i64h_gemm_i8_colscale(const int8_t* A, const float* row_scale, const int8_t* B, const float* col_scale, int64_t M, int32_t N, int32_t K,

@@ -523,3 +523,44 @@ def test_fused_residual_norm(dev):
     for s in range(5):
         sel = (slots == s).any(dim=1)
         assert lohi[1 + s, 0] == min(nn[sel].min().item(), 0.0) and lohi[1 + s, 1] == max(nn[sel].max().item(), 0.0)
+
+
+def test_fused_qkv_rope_kv_equals_two_kernel_path(dev):
+    """Decode-sized qkv projection with the QK norm / RoPE / cache write in its epilogue against the projection followed by
+    the row kernel: same q, same cache bytes (identical operation order), all cache dtypes, ragged last row block."""
+    ops = _ops()
+    from vllm_i64_amd.model import pack_per_tensor, rope_table
+    g = torch.Generator().manual_seed(71)
+    nh, kvh, hd, H = 8, 2, 64, 256
+    tab = rope_table(128, hd, 10000.0).to(dev)
+    w = pack_per_tensor(torch.empty((nh + 2 * kvh) * hd, H).normal_(0, 0.05, generator=g), dev)
+    qw, kw = (torch.rand(hd, generator=g) + 0.5).to(dev), (torch.rand(hd, generator=g) + 0.5).to(dev)
+    for n, dt in ((37, torch.float32), (64, torch.bfloat16), (5, torch.float16), (20, torch.float8_e4m3fn)):
+        x = torch.empty(n, H).normal_(0, 1, generator=g).to(dev)
+        pos = torch.randint(0, 100, (n,), generator=g).to(torch.int32)
+        slot = torch.arange(n, dtype=torch.int32) % 7
+        pos = (pos + slot * 0).to(dev)          # several rows may share a sequence; positions make their cache cells distinct
+        pos = (torch.arange(n, dtype=torch.int32) // 7 + 3).to(dev)
+        slot = slot.to(dev)
+        nblk = 7 * 8
+        bt = torch.randperm(nblk, generator=g).to(torch.int32).view(7, 8).to(dev)
+        stats = ops.stats_alloc(2, dev)
+        ops.stats_reset(stats)
+        ops.rows_minmax(x, stats, slot_base=1)
+        outs = []
+        for fused in (False, True):
+            kc = torch.zeros(nblk, 16, kvh, hd, device=dev).to(dt)
+            vc = torch.zeros(nblk, 16, kvh, hd, device=dev).to(dt)
+            q = torch.zeros(n, nh, hd, device=dev)
+            qkv = torch.zeros(n, (nh + 2 * kvh) * hd, device=dev)
+            d = ops.gemm_desc(x, w.w_q, w.w_s, qkv, a_slot_base=1, stats=stats)
+            if fused:
+                ops.gemm_i8_qkv_rope_kv(d, qw, kw, 1e-6, tab, pos, slot, bt, kc, vc, q, nh, kvh, hd)
+            else:
+                ops.gemm_i8_pair(d)
+                ops.qk_norm_rope_kv(qkv, qw, kw, 1e-6, tab, pos, slot, bt, kc, vc, nh, kvh, hd, q_out=q)
+            outs.append((q.cpu(), kc.cpu().view(torch.uint8) if dt.itemsize == 1 else kc.cpu().float(),
+                         vc.cpu().view(torch.uint8) if dt.itemsize == 1 else vc.cpu().float()))
+        for a, b in zip(outs[0], outs[1]):
+            assert torch.equal(a, b)
+        assert outs[1][0].abs().sum() > 0

@@ -47,6 +47,7 @@ SIGNATURES: Dict[str, str] = {
     "i64h_set_prefill_attn": "i",
     "i64h_debug_set_attn_stamps": "p",
     "i64h_gemm_i8_pair": "ppp",
+    "i64h_gemm_i8_qkv_rope_kv": "pppfpppp" + "ipppiiiiip",
     "i64h_gemm_i8_colscale": "ppppliipp",
     "i64h_moe_forward": "pplppplp",
     "i64h_set_skinny_waves": "i",

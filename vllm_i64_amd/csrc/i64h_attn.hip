@@ -405,20 +405,6 @@ __global__ __launch_bounds__(GS * 64) void paged_attn_prefill_kernel(const float
     }
 }
 
-// Device-coherent accesses for data handed from one workgroup to another inside a launch: relaxed agent-scope atomics
-// compile to sc1 stores / loads, which are coherent across CUs and XCDs without any cache write-back or invalidate.
-__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// two adjacent floats (8-byte aligned) in one access
-__device__ __forceinline__ float2 ld_agent2(const float* p) {
-    const unsigned long long u = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return make_float2(__uint_as_float((uint32_t)u), __uint_as_float((uint32_t)(u >> 32)));
-}
-__device__ __forceinline__ void st_agent2(float* p, float a, float b) {
-    __hip_atomic_store((unsigned long long*)p, (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // merge the splits of one query row (all heads) with one workgroup: one float4 of one head per thread and pass;
 // optionally folds min/max of the row into a stat slot
 template <bool COH>

@@ -129,6 +129,20 @@ __device__ __forceinline__ float half_swap_max(float v) {
     return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
 }
 
+// Device-coherent accesses for data handed from one workgroup to another inside a launch: relaxed agent-scope atomics
+// compile to sc1 stores / loads, which are coherent across CUs and XCDs without any cache write-back or invalidate.
+__device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// two adjacent floats (8-byte aligned) in one access
+__device__ __forceinline__ float2 ld_agent2(const float* p) {
+    const unsigned long long u = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((uint32_t)u), __uint_as_float((uint32_t)(u >> 32)));
+}
+__device__ __forceinline__ void st_agent2(float* p, float a, float b) {
+    __hip_atomic_store((unsigned long long*)p, (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- 8-bit float KV storage (the reference's kv_cache_dtype "fp8" / "fp8_e5m2": a plain cast, vllm_i64/core/kv_cache.py:69-75) ----
 // One byte per element.  fp32 -> fp8 follows the cast torch performs (round to nearest even; e4m3fn has no infinity:
 // magnitudes that round beyond 448 become NaN; e5m2 overflows to infinity); fp8 -> fp32 is exact (hardware conversion,

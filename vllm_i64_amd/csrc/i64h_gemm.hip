@@ -18,12 +18,16 @@
 // gemm_f32_kernel: C = A[M,K] @ B[N,K]^T in fp32 on v_mfma_f32_16x16x4_f32 (tied lm_head; bit-for-bit a k-ordered
 //   fmaf chain per output).  gemm_w8a32_kernel: fp32 activations x dequantised int8 weights (operator API).
 #include "i64h_common.h"
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 #define EPI_STORE 0
 #define EPI_SWIGLU 1
+// decode-sized kernel only:
+#define EPI_QKR 2  // fused qkv projection: a 64-column tile is one head -> per-head RMSNorm + RoPE, q to q_out, K/V into the paged cache
 #define BK 128
 #define MAX_GROUPS 256
 
@@ -46,6 +50,22 @@ struct GemmI8Args {
     uint32_t* stats;           // stat slots (input parameters for a_fp32, output statistics for EPI_SWIGLU); may be nullptr
     int want_stats;
     unsigned long long* stamps;  // diagnostics: per-workgroup phase timestamps (nullptr = off)
+};
+// What the row-wise epilogue of the decode-sized kernel needs beyond the GEMM itself.
+struct RowTailArgs {
+    // EPI_QKR (the arguments of i64h_qk_norm_rope_kv)
+    const int32_t* positions;
+    const int32_t* slot_ids;
+    const int32_t* block_table;
+    int max_blocks_per_seq;
+    const float* rope_tab;
+    const float* qw;
+    const float* kw;
+    float qk_eps;
+    float* q_out;
+    void* k_cache;
+    void* v_cache;
+    int kv_dtype, nh, kvh, block;
 };
 struct GemmI8Pair {
     GemmI8Args p[2];
@@ -378,8 +398,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void
 #define SK_BM 16  // operand rows per workgroup: one MFMA row fragment (more, smaller workgroups; each reads 1/4 of a 64-row operand)
 #define SK_MF (SK_BM / 16)
 
+__device__ __forceinline__ void kv_store(void* cache, int64_t idx, float v, int kv_dtype) {
+    switch (kv_dtype) {
+        case 0: ((float*)cache)[idx] = v; break;
+        case 1: ((__half*)cache)[idx] = __float2half(v); break;
+        case 2: ((__hip_bfloat16*)cache)[idx] = __float2bfloat16(v); break;
+        case 3: ((uint8_t*)cache)[idx] = f32_to_e4m3fn(v); break;
+        default: ((uint8_t*)cache)[idx] = f32_to_e5m2(v); break;
+    }
+}
+
 template <int EPI, int NW>
-__device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const int bid, char* smem) {
+__device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const int bid, char* smem, const RowTailArgs& ta) {
     constexpr int NF = (EPI == EPI_SWIGLU) ? 2 : 1;  // B fragments per wave per step
     // K steps (64 deep) whose B fragments are in flight together: all of K = 1024 in one batch (half with two fragments per step)
     constexpr int SK_STEPS = 16 / NF;
@@ -418,6 +448,21 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
     const int g = s_info[0], row0 = s_info[1], rows = s_info[2];
     if (g < 0) return;
     SK_STAMP(6);
+    // EPI_QKR: cache slot and rotation of this wave's rows (wid, wid + 4, ...) are looked up now, far ahead of their use
+    int qk_pos[4] = {0, 0, 0, 0}, qk_pb[4] = {0, 0, 0, 0};
+    float qk_c[4] = {0, 0, 0, 0}, qk_s[4] = {0, 0, 0, 0};
+    if constexpr (EPI == EPI_QKR) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = wid + 4 * j;
+            const int64_t t = row0 + (r < rows ? r : 0);
+            qk_pos[j] = ta.positions[t];
+            qk_pb[j] = ta.block_table[(int64_t)ta.slot_ids[t] * ta.max_blocks_per_seq + qk_pos[j] / ta.block];
+            const float* cs = ta.rope_tab + (int64_t)qk_pos[j] * 64;
+            qk_c[j] = cs[lane & 31];
+            qk_s[j] = cs[32 + (lane & 31)];
+        }
+    }
 
     const int fr = lane & 15, fq = lane >> 4;
     const int nsteps = K / 64;  // K % 64 == 0 is required by the launcher
@@ -532,7 +577,7 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
 
     SK_STAMP(4);
     const float ws = p.w_scale[g];
-    if (EPI == EPI_STORE) {
+    if constexpr (EPI == EPI_STORE) {
 #pragma unroll
         for (int i = 0; i < SK_MF; ++i)
 #pragma unroll
@@ -540,6 +585,45 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
                 const int r = i * 16 + fq * 4 + reg;
                 if (r < rows && col_ok) p.C[(int64_t)(row0 + r) * p.N + col] = (float)acc[i][0][reg] * (q_scale[r] * ws);
             }
+    } else if constexpr (EPI == EPI_QKR) {
+        // The workgroup's 64 columns are exactly one head (launcher: head_dim == 64 == NW * 16), so the per-head RMSNorm, the
+        // rotate-half RoPE and the cache write need nothing from other workgroups.  The tile goes through LDS once so that
+        // a wave owns whole rows (lane = dim), the same shape and operation order as the stand-alone row kernel.
+        static_assert(SK_MF == 1 && NW == 4, "one row fragment, four waves = 64 columns");
+        __syncthreads();  // the operand rows in LDS are no longer needed
+        float* s_c = (float*)smem;  // [16][64]
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int r = fq * 4 + reg;
+            s_c[r * 64 + wid * 16 + fr] = (float)acc[0][0][reg] * (q_scale[r] * ws);
+        }
+        __syncthreads();
+        const int head = nt, nh = ta.nh, kvh = ta.kvh, hd = 64, half = 32;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = wid + 4 * j;
+            if (r >= rows) break;
+            const int64_t t = row0 + r;
+            const int pos = qk_pos[j], pb = qk_pb[j];
+            const int64_t cache_row = ((int64_t)pb * ta.block + pos % ta.block) * kvh;  // in heads
+            const float x = s_c[r * 64 + lane];
+            if (head >= nh + kvh) {  // V: raw copy into the cache
+                if (pb >= 0) kv_store(ta.v_cache, (cache_row + (head - nh - kvh)) * hd + lane, x, ta.kv_dtype);
+                continue;
+            }
+            const bool is_q = head < nh;
+            const float* w = is_q ? ta.qw : ta.kw;
+            float ss = __builtin_fmaf(x, x, 0.0f);
+            ss = wave_sum(ss);
+            const float rr = w ? rsqrtf(ss / (float)hd + ta.qk_eps) : 1.0f;
+            const float self = w ? x * rr * w[lane] : x;
+            const float partner = __shfl_xor(self, 32);
+            const float c = qk_c[j], sn = qk_s[j];
+            const float other = lane < half ? -partner : partner;
+            const float o = self * c + other * sn;
+            if (is_q) ta.q_out[(t * nh + head) * hd + lane] = o;
+            else if (pb >= 0) kv_store(ta.k_cache, (cache_row + (head - nh)) * hd + lane, o, ta.kv_dtype);
+        }
     } else {
         __syncthreads();  // A tile no longer needed: reuse its memory for the per-workgroup statistics table
         uint32_t* tab_lo = (uint32_t*)smem;
@@ -595,10 +679,10 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
 }
 
 template <int EPI, int NW>
-__global__ __launch_bounds__(NW * 64) void gemm_i8_skinny_kernel(GemmI8Pair pp) {
+__global__ __launch_bounds__(NW * 64) void gemm_i8_skinny_kernel(GemmI8Pair pp, RowTailArgs ta) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if ((int)blockIdx.x < pp.nblk0) gemm_i8_skinny_body<EPI, NW>(pp.p[0], blockIdx.x, smem);
-    else gemm_i8_skinny_body<EPI, NW>(pp.p[1], blockIdx.x - pp.nblk0, smem);
+    if ((int)blockIdx.x < pp.nblk0) gemm_i8_skinny_body<EPI, NW>(pp.p[0], blockIdx.x, smem, ta);
+    else gemm_i8_skinny_body<EPI, NW>(pp.p[1], blockIdx.x - pp.nblk0, smem, ta);
 }
 
 // ---- fp32 GEMM on the f32 matrix cores: C[M,N] = A[M,K] @ B[N,K]^T ------------------------------------------------
@@ -832,7 +916,9 @@ static int skinny_blocks(const i64h_gemm_desc* d, int bnb) {
 static int g_skinny_waves = 0;  // 0 = default; test/tuning override through i64h_set_skinny_waves
 
 template <int EPI, int NW>
-static int launch_skinny(const i64h_gemm_desc* a, const i64h_gemm_desc* b, hipStream_t st) {
+static int launch_skinny(const i64h_gemm_desc* a, const i64h_gemm_desc* b, hipStream_t st, const RowTailArgs* tail = nullptr) {
+    RowTailArgs ta;
+    if (tail) ta = *tail; else memset(&ta, 0, sizeof(ta));
     GemmI8Pair pp;
     pp.p[0] = to_args(a);
     pp.p[1] = b ? to_args(b) : pp.p[0];
@@ -844,8 +930,9 @@ static int launch_skinny(const i64h_gemm_desc* a, const i64h_gemm_desc* b, hipSt
         g_stamp_cur += total;
     }
     const int kmax = b && b->K > a->K ? b->K : a->K;
-    const size_t lds = (size_t)SK_BM * (kmax + 32) + 16 + 3 * SK_BM * 4;
-    hipLaunchKernelGGL((gemm_i8_skinny_kernel<EPI, NW>), dim3((unsigned)total), dim3(NW * 64), lds, st, pp);
+    size_t lds = (size_t)SK_BM * (kmax + 32) + 16 + 3 * SK_BM * 4;
+    if (lds < 16 * 64 * 4 + 16 + 3 * SK_BM * 4) lds = 16 * 64 * 4 + 16 + 3 * SK_BM * 4;  // the head tile of EPI_QKR lives in the operand area
+    hipLaunchKernelGGL((gemm_i8_skinny_kernel<EPI, NW>), dim3((unsigned)total), dim3(NW * 64), lds, st, pp, ta);
     I64H_CHECK_LAUNCH();
     return 0;
 }
@@ -944,6 +1031,35 @@ int i64h_gemm_i8_colscale(const int8_t* A, const float* row_scale, const int8_t*
     if (M == 0) return 0;
     d.col_scale = col_scale;
     return i64h_gemm_i8_pair(&d, nullptr, stream);
+}
+
+// ---- decode-sized fused forms (fp32 operand quantized in the kernel, one group, at most 512 rows) -------------------------
+static int check_fused(const i64h_gemm_desc* d, const char* who) {
+    if (int rc = check_desc(d, who)) return rc;
+    I64H_CHECK_ARG(skinny_ok(d) && d->group_offsets == nullptr && d->epilogue == EPI_STORE && d->a_src_row == nullptr,
+                   "%s: needs an fp32 operand of at most 512 rows, one group, K a multiple of 64 up to 2048, plain epilogue", who);
+    return 0;
+}
+
+// qkv projection + per-head QK RMSNorm + rotate-half RoPE + paged-KV write in one launch: i64h_gemm_i8_pair(d) followed by
+// i64h_qk_norm_rope_kv(d->C, ...) without the fp32 qkv round trip (d->C is not written).  head_dim must be 64.
+int i64h_gemm_i8_qkv_rope_kv(const i64h_gemm_desc* d, const float* q_norm_w, const float* k_norm_w, float qk_eps, const float* rope_tab,
+                             const int32_t* positions, const int32_t* slot_ids, const int32_t* block_table, int32_t max_blocks_per_seq,
+                             float* q_out, void* k_cache, void* v_cache, int32_t kv_dtype, int32_t num_heads, int32_t num_kv_heads,
+                             int32_t head_dim, int32_t block_size, void* stream) {
+    if (int rc = check_fused(d, "gemm_i8_qkv_rope_kv")) return rc;
+    I64H_CHECK_ARG(head_dim == 64 && d->N == (num_heads + 2 * num_kv_heads) * 64 && d->K >= 256,
+                   "gemm_i8_qkv_rope_kv: head_dim %d / N %d / K %d unsupported (head_dim 64, N = (heads + 2 kv heads) * 64, K >= 256)", head_dim,
+                   d->N, d->K);
+    I64H_CHECK_ARG(kv_dtype >= 0 && kv_dtype <= 4 && block_size > 0, "gemm_i8_qkv_rope_kv: bad kv dtype / block size");
+    I64H_CHECK_ARG(positions && slot_ids && block_table && rope_tab && q_out && k_cache && v_cache, "gemm_i8_qkv_rope_kv: null argument");
+    if (d->M_total == 0) return 0;
+    RowTailArgs ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.positions = positions; ta.slot_ids = slot_ids; ta.block_table = block_table; ta.max_blocks_per_seq = max_blocks_per_seq;
+    ta.rope_tab = rope_tab; ta.qw = q_norm_w; ta.kw = k_norm_w; ta.qk_eps = qk_eps; ta.q_out = q_out; ta.k_cache = k_cache; ta.v_cache = v_cache;
+    ta.kv_dtype = kv_dtype; ta.nh = num_heads; ta.kvh = num_kv_heads; ta.block = block_size;
+    return launch_skinny<EPI_QKR, 4>(d, nullptr, (hipStream_t)stream, &ta);
 }
 
 int i64h_gemm_f32(const float* A, const int32_t* a_rows, const float* B, float* C, int64_t M, int32_t N, int32_t K, void* stream) {

@@ -196,6 +196,7 @@ class I64MoEModel:
         return self._bufs[key]
 
     FUSE_MAX_ROWS = 256  # up to this many operand rows the quantizer runs inside the GEMM (one launch per Linear call)
+    fuse_qkr = True   # decode-sized steps: QK norm / RoPE / cache write inside the qkv GEMM
 
     def _linear(self, x, pl: PackedLinear, slot: int, xa, xs, out, epilogue=ops.EPI_STORE, stats_slot: Optional[int] = None):
         """One dense dynamic-int8 Linear call: quantize with the call's statistics, int8 GEMM, fp32 rescale."""
@@ -224,6 +225,7 @@ class I64MoEModel:
         B = self.buffers(n, logit_rows.numel() if logit_rows is not None else n)
         H, nbk, spl = cfg.hidden_size, self.nb, self.spl
         eps = cfg.rms_eps
+        fuse_rows = n <= self.FUSE_MAX_ROWS
         rw = cfg.route_weights
         ep_plans = None
         if self.ep_layers is not None:
@@ -249,9 +251,15 @@ class I64MoEModel:
                 ops.fused_residual_norm(B.h, W["ln1"], eps, h_out=B.h, normed=B.normed, slot_base=base, stats=st)
             if record is not None:
                 record[f"l{l}.in"] = B.h.clone()
-            self._linear(B.normed, W["qkv"], base + 0, B.xa, B.xs, B.qkv)
-            ops.qk_norm_rope_kv(B.qkv, W["q_norm"], W["k_norm"], 1e-6, self.rope, positions, slot_ids, kvc.block_table,
-                                kvc.k[l], kvc.v[l], cfg.num_heads, cfg.num_kv_heads, cfg.head_dim, q_out=B.q)
+            if fuse_rows and self.fuse_qkr and cfg.head_dim == 64 and H >= 256:
+                # decode-sized step: projection, QK norm, RoPE and cache write in one launch (a 64-column tile is one head)
+                ops.gemm_i8_qkv_rope_kv(ops.gemm_desc(B.normed, W["qkv"].w_q, W["qkv"].w_s, B.qkv, a_slot_base=base + 0, stats=st),
+                                        W["q_norm"], W["k_norm"], 1e-6, self.rope, positions, slot_ids, kvc.block_table, kvc.k[l], kvc.v[l],
+                                        B.q, cfg.num_heads, cfg.num_kv_heads, cfg.head_dim)
+            else:
+                self._linear(B.normed, W["qkv"], base + 0, B.xa, B.xs, B.qkv)
+                ops.qk_norm_rope_kv(B.qkv, W["q_norm"], W["k_norm"], 1e-6, self.rope, positions, slot_ids, kvc.block_table,
+                                    kvc.k[l], kvc.v[l], cfg.num_heads, cfg.num_kv_heads, cfg.head_dim, q_out=B.q)
             ops.paged_attn(B.q, kvc.k[l], kvc.v[l], kvc.block_table, ctx_len, slot_ids=slot_ids,
                            softmax_scale=1.0 / math.sqrt(cfg.head_dim), splits=splits, out=B.attn, workspace=B.attn_ws,
                            stats=st if splits > 1 else None, stat_slot=base + 1)
@@ -260,19 +268,25 @@ class I64MoEModel:
                 record[f"l{l}.attn_out"] = attn2d.clone()
             if splits == 1:
                 ops.rows_minmax(attn2d, st, slot_base=base + 1)
-            self._linear(attn2d, W["o"], base + 1, B.xa, B.xs, B.o)
+            # h += o_proj(attn) ; normed = ln2(h) ; statistics of the Linear call(s) that read normed
             if ep_plans is not None:
-                # expert parallel: the layer object gathers its own statistics; its output joins the residual stream
-                ops.fused_residual_norm(B.h, W["ln2"], eps, add=B.o, h_out=B.h, normed=B.normed)
+                ln2_slots, ln2_stats = None, None          # the expert-parallel layer gathers its own statistics
+            elif cfg.is_moe:
+                ln2_slots, ln2_stats = B.plan.tok_slots[l], st   # the shared call and every (route, expert) bucket call
+            else:
+                ln2_slots, ln2_stats = None, st
+            # (folding this residual + norm into the o projection through a last-arriving workgroup per row block was built and
+            # measured: the tail's device-coherent round trip costs more than the kernel boundary it removes)
+            self._linear(attn2d, W["o"], base + 1, B.xa, B.xs, B.o)
+            ops.fused_residual_norm(B.h, W["ln2"], eps, add=B.o, h_out=B.h, normed=B.normed, slots=ln2_slots, slot_base=base + 2,
+                                    stats=ln2_stats)
+            if ep_plans is not None:
                 moe_out = self.ep_layers[l].forward(B.normed, None, plan=ep_plans[l])
                 nxt = self.layers[l + 1]["ln1"] if l + 1 < cfg.num_layers else self.final_norm
                 last = l + 1 == cfg.num_layers
                 ops.fused_residual_norm(B.h, nxt, eps, add=moe_out, h_out=B.h, normed=B.normed, slot_base=base + spl,
                                         stats=None if last else st)
             elif cfg.is_moe:
-                # h += o ; normed = ln2(h) ; statistics for the shared call and for every (route, expert) bucket
-                ops.fused_residual_norm(B.h, W["ln2"], eps, add=B.o, h_out=B.h, normed=B.normed, slots=B.plan.tok_slots[l],
-                                        slot_base=base + 2, stats=st)
                 if record is not None:
                     record[f"l{l}.mlp_in"] = B.normed.clone()
                 self._moe(B, W, l, base)
@@ -285,7 +299,6 @@ class I64MoEModel:
                 if record is not None:
                     record[f"l{l}.out"] = B.h.clone()
             else:
-                ops.fused_residual_norm(B.h, W["ln2"], eps, add=B.o, h_out=B.h, normed=B.normed, slot_base=base + 2, stats=st)
                 if record is not None:
                     record[f"l{l}.mlp_in"] = B.normed.clone()
                 self._linear(B.normed, W["gu"], base + 2, B.xa, B.xs, B.d_inter, epilogue=ops.EPI_SWIGLU, stats_slot=base + 3)

@@ -232,6 +232,15 @@ def gemm_i8_pair(a_desc, b_desc=None):
     call("i64h_gemm_i8_pair", ctypes.addressof(a_desc), ctypes.addressof(b_desc) if b_desc is not None else 0, _stream())
 
 
+def gemm_i8_qkv_rope_kv(desc, q_norm_w, k_norm_w, qk_eps, rope_tab, positions, slot_ids, block_table, k_cache, v_cache, q_out,
+                        num_heads: int, num_kv_heads: int, head_dim: int):
+    """qkv projection (desc: fp32 operand, decode-sized) + QK norm + RoPE + paged-KV write in one launch."""
+    call("i64h_gemm_i8_qkv_rope_kv", ctypes.addressof(desc), ptr(q_norm_w), ptr(k_norm_w), float(qk_eps), ptr(rope_tab), ptr(positions),
+         ptr(slot_ids), ptr(block_table), block_table.shape[1], ptr(q_out), ptr(k_cache), ptr(v_cache), KV_DTYPE_CODE[k_cache.dtype],
+         num_heads, num_kv_heads, head_dim, k_cache.shape[1], _stream())
+    return q_out
+
+
 def gemm_f32(a: torch.Tensor, b: torch.Tensor, a_rows: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk(a, torch.float32, "a"), _chk(b, torch.float32, "b")
     M = a_rows.numel() if a_rows is not None else a.shape[0]
