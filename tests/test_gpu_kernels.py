@@ -92,6 +92,72 @@ def test_gemm_i8_swiglu_and_stats(dev):
     assert lohi[0, 0] == 0 and lohi[0, 1] == 0
 
 
+# ---- row-streaming kernel (>= 1024 rows per group): same contract, operand rows loaded straight into MFMA fragments ----
+@pytest.mark.parametrize("depth", [2, 4])
+@pytest.mark.parametrize("M_,N_,K_,G_", [(5000, 200, 448, 3), (2100, 1024, 1024, 1), (9000, 130, 64, 8), (1024, 128, 1792, 1)])
+def test_gemm_i8_rowstream_exact(dev, M_, N_, K_, G_, depth):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M_ * 3 + N_ + depth)
+    a = torch.randint(-127, 128, (M_, K_), generator=g, dtype=torch.int8)
+    w = torch.randint(-128, 128, (G_, N_, K_), generator=g, dtype=torch.int8)
+    cuts = sorted(torch.randint(0, M_ + 1, (G_ - 1,), generator=g).tolist()) if G_ > 1 else []
+    if G_ > 2:
+        cuts[1] = cuts[0]  # an empty group
+    off = [0] + cuts + [M_]
+    rs = torch.rand(M_, generator=g) + 0.5
+    ws = torch.rand(G_, generator=g) + 0.5
+    ref = torch.empty(M_, N_)
+    for gi in range(G_):
+        s, e = off[gi], off[gi + 1]
+        ref[s:e] = (a[s:e].double() @ w[gi].double().t()).float() * (rs[s:e].unsqueeze(1) * ws[gi])
+    ops.call("i64h_set_gemm_rowstream", depth)
+    try:
+        out = ops.gemm_i8(a.to(dev), rs.to(dev), w.to(dev), ws.to(dev),
+                          group_offsets=torch.tensor(off, dtype=torch.int32, device=dev) if G_ > 1 else None)
+        ops.call("i64h_set_gemm_rowstream", 0)
+        tiled = ops.gemm_i8(a.to(dev), rs.to(dev), w.to(dev), ws.to(dev),
+                            group_offsets=torch.tensor(off, dtype=torch.int32, device=dev) if G_ > 1 else None)
+    finally:
+        ops.call("i64h_set_gemm_rowstream", 4)
+    assert torch.equal(out.cpu(), ref)
+    assert torch.equal(tiled.cpu(), ref)
+
+
+@pytest.mark.parametrize("depth", [2, 4])
+@pytest.mark.parametrize("I_,K_", [(72, 256), (448, 1024)])
+def test_gemm_i8_rowstream_swiglu_and_stats(dev, I_, K_, depth):
+    """silu goes through the hardware exp2 / reciprocal here: a few ulp from torch's, statistics exact on the stored values."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(13 + I_)
+    M_, G_ = 4133, 3
+    a = torch.randint(-127, 128, (M_, K_), generator=g, dtype=torch.int8)
+    w = torch.randint(-128, 128, (G_, 2 * I_, K_), generator=g, dtype=torch.int8)
+    off = [0, 1500, 1500, M_]
+    rs = (torch.rand(M_, generator=g) + 0.5) * 1e-3
+    ws = (torch.rand(G_, generator=g) + 0.5) * 1e-2
+    slot = torch.randint(0, 4, (M_,), generator=g, dtype=torch.int32)
+    ref = torch.empty(M_, I_)
+    for gi in range(G_):
+        s, e = off[gi], off[gi + 1]
+        c = (a[s:e].double() @ w[gi].double().t()).float() * (rs[s:e].unsqueeze(1) * ws[gi])
+        ref[s:e] = torch.nn.functional.silu(c[:, :I_]) * c[:, I_:]
+    stats = ops.stats_alloc(8, dev)
+    ops.stats_reset(stats)
+    ops.call("i64h_set_gemm_rowstream", depth)
+    try:
+        out = ops.gemm_i8(a.to(dev), rs.to(dev), w.to(dev), ws.to(dev), group_offsets=torch.tensor(off, dtype=torch.int32, device=dev),
+                          epilogue=ops.EPI_SWIGLU, row_slot=slot.to(dev), slot_base=2, stats=stats)
+    finally:
+        ops.call("i64h_set_gemm_rowstream", 4)
+    torch.testing.assert_close(out.cpu(), ref, rtol=4e-6, atol=1e-6)
+    _, _, lohi = ops.qparams(stats, 8)
+    lohi, o = lohi.cpu(), out.cpu()
+    for s in range(4):
+        rows = o[slot == s]
+        assert lohi[2 + s, 0] == min(rows.min().item(), 0.0) and lohi[2 + s, 1] == max(rows.max().item(), 0.0)
+    assert lohi[0, 0] == 0 and lohi[0, 1] == 0
+
+
 @pytest.mark.parametrize("M_,K_,G_", [(64, 1024, 1), (130, 448, 4), (7, 160, 2)])
 def test_gemm_i8_fused_quantize_matches_two_step(dev, M_, K_, G_):
     """fp32 operand quantized inside the GEMM (per-row stat slots, gathered rows) == quantize kernel + int8 GEMM, bit for bit;

@@ -166,7 +166,7 @@ if __name__ == "__main__":
     if what in ("gemm", "all"):
         bench_gemm()
     if what in ("gemmp", "all"):
-        for on in (0, 1):
-            ops.call("i64h_set_gemm_stage64", on)
-            print(f"--- 64-byte stages for short K: {on}")
+        for depth in (0, 2, 4):
+            ops.call("i64h_set_gemm_rowstream", depth)
+            print(f"--- row-streaming kernel prefetch depth {depth} (0 = LDS-tiled kernel)")
             bench_gemm_prefill()

@@ -53,6 +53,7 @@ SIGNATURES: Dict[str, str] = {
     "i64h_set_skinny_waves": "i",
     "i64h_debug_set_stamps": "pl",
     "i64h_set_gemm_stage64": "i",
+    "i64h_set_gemm_rowstream": "i",
 }
 _KIND = {"p": _P, "i": _I, "l": _L, "f": _F}
 

@@ -79,6 +79,39 @@ __device__ __forceinline__ int swz64(int row, int chunk) { return row * 64 + ((c
 template <int BKT>
 __device__ __forceinline__ int swzt(int row, int chunk) { return BKT == 128 ? swz(row, chunk) : swz64(row, chunk); }
 
+// Wave-wide search for m-tile mt of a grouped problem: lane i looks at group c0 + i, 64 groups per pass; writes
+// (group or -1, first row, rows in the tile) to s_info.  The grid is an upper bound on the number of m-tiles.
+template <int BM>
+__device__ __forceinline__ void locate_mtile(const GemmI8Args& p, const int mt, const int lane, int* s_info) {
+    int g = -1, row0 = 0, rows = 0, base = 0;
+    const int G = p.group_off ? p.G : 1;
+    for (int c0 = 0; c0 < G && g < 0; c0 += 64) {
+        const int i = c0 + lane;
+        int b = 0, e = 0;
+        if (i < G) {
+            b = p.group_off ? p.group_off[i] : 0;
+            e = p.group_off ? p.group_off[i + 1] : p.M_total;
+        }
+        const int tiles = (e - b + BM - 1) / BM;
+        int incl = tiles;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        const int excl = base + incl - tiles;
+        const unsigned long long hit = __ballot(i < G && mt >= excl && mt < excl + tiles);
+        if (hit) {
+            const int src = __ffsll(hit) - 1;
+            g = c0 + src;
+            row0 = __shfl(b, src) + (mt - __shfl(excl, src)) * BM;
+            rows = min(BM, __shfl(e, src) - row0);
+        }
+        base += __shfl(incl, 63);
+    }
+    if (lane == 0) { s_info[0] = g; s_info[1] = row0; s_info[2] = rows; }
+}
+
 // BKT = K bytes per LDS stage: 128 (two MFMA K steps per barrier, fragment reads software-pipelined) or 64 (one step per
 // barrier, half the LDS and fewer registers: four 128 x 128 workgroups per CU, which is what hides the per-tile prologue
 // and epilogue of short-K problems).
@@ -101,35 +134,7 @@ __device__ __forceinline__ void gemm_i8_body(const GemmI8Args& p, const int bid,
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int n_tiles = (EPI == EPI_SWIGLU) ? ((p.N / 2) + BN / 2 - 1) / (BN / 2) : (p.N + BN - 1) / BN;
     const int mt = bid / n_tiles, nt = bid % n_tiles;
-    if (wid == 0) {  // locate (group, row range) of m-tile mt: lane i looks at group i, 64 groups per pass
-        int g = -1, row0 = 0, rows = 0, base = 0;
-        const int G = p.group_off ? p.G : 1;
-        for (int c0 = 0; c0 < G && g < 0; c0 += 64) {
-            const int i = c0 + lane;
-            int b = 0, e = 0;
-            if (i < G) {
-                b = p.group_off ? p.group_off[i] : 0;
-                e = p.group_off ? p.group_off[i + 1] : p.M_total;
-            }
-            const int tiles = (e - b + BM - 1) / BM;
-            int incl = tiles;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int t = __shfl_up(incl, o);
-                if (lane >= o) incl += t;
-            }
-            const int excl = base + incl - tiles;
-            const unsigned long long hit = __ballot(i < G && mt >= excl && mt < excl + tiles);
-            if (hit) {
-                const int src = __ffsll(hit) - 1;
-                g = c0 + src;
-                row0 = __shfl(b, src) + (mt - __shfl(excl, src)) * BM;
-                rows = min(BM, __shfl(e, src) - row0);
-            }
-            base += __shfl(incl, 63);
-        }
-        if (lane == 0) { s_info[0] = g; s_info[1] = row0; s_info[2] = rows; }
-    }
+    if (wid == 0) locate_mtile<BM>(p, mt, lane, s_info);
     __syncthreads();
     const int g = s_info[0], row0 = s_info[1], rows = s_info[2];
     if (g < 0) return;  // grid is an upper bound on the number of m-tiles
@@ -386,6 +391,235 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void
     const int bid = blockIdx.x;
     if (bid < pp.nblk0) gemm_i8_body<BM, BN, EPI, AQ, 2, 2, BKT>(pp.p[0], xcd_remap(bid, pp.nblk0), smem);
     else gemm_i8_body<BM, BN, EPI, AQ, 2, 2, BKT>(pp.p[1], xcd_remap(bid - pp.nblk0, nblk_total - pp.nblk0), smem);
+}
+
+// ---- prefill-sized problems: activation rows streamed into registers --------------------------------------------------
+// Workgroup = 4 waves, tile 256 rows x 128 columns; wave w owns rows [64w, 64w + 64) and all 128 columns.  A wave loads the
+// MFMA fragments of ITS rows straight from global memory (16 B per lane per 64-byte K step, D steps ahead, no LDS round
+// trip: nobody else needs them); only the weight tile, which the four waves share, goes through LDS (two 8 KB stages,
+// one barrier per step).  Per K step a wave issues 8 ds_read_b128 for 32 MFMAs (the 2 x 2 tile kernel above: 8 for 16,
+// plus staging both operands), and its register budget (128 accumulators + D x 16 operand registers) leaves two
+// workgroups per CU, so one workgroup's epilogue runs under the other's MFMAs.
+// The SwiGLU epilogue evaluates silu through v_exp_f32 / v_rcp_f32 (a few ulp; the exact expf + IEEE divide cost as many
+// VALU cycles per tile as the tile's MFMAs): results differ from the decode-sized kernel's in the last bits only.
+#define RS_BM 256
+#define RS_BN 128
+__device__ __forceinline__ float silu_fast(float g) {
+    const float e = __builtin_amdgcn_exp2f(g * -1.44269504088896341f);
+    return g * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+template <int EPI, int D>
+__device__ __forceinline__ void gemm_i8_rs_body(const GemmI8Args& p, const int bid, char* smem) {
+    static_assert(D % 2 == 0, "the unrolled step index doubles as the LDS stage parity");
+    constexpr int NT = 256, STAGE = RS_BN * 64;
+    int* s_info = (int*)(smem + 2 * STAGE);
+    float* q_scale = (float*)(smem + 2 * STAGE + 16);
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+#define RS_STAMP(i) do { if (p.stamps && tid == 0) p.stamps[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+    RS_STAMP(0);
+    const int fr = lane & 15, fq = lane >> 4;
+    const int I = p.N / 2;
+    const int n_tiles = (EPI == EPI_SWIGLU) ? (I + RS_BN / 2 - 1) / (RS_BN / 2) : (p.N + RS_BN - 1) / RS_BN;
+    const int mt = bid / n_tiles, nt = bid % n_tiles;
+    if (wid == 0) locate_mtile<RS_BM>(p, mt, lane, s_info);
+    __syncthreads();
+    RS_STAMP(1);
+    const int g = __builtin_amdgcn_readfirstlane(s_info[0]);
+    const int row0 = __builtin_amdgcn_readfirstlane(s_info[1]);
+    const int rows = __builtin_amdgcn_readfirstlane(s_info[2]);
+    if (g < 0) return;
+
+    const int K = p.K, KS = K / 64;
+    const char* Abase = (const char*)p.A + (int64_t)row0 * K;
+    const char* Bbase = (const char*)p.B + (int64_t)g * p.N * K;
+    for (int r = tid; r < RS_BM; r += NT) q_scale[r] = r < rows ? p.row_scale[row0 + r] : 0.0f;  // published by the prologue's barrier
+
+    // operand fragments: lane (fr, fq) of row fragment i holds bytes [16 fq, 16 fq + 16) of row 64 wid + 16 i + fr of each K step;
+    // rows past the tile's end read the last valid row (their results are never stored)
+    uint32_t a_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_off[i] = (uint32_t)min(wid * 64 + i * 16 + fr, rows - 1) * (uint32_t)K + fq * 16;
+    // weight staging: thread -> 16-B chunk ld_c of tile rows ld_r and ld_r + 64 (EPI_SWIGLU: a gate column and its up partner)
+    const int ld_c = tid & 3, ld_r = tid >> 2;
+    uint32_t b_off[2];
+    int b_lds[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int col;
+        if (EPI == EPI_SWIGLU) {
+            const int j = min(nt * (RS_BN / 2) + ld_r, I - 1);
+            col = i ? I + j : j;
+        } else {
+            col = min(nt * RS_BN + ld_r + 64 * i, p.N - 1);
+        }
+        b_off[i] = (uint32_t)col * (uint32_t)K + ld_c * 16;
+        b_lds[i] = swz64(ld_r + 64 * i, ld_c);
+    }
+
+    v4i acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (v4i){0, 0, 0, 0};
+    v4i ra[D][4], rb[2][2];
+    // Every load below is unconditional (steps past the end re-read the last step; their weights are staged as zeros): a load
+    // under a branch would make the compiler's counted vmcnt waits fall back to draining the queue on every step.
+    const int klast = KS - 1;
+    auto aload = [&](int u, int k) {
+        const int kk = min(k, klast);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[u][i] = *(const v4i*)(Abase + (int64_t)kk * 64 + a_off[i]);
+    };
+    auto bload = [&](int s, int k) {
+        const int kk = min(k, klast);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) rb[s][i] = *(const v4i*)(Bbase + (int64_t)kk * 64 + b_off[i]);
+    };
+    auto bstore = [&](int s, int k) {  // weights of step k into stage k & 1 (== s); zeros past the end of K
+        const bool in = k < KS;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *(v4i*)(smem + s * STAGE + b_lds[i]) = in ? rb[s][i] : (v4i){0, 0, 0, 0};
+    };
+
+    // step k: the weights of step k are in stage k & 1; stage (k + 1) & 1 is filled from the registers loaded two steps ago,
+    // which are then re-requested for step k + 3; the operand registers of step k are re-requested for step k + D after its
+    // MFMAs.  The prologue issues the same sequence for steps -max(D, 3) .. -1 minus the MFMAs, so that the number of
+    // younger loads behind each register is the same on loop entry as around the back edge.
+    constexpr int PRE = D > 3 ? D : 3;
+#pragma unroll
+    for (int k = -PRE; k < 0; ++k) {
+        if (k + 1 == 0) bstore(0, 0);
+        if (k + 3 >= 0) bload((k + 3) & 1, k + 3);
+        if (k + D >= 0) aload(k + D, k + D);
+    }
+    __syncthreads();
+    RS_STAMP(2);
+    const int KSP = (KS + D - 1) / D * D;
+    for (int k0 = 0; k0 < KSP; k0 += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            const int k = k0 + u, cur = u & 1;
+            v4i bf[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bf[j] = *(const v4i*)(smem + cur * STAGE + swz64(j * 16 + fr, fq));
+            bstore(cur ^ 1, k + 1);
+            bload(cur ^ 1, k + 3);
+            // transposed product: the weight fragment is the row operand, so a lane ends up with 4 consecutive output columns
+            // of one output row (D[n = 4 fq + reg][m = fr]) and stores them as one 16-byte word
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bf[j], ra[u][i], acc[i][j], 0, 0, 0);
+            aload(u, k + D);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: fragment (i, j): row 16 i + fr, columns 16 j + 4 fq + (0..3) ----
+    RS_STAMP(3);
+    const float ws = p.w_scale[g];
+    if (EPI == EPI_STORE) {
+        const bool vec = (p.N & 3) == 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = wid * 64 + i * 16 + fr;
+            if (r >= rows) continue;
+            const float qs = q_scale[r], m = qs * ws;
+            float* crow = p.C + (int64_t)(row0 + r) * p.N;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c0 = nt * RS_BN + j * 16 + fq * 4;
+                float v[4];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    v[reg] = (float)acc[i][j][reg] * (p.col_scale ? qs * p.col_scale[(int64_t)g * p.N + min(c0 + reg, p.N - 1)] : m);
+                if (vec && c0 + 3 < p.N) {
+                    *(float4*)(crow + c0) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg)
+                        if (c0 + reg < p.N) crow[c0 + reg] = v[reg];
+                }
+            }
+        }
+    } else {
+        uint32_t* tab_lo = (uint32_t*)smem;  // the weight stages are free now
+        uint32_t* tab_hi = tab_lo + I64H_STAT_TAB;
+        const bool st = p.want_stats != 0;
+        if (st) {
+            for (int i = tid; i < I64H_STAT_TAB; i += NT) { tab_lo[i] = I64H_ORDERED_ZERO; tab_hi[i] = I64H_ORDERED_ZERO; }
+            __syncthreads();
+        }
+        const bool vec = (I & 3) == 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = wid * 64 + i * 16 + fr;
+            const bool rok = r < rows;
+            const float m = rok ? q_scale[r] * ws : 0.0f;
+            float* crow = p.C + (int64_t)(row0 + (rok ? r : 0)) * I;
+            float a = 0.0f, b = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c0 = nt * (RS_BN / 2) + j * 16 + fq * 4;
+                float v[4];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const float gate = (float)acc[i][j][reg] * m;
+                    const float up = (float)acc[i][j + 4][reg] * m;
+                    v[reg] = silu_fast(gate) * up;
+                }
+                if (rok) {
+                    if (vec && c0 + 3 < I) {
+                        *(float4*)(crow + c0) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) { a = fminf(a, v[reg]); b = fmaxf(b, v[reg]); }
+                    } else {
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg)
+                            if (c0 + reg < I) { crow[c0 + reg] = v[reg]; a = fminf(a, v[reg]); b = fmaxf(b, v[reg]); }
+                    }
+                }
+            }
+            if (st) {
+                a = fminf(a, __shfl_xor(a, 16)); b = fmaxf(b, __shfl_xor(b, 16));
+                a = fminf(a, __shfl_xor(a, 32)); b = fmaxf(b, __shfl_xor(b, 32));
+                if (fq == 0 && rok) {
+                    const int rel = p.out_row_slot ? p.out_row_slot[row0 + r] : 0;
+                    if (rel >= 0 && rel < I64H_STAT_TAB) {
+                        atomicMin(&tab_lo[rel], f32_to_ordered(a));
+                        atomicMax(&tab_hi[rel], f32_to_ordered(b));
+                    } else {
+                        stat_update(p.stats, p.out_slot_base + rel, bid, a, b);
+                    }
+                }
+            }
+        }
+        if (st) {
+            __syncthreads();
+            for (int i = tid; i < I64H_STAT_TAB; i += NT)
+                if (tab_lo[i] != I64H_ORDERED_ZERO || tab_hi[i] != I64H_ORDERED_ZERO) {
+                    uint32_t* q = p.stats + (int64_t)(p.out_slot_base + i) * I64H_SLOT_WORDS + 2 * (bid & (I64H_NSHARD - 1));
+                    atomicMin(q, tab_lo[i]);
+                    atomicMax(q + 1, tab_hi[i]);
+                }
+        }
+    }
+    RS_STAMP(4);
+    if (p.stamps) {  // diagnostics only: when the tile's stores have left the wave
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        RS_STAMP(5);
+    }
+#undef RS_STAMP
+}
+
+template <int EPI, int D>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_i8_rs_kernel(GemmI8Pair pp, int nblk_total) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bid = blockIdx.x;
+    if (bid < pp.nblk0) gemm_i8_rs_body<EPI, D>(pp.p[0], xcd_remap(bid, pp.nblk0), smem);
+    else gemm_i8_rs_body<EPI, D>(pp.p[1], xcd_remap(bid - pp.nblk0, nblk_total - pp.nblk0), smem);
 }
 
 // ---- decode-sized problems: weight-streaming kernel with the quantizer in front ---------------------------------------
@@ -906,6 +1140,31 @@ static int launch_pair(const i64h_gemm_desc* a, const i64h_gemm_desc* b, hipStre
     return 0;
 }
 
+static int g_rowstream = 4;  // tuning knob: operand prefetch depth of the row-streaming kernel (2 or 4); 0 = kernel off
+
+template <int EPI, int D>
+static int launch_rs(const i64h_gemm_desc* a, const i64h_gemm_desc* b, hipStream_t st) {
+    GemmI8Pair pp;
+    pp.p[0] = to_args(a);
+    pp.p[1] = to_args(b ? b : a);
+    pp.nblk0 = nblocks_of<RS_BM, RS_BN>(a);
+    const int total = pp.nblk0 + (b ? nblocks_of<RS_BM, RS_BN>(b) : 0);
+    if (total == 0) return 0;
+    if (g_stamps && g_stamp_cur + total <= g_stamp_cap) {
+        pp.p[0].stamps = pp.p[1].stamps = g_stamps + g_stamp_cur * 8;
+        g_stamp_cur += total;
+    }
+    const size_t lds = 2 * RS_BN * 64 + 16 + RS_BM * 4;
+    hipLaunchKernelGGL((gemm_i8_rs_kernel<EPI, D>), dim3((unsigned)total), dim3(256), lds, st, pp, total);
+    I64H_CHECK_LAUNCH();
+    return 0;
+}
+
+static bool rs_ok(const i64h_gemm_desc* d) {
+    // offsets inside a tile / a group's weight matrix are 32-bit; row counts that keep 256-row tiles mostly full
+    return !d->a_fp32 && d->K % 64 == 0 && (int64_t)d->N * d->K < (1ll << 31) && d->M_total / d->num_groups >= 1024;
+}
+
 static int skinny_blocks(const i64h_gemm_desc* d, int bnb) {
     const int G = d->group_offsets ? d->num_groups : 1;
     const int nout = d->epilogue == EPI_SWIGLU ? d->N / 2 : d->N;
@@ -961,6 +1220,14 @@ int i64h_set_gemm_stage64(int32_t on) {
     return 0;
 }
 
+// tuning knob: operand prefetch depth (2 or 4 K steps; default 4) of the row-streaming kernel that serves int8 operands with
+// at least 1024 rows per group; 0 = use the LDS-tiled kernel for them too
+int i64h_set_gemm_rowstream(int32_t depth) {
+    I64H_CHECK_ARG(depth == 0 || depth == 2 || depth == 4, "set_gemm_rowstream: %d not in {0,2,4}", depth);
+    g_rowstream = depth;
+    return 0;
+}
+
 // diagnostics: device buffer of 8 uint64 per workgroup that the weight-streaming kernel fills with s_memtime stamps at its
 // phase boundaries (0 entry, 1 weights requested, 2 row parameters ready, 3 operand rows quantized, 4 K loop done, 5 stores
 // drained, 6 tile located, 7 statistics requested); successive launches append (launch i's workgroups follow launch i-1's) until the capacity is used up; NULL
@@ -993,6 +1260,10 @@ int i64h_gemm_i8_pair(const i64h_gemm_desc* a, const i64h_gemm_desc* b, void* st
     hipStream_t st = (hipStream_t)stream;
     if (skinny_ok(a) && (!b || skinny_ok(b)))
         return a->epilogue == EPI_STORE ? launch_skinny_nw<EPI_STORE>(a, b, st) : launch_skinny_nw<EPI_SWIGLU>(a, b, st);
+    if (g_rowstream && rs_ok(a) && (!b || rs_ok(b))) {
+        if (a->epilogue == EPI_STORE) return g_rowstream == 2 ? launch_rs<EPI_STORE, 2>(a, b, st) : launch_rs<EPI_STORE, 4>(a, b, st);
+        return g_rowstream == 2 ? launch_rs<EPI_SWIGLU, 2>(a, b, st) : launch_rs<EPI_SWIGLU, 4>(a, b, st);
+    }
     const int64_t rows = a->M_total / a->num_groups;
     const bool big = !a->a_fp32 && rows >= 256;  // fp32 operands are meant for small M (quantized per workgroup)
     // short K: a tile's K loop is a handful of steps, so occupancy (4 workgroups per CU) hides the per-tile prologue and
