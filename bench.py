@@ -234,7 +234,7 @@ def main():
         g_ms = sum(g_ms) / len(g_ms)
         g_ops = 2.0 * R * (2 * cfg.expert_inter) * cfg.hidden_size
         tops = g_ops / (g_ms * 1e-3) / 1e12
-        mfma = {"bound": "mfma", "kernel": "gemm_i8_kernel<128,128,SWIGLU> grouped expert gate_up, one prefill chunk",
+        mfma = {"bound": "mfma", "kernel": "gemm_i8_rs_kernel<SWIGLU> grouped expert gate_up, one prefill chunk",
                 "achieved": round(tops, 1), "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s", "frac": round(tops / MFMA_I8_PEAK_TOPS, 4),
                 "traffic": None, "avg_launch_ms": round(g_ms, 4), "algorithmic_ops_per_launch": g_ops, "rows": R,
                 "groups": cfg.num_experts, "N": 2 * cfg.expert_inter, "K": cfg.hidden_size}

@@ -93,9 +93,9 @@ def test_gemm_i8_swiglu_and_stats(dev):
 
 
 # ---- row-streaming kernel (>= 1024 rows per group): same contract, operand rows loaded straight into MFMA fragments ----
-@pytest.mark.parametrize("depth", [2, 4])
+@pytest.mark.parametrize("depth", [2])
 @pytest.mark.parametrize("M_,N_,K_,G_", [(5000, 200, 448, 3), (2100, 1024, 1024, 1), (9000, 130, 64, 8), (1024, 128, 1792, 1)])
-def test_gemm_i8_rowstream_exact(dev, M_, N_, K_, G_, depth):
+def test_gemm_i8_rowstream_exact(dev, M_, N_, K_, G_, depth):  # depth: the knob's mode (2 = every epilogue)
     ops = _ops()
     g = torch.Generator().manual_seed(M_ * 3 + N_ + depth)
     a = torch.randint(-127, 128, (M_, K_), generator=g, dtype=torch.int8)
@@ -118,12 +118,12 @@ def test_gemm_i8_rowstream_exact(dev, M_, N_, K_, G_, depth):
         tiled = ops.gemm_i8(a.to(dev), rs.to(dev), w.to(dev), ws.to(dev),
                             group_offsets=torch.tensor(off, dtype=torch.int32, device=dev) if G_ > 1 else None)
     finally:
-        ops.call("i64h_set_gemm_rowstream", 4)
+        ops.call("i64h_set_gemm_rowstream", 1)
     assert torch.equal(out.cpu(), ref)
     assert torch.equal(tiled.cpu(), ref)
 
 
-@pytest.mark.parametrize("depth", [2, 4])
+@pytest.mark.parametrize("depth", [1, 2])
 @pytest.mark.parametrize("I_,K_", [(72, 256), (448, 1024)])
 def test_gemm_i8_rowstream_swiglu_and_stats(dev, I_, K_, depth):
     """silu goes through the hardware exp2 / reciprocal here: a few ulp from torch's, statistics exact on the stored values."""
@@ -148,7 +148,7 @@ def test_gemm_i8_rowstream_swiglu_and_stats(dev, I_, K_, depth):
         out = ops.gemm_i8(a.to(dev), rs.to(dev), w.to(dev), ws.to(dev), group_offsets=torch.tensor(off, dtype=torch.int32, device=dev),
                           epilogue=ops.EPI_SWIGLU, row_slot=slot.to(dev), slot_base=2, stats=stats)
     finally:
-        ops.call("i64h_set_gemm_rowstream", 4)
+        ops.call("i64h_set_gemm_rowstream", 1)
     torch.testing.assert_close(out.cpu(), ref, rtol=4e-6, atol=1e-6)
     _, _, lohi = ops.qparams(stats, 8)
     lohi, o = lohi.cpu(), out.cpu()

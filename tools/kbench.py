@@ -151,7 +151,7 @@ if __name__ == "__main__":
             bench_gemm()
         sys.exit(0)
     if what == "gemm1":  # one shape, one variant: python tools/kbench.py gemm1 <variant> <name substring> (for counter passes)
-        ops.call("i64h_set_gemm_stage64", int(sys.argv[2]))
+        ops.call("i64h_set_gemm_rowstream", int(sys.argv[2]))  # variant: 0 = LDS-tiled kernel, 2 = row-streaming kernel
         bench_gemm_prefill(sys.argv[3])
         sys.exit(0)
     if what == "attnp":
@@ -166,7 +166,15 @@ if __name__ == "__main__":
     if what in ("gemm", "all"):
         bench_gemm()
     if what in ("gemmp", "all"):
-        for depth in (0, 2, 4):
-            ops.call("i64h_set_gemm_rowstream", depth)
-            print(f"--- row-streaming kernel prefetch depth {depth} (0 = LDS-tiled kernel)")
-            bench_gemm_prefill()
+        # python tools/kbench.py gemmp [name substring]: LDS-tiled kernel, then the row-streaming kernel per (depth, grid, stagger)
+        only = sys.argv[2] if len(sys.argv) > 2 else None
+        ops.call("i64h_set_gemm_rowstream", 0)
+        print("--- LDS-tiled kernel")
+        bench_gemm_prefill(only)
+        for wgs, stagger in ((1 << 20, 0), (512, 0), (512, 8000)):
+            ops.call("i64h_set_gemm_rowstream", 2)
+            ops.call("i64h_set_gemm_rs_grid", wgs, stagger)
+            print(f"--- row-streaming kernel: grid <= {wgs} workgroups, stagger {stagger} cycles")
+            bench_gemm_prefill(only)
+        ops.call("i64h_set_gemm_rowstream", 1)
+        ops.call("i64h_set_gemm_rs_grid", 512, 0)

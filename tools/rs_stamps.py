@@ -1,13 +1,12 @@
 """Phase timing inside the row-streaming int8 GEMM (s_memtime stamps) on the prefill-shaped problems of tools/kbench.py gemmp.
-python tools/rs_stamps.py [depth]  -> per shape: workgroups, median cycles per phase, and the launch's span."""
+python tools/rs_stamps.py  -> per shape: workgroups, median cycles per phase, and the launch's span."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vllm_i64_amd import ops
 
 dev = torch.device("cuda:0")
-depth = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-ops.call("i64h_set_gemm_rowstream", depth)
+ops.call("i64h_set_gemm_rowstream", 2)
 lib = ops._lib.load()
 shapes = [("expert gate_up", 32768, 896, 1024, 8, 1), ("expert down", 32768, 1024, 448, 8, 0), ("shared gate_up", 16384, 3584, 1024, 1, 1),
           ("qkv", 16384, 1536, 1024, 1, 0), ("square 8192", 8192, 8192, 8192, 1, 0)]

@@ -54,6 +54,7 @@ SIGNATURES: Dict[str, str] = {
     "i64h_debug_set_stamps": "pl",
     "i64h_set_gemm_stage64": "i",
     "i64h_set_gemm_rowstream": "i",
+    "i64h_set_gemm_rs_grid": "ii",
 }
 _KIND = {"p": _P, "i": _I, "l": _L, "f": _F}
 

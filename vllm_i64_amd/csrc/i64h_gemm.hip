@@ -398,75 +398,108 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void
 // MFMA fragments of ITS rows straight from global memory (16 B per lane per 64-byte K step, D steps ahead, no LDS round
 // trip: nobody else needs them); only the weight tile, which the four waves share, goes through LDS (two 8 KB stages,
 // one barrier per step).  Per K step a wave issues 8 ds_read_b128 for 32 MFMAs (the 2 x 2 tile kernel above: 8 for 16,
-// plus staging both operands), and its register budget (128 accumulators + D x 16 operand registers) leaves two
-// workgroups per CU, so one workgroup's epilogue runs under the other's MFMAs.
+// plus staging both operands), and its register budget (128 accumulators + D x 16 operand registers, D = 2) leaves
+// two workgroups per CU.
+// The product is formed transposed (weight fragment = row operand): a lane ends up with 4 consecutive output columns of
+// one output row and stores them as one 16-byte word.
+// Workgroups are persistent: workgroup w runs tiles w, w + grid, ... (the grid is sized so that every workgroup gets the
+// same number of tiles), all of them located once at the start, and the first loads of the next tile are issued before
+// the epilogue of the current one.  Measured per tile before that: 2.8 k cycles locating it, 6 k waiting for its first
+// loads, 31 k in the K loop (the operand stream out of L2, about 33 B/clk per CU, is what paces it) and 11-20 k in the
+// epilogue, with every workgroup of the chip in the same phase at the same time.
 // The SwiGLU epilogue evaluates silu through v_exp_f32 / v_rcp_f32 (a few ulp; the exact expf + IEEE divide cost as many
 // VALU cycles per tile as the tile's MFMAs): results differ from the decode-sized kernel's in the last bits only.
 #define RS_BM 256
 #define RS_BN 128
+#define RS_MAXR 16  // tiles per workgroup the launch may assign
 __device__ __forceinline__ float silu_fast(float g) {
     const float e = __builtin_amdgcn_exp2f(g * -1.44269504088896341f);
     return g * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 template <int EPI, int D>
-__device__ __forceinline__ void gemm_i8_rs_body(const GemmI8Args& p, const int bid, char* smem) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_i8_rs_kernel(GemmI8Pair pp, int nblk_total, int stagger) {
     static_assert(D % 2 == 0, "the unrolled step index doubles as the LDS stage parity");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT = 256, STAGE = RS_BN * 64;
-    int* s_info = (int*)(smem + 2 * STAGE);
-    float* q_scale = (float*)(smem + 2 * STAGE + 16);
+    int* s_info = (int*)(smem + 2 * STAGE);  // [RS_MAXR][4]: group (-1: no tile), first row, rows, n-tile | problem << 30
+    uint32_t* tab_lo = (uint32_t*)(smem + 2 * STAGE + RS_MAXR * 16);
+    uint32_t* tab_hi = tab_lo + I64H_STAT_TAB;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-#define RS_STAMP(i) do { if (p.stamps && tid == 0) p.stamps[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-    RS_STAMP(0);
     const int fr = lane & 15, fq = lane >> 4;
-    const int I = p.N / 2;
-    const int n_tiles = (EPI == EPI_SWIGLU) ? (I + RS_BN / 2 - 1) / (RS_BN / 2) : (p.N + RS_BN - 1) / RS_BN;
-    const int mt = bid / n_tiles, nt = bid % n_tiles;
-    if (wid == 0) locate_mtile<RS_BM>(p, mt, lane, s_info);
+    const int nwg = gridDim.x, w = blockIdx.x;
+    unsigned long long* stamps = pp.p[0].stamps;
+#define RS_STAMP(i) do { if (stamps && tid == 0) stamps[(int64_t)w * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+    RS_STAMP(0);
+    const int rounds = (nblk_total + nwg - 1) / nwg;
+    // tiles in index order are m-major; the workgroups of one XCD (ids congruent mod 8) take a contiguous run of every round,
+    // so the tiles that share operand rows or weight columns meet in that XCD's L2
+    const int slot = (nwg & 7) == 0 ? (w & 7) * (nwg >> 3) + (w >> 3) : w;
+    for (int r = wid; r < rounds; r += 4) {
+        int* info = s_info + r * 4;
+        const int t = r * nwg + slot;
+        if (t < nblk_total) {
+            const int which = t >= pp.nblk0;
+            const GemmI8Args& p = pp.p[which];
+            const int tl = which ? t - pp.nblk0 : t;
+            const int n_tiles = (EPI == EPI_SWIGLU) ? (p.N / 2 + RS_BN / 2 - 1) / (RS_BN / 2) : (p.N + RS_BN - 1) / RS_BN;
+            locate_mtile<RS_BM>(p, tl / n_tiles, lane, info);
+            if (lane == 0) info[3] = (tl % n_tiles) | (which << 30);
+        } else if (lane == 0) {
+            info[0] = -1; info[1] = 0; info[2] = 0; info[3] = 0;
+        }
+    }
+    if (stagger > 0 && w >= (nwg >> 1)) {  // tuning aid: the second half of the grid starts late, so that the two workgroups of a CU run different phases
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while ((long long)(__builtin_amdgcn_s_memtime() - t0) < stagger) __builtin_amdgcn_s_sleep(8);
+    }
     __syncthreads();
     RS_STAMP(1);
-    const int g = __builtin_amdgcn_readfirstlane(s_info[0]);
-    const int row0 = __builtin_amdgcn_readfirstlane(s_info[1]);
-    const int rows = __builtin_amdgcn_readfirstlane(s_info[2]);
-    if (g < 0) return;
 
-    const int K = p.K, KS = K / 64;
-    const char* Abase = (const char*)p.A + (int64_t)row0 * K;
-    const char* Bbase = (const char*)p.B + (int64_t)g * p.N * K;
-    for (int r = tid; r < RS_BM; r += NT) q_scale[r] = r < rows ? p.row_scale[row0 + r] : 0.0f;  // published by the prologue's barrier
-
-    // operand fragments: lane (fr, fq) of row fragment i holds bytes [16 fq, 16 fq + 16) of row 64 wid + 16 i + fr of each K step;
-    // rows past the tile's end read the last valid row (their results are never stored)
-    uint32_t a_off[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a_off[i] = (uint32_t)min(wid * 64 + i * 16 + fr, rows - 1) * (uint32_t)K + fq * 16;
     // weight staging: thread -> 16-B chunk ld_c of tile rows ld_r and ld_r + 64 (EPI_SWIGLU: a gate column and its up partner)
     const int ld_c = tid & 3, ld_r = tid >> 2;
-    uint32_t b_off[2];
-    int b_lds[2];
+    const int b_lds[2] = {swz64(ld_r, ld_c), swz64(ld_r + 64, ld_c)};
+
+    // ---- what the loads of a tile need (re-pointed at the next tile while the epilogue of the current one runs) ----
+    const char* Abase = nullptr;
+    const char* Bbase = nullptr;
+    uint32_t a_off[4], b_off[2];
+    int KS = 0, klast = 0;
+    auto aim = [&](int r) {
+        const int* info = s_info + r * 4;
+        const int g = __builtin_amdgcn_readfirstlane(info[0]);
+        const int row0 = __builtin_amdgcn_readfirstlane(info[1]);
+        const int rows = __builtin_amdgcn_readfirstlane(info[2]);
+        const int x = __builtin_amdgcn_readfirstlane(info[3]);
+        const GemmI8Args& p = pp.p[x >> 30];
+        const int nt = x & 0xffff, K = p.K, I = p.N / 2;
+        // no tile (the grid is an upper bound): zero K steps on row 0 / column 0, nothing stored
+        KS = g >= 0 ? K / 64 : 0;
+        klast = max(KS - 1, 0);
+        Abase = (const char*)p.A + (int64_t)row0 * K;
+        Bbase = (const char*)p.B + (int64_t)max(g, 0) * p.N * K;
+        // operand fragments: lane (fr, fq) of row fragment i holds bytes [16 fq, 16 fq + 16) of row 64 wid + 16 i + fr of each
+        // K step; rows past the tile's end read its last row (their results are never stored)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int col;
-        if (EPI == EPI_SWIGLU) {
-            const int j = min(nt * (RS_BN / 2) + ld_r, I - 1);
-            col = i ? I + j : j;
-        } else {
-            col = min(nt * RS_BN + ld_r + 64 * i, p.N - 1);
+        for (int i = 0; i < 4; ++i) a_off[i] = (uint32_t)max(min(wid * 64 + i * 16 + fr, rows - 1), 0) * (uint32_t)K + fq * 16;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int col;
+            if (EPI == EPI_SWIGLU) {
+                const int j = min(nt * (RS_BN / 2) + ld_r, I - 1);
+                col = i ? I + j : j;
+            } else {
+                col = min(nt * RS_BN + ld_r + 64 * i, p.N - 1);
+            }
+            b_off[i] = (uint32_t)col * (uint32_t)K + ld_c * 16;
         }
-        b_off[i] = (uint32_t)col * (uint32_t)K + ld_c * 16;
-        b_lds[i] = swz64(ld_r + 64 * i, ld_c);
-    }
+    };
 
     v4i acc[4][8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = (v4i){0, 0, 0, 0};
     v4i ra[D][4], rb[2][2];
     // Every load below is unconditional (steps past the end re-read the last step; their weights are staged as zeros): a load
     // under a branch would make the compiler's counted vmcnt waits fall back to draining the queue on every step.
-    const int klast = KS - 1;
     auto aload = [&](int u, int k) {
         const int kk = min(k, klast);
 #pragma unroll
@@ -482,144 +515,173 @@ __device__ __forceinline__ void gemm_i8_rs_body(const GemmI8Args& p, const int b
 #pragma unroll
         for (int i = 0; i < 2; ++i) *(v4i*)(smem + s * STAGE + b_lds[i]) = in ? rb[s][i] : (v4i){0, 0, 0, 0};
     };
-
     // step k: the weights of step k are in stage k & 1; stage (k + 1) & 1 is filled from the registers loaded two steps ago,
     // which are then re-requested for step k + 3; the operand registers of step k are re-requested for step k + D after its
-    // MFMAs.  The prologue issues the same sequence for steps -max(D, 3) .. -1 minus the MFMAs, so that the number of
-    // younger loads behind each register is the same on loop entry as around the back edge.
+    // MFMAs.  A tile's first loads are issued as the same sequence for steps -max(D, 3) .. -1 minus the MFMAs, so that the
+    // number of younger loads behind each register is at least what it is around the back edge; the last of these steps
+    // (it writes LDS) runs after the previous tile's epilogue, the others before it.
     constexpr int PRE = D > 3 ? D : 3;
+    auto pre_early = [&]() {
 #pragma unroll
-    for (int k = -PRE; k < 0; ++k) {
-        if (k + 1 == 0) bstore(0, 0);
-        if (k + 3 >= 0) bload((k + 3) & 1, k + 3);
-        if (k + D >= 0) aload(k + D, k + D);
-    }
-    __syncthreads();
-    RS_STAMP(2);
-    const int KSP = (KS + D - 1) / D * D;
-    for (int k0 = 0; k0 < KSP; k0 += D) {
-#pragma unroll
-        for (int u = 0; u < D; ++u) {
-            const int k = k0 + u, cur = u & 1;
-            v4i bf[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) bf[j] = *(const v4i*)(smem + cur * STAGE + swz64(j * 16 + fr, fq));
-            bstore(cur ^ 1, k + 1);
-            bload(cur ^ 1, k + 3);
-            // transposed product: the weight fragment is the row operand, so a lane ends up with 4 consecutive output columns
-            // of one output row (D[n = 4 fq + reg][m = fr]) and stores them as one 16-byte word
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bf[j], ra[u][i], acc[i][j], 0, 0, 0);
-            aload(u, k + D);
-            __syncthreads();
+        for (int k = -PRE; k < -1; ++k) {
+            if (k + 3 >= 0) bload((k + 3) & 1, k + 3);
+            if (k + D >= 0) aload(k + D, k + D);
         }
-    }
+    };
+    auto pre_late = [&]() {
+        bstore(0, 0);
+        bload(0, 2);
+        aload(D - 1, D - 1);
+    };
 
-    // ---- epilogue: fragment (i, j): row 16 i + fr, columns 16 j + 4 fq + (0..3) ----
-    RS_STAMP(3);
-    const float ws = p.w_scale[g];
-    if (EPI == EPI_STORE) {
-        const bool vec = (p.N & 3) == 0;
+    aim(0);
+    pre_early();
+    for (int r = 0; r < rounds; ++r) {
+        // ---- what the epilogue of this tile needs ----
+        const int* info = s_info + r * 4;
+        const int g = __builtin_amdgcn_readfirstlane(info[0]);
+        const int row0 = __builtin_amdgcn_readfirstlane(info[1]);
+        const int rows = __builtin_amdgcn_readfirstlane(info[2]);
+        const int x = __builtin_amdgcn_readfirstlane(info[3]);
+        const GemmI8Args& p = pp.p[x >> 30];
+        const int nt = x & 0xffff, I = p.N / 2;
+        const int t = r * nwg + slot;  // statistics shard
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = (v4i){0, 0, 0, 0};
+        pre_late();
+        // row scales and statistics slots of the lane's four output rows: requested here, used in the epilogue (a load issued
+        // there would sit behind the next tile's first loads in the in-order queue)
+        float qs[4];
+        int rel[4];
+        const int32_t* slot_of = p.out_row_slot ? p.out_row_slot : (const int32_t*)p.row_scale;  // null: any readable word, unused
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int r = wid * 64 + i * 16 + fr;
-            if (r >= rows) continue;
-            const float qs = q_scale[r], m = qs * ws;
-            float* crow = p.C + (int64_t)(row0 + r) * p.N;
+            const int rr = row0 + max(min(wid * 64 + i * 16 + fr, rows - 1), 0);
+            qs[i] = p.row_scale[rr];
+            rel[i] = (EPI == EPI_SWIGLU) ? slot_of[rr] : 0;
+        }
+        __syncthreads();
+        if (r == 0) RS_STAMP(2);
+        const int KSP = (KS + D - 1) / D * D;
+        for (int k0 = 0; k0 < KSP; k0 += D) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int c0 = nt * RS_BN + j * 16 + fq * 4;
-                float v[4];
+            for (int u = 0; u < D; ++u) {
+                const int k = k0 + u, cur = u & 1;
+                v4i bf[8];
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg)
-                    v[reg] = (float)acc[i][j][reg] * (p.col_scale ? qs * p.col_scale[(int64_t)g * p.N + min(c0 + reg, p.N - 1)] : m);
-                if (vec && c0 + 3 < p.N) {
-                    *(float4*)(crow + c0) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
+                for (int j = 0; j < 8; ++j) bf[j] = *(const v4i*)(smem + cur * STAGE + swz64(j * 16 + fr, fq));
+                bstore(cur ^ 1, k + 1);
+                bload(cur ^ 1, k + 3);
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg)
-                        if (c0 + reg < p.N) crow[c0 + reg] = v[reg];
-                }
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bf[j], ra[u][i], acc[i][j], 0, 0, 0);
+                aload(u, k + D);
+                __syncthreads();
             }
         }
-    } else {
-        uint32_t* tab_lo = (uint32_t*)smem;  // the weight stages are free now
-        uint32_t* tab_hi = tab_lo + I64H_STAT_TAB;
-        const bool st = p.want_stats != 0;
-        if (st) {
-            for (int i = tid; i < I64H_STAT_TAB; i += NT) { tab_lo[i] = I64H_ORDERED_ZERO; tab_hi[i] = I64H_ORDERED_ZERO; }
-            __syncthreads();
+        if (r == 0) RS_STAMP(3);
+        if (r + 1 < rounds) {
+            aim(r + 1);
+            pre_early();
         }
-        const bool vec = (I & 3) == 0;
+        if (g < 0) continue;
+
+        // ---- epilogue: fragment (i, j): row 16 i + fr, columns 16 j + 4 fq + (0..3) ----
+        const float ws = p.w_scale[g];
+        if (EPI == EPI_STORE) {
+            const bool vec = (p.N & 3) == 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = wid * 64 + i * 16 + fr;
-            const bool rok = r < rows;
-            const float m = rok ? q_scale[r] * ws : 0.0f;
-            float* crow = p.C + (int64_t)(row0 + (rok ? r : 0)) * I;
-            float a = 0.0f, b = 0.0f;
+            for (int i = 0; i < 4; ++i) {
+                const int rr = wid * 64 + i * 16 + fr;
+                if (rr >= rows) continue;
+                const float m = qs[i] * ws;
+                float* crow = p.C + (int64_t)(row0 + rr) * p.N;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c0 = nt * (RS_BN / 2) + j * 16 + fq * 4;
-                float v[4];
+                for (int j = 0; j < 8; ++j) {
+                    const int c0 = nt * RS_BN + j * 16 + fq * 4;
+                    float v[4];
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const float gate = (float)acc[i][j][reg] * m;
-                    const float up = (float)acc[i][j + 4][reg] * m;
-                    v[reg] = silu_fast(gate) * up;
-                }
-                if (rok) {
-                    if (vec && c0 + 3 < I) {
+                    for (int reg = 0; reg < 4; ++reg)
+                        v[reg] = (float)acc[i][j][reg] * (p.col_scale ? qs[i] * p.col_scale[(int64_t)g * p.N + min(c0 + reg, p.N - 1)] : m);
+                    if (vec && c0 + 3 < p.N) {
                         *(float4*)(crow + c0) = make_float4(v[0], v[1], v[2], v[3]);
-#pragma unroll
-                        for (int reg = 0; reg < 4; ++reg) { a = fminf(a, v[reg]); b = fmaxf(b, v[reg]); }
                     } else {
 #pragma unroll
                         for (int reg = 0; reg < 4; ++reg)
-                            if (c0 + reg < I) { crow[c0 + reg] = v[reg]; a = fminf(a, v[reg]); b = fmaxf(b, v[reg]); }
+                            if (c0 + reg < p.N) crow[c0 + reg] = v[reg];
+                    }
+                }
+            }
+        } else {
+            const bool st = p.want_stats != 0;
+            if (st) {
+                for (int i = tid; i < I64H_STAT_TAB; i += NT) { tab_lo[i] = I64H_ORDERED_ZERO; tab_hi[i] = I64H_ORDERED_ZERO; }
+                __syncthreads();
+            }
+            const bool vec = (I & 3) == 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rr = wid * 64 + i * 16 + fr;
+                const bool rok = rr < rows;
+                const float m = rok ? qs[i] * ws : 0.0f;
+                float* crow = p.C + (int64_t)(row0 + (rok ? rr : 0)) * I;
+                float a = 0.0f, b = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c0 = nt * (RS_BN / 2) + j * 16 + fq * 4;
+                    float v[4];
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const float gate = (float)acc[i][j][reg] * m;
+                        const float up = (float)acc[i][j + 4][reg] * m;
+                        v[reg] = silu_fast(gate) * up;
+                    }
+                    if (rok) {
+                        if (vec && c0 + 3 < I) {
+                            *(float4*)(crow + c0) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                            for (int reg = 0; reg < 4; ++reg) { a = fminf(a, v[reg]); b = fmaxf(b, v[reg]); }
+                        } else {
+#pragma unroll
+                            for (int reg = 0; reg < 4; ++reg)
+                                if (c0 + reg < I) { crow[c0 + reg] = v[reg]; a = fminf(a, v[reg]); b = fmaxf(b, v[reg]); }
+                        }
+                    }
+                }
+                if (st) {
+                    a = fminf(a, __shfl_xor(a, 16)); b = fmaxf(b, __shfl_xor(b, 16));
+                    a = fminf(a, __shfl_xor(a, 32)); b = fmaxf(b, __shfl_xor(b, 32));
+                    if (fq == 0 && rok) {
+                        const int sl = p.out_row_slot ? rel[i] : 0;
+                        if (sl >= 0 && sl < I64H_STAT_TAB) {
+                            atomicMin(&tab_lo[sl], f32_to_ordered(a));
+                            atomicMax(&tab_hi[sl], f32_to_ordered(b));
+                        } else {
+                            stat_update(p.stats, p.out_slot_base + sl, t, a, b);
+                        }
                     }
                 }
             }
             if (st) {
-                a = fminf(a, __shfl_xor(a, 16)); b = fmaxf(b, __shfl_xor(b, 16));
-                a = fminf(a, __shfl_xor(a, 32)); b = fmaxf(b, __shfl_xor(b, 32));
-                if (fq == 0 && rok) {
-                    const int rel = p.out_row_slot ? p.out_row_slot[row0 + r] : 0;
-                    if (rel >= 0 && rel < I64H_STAT_TAB) {
-                        atomicMin(&tab_lo[rel], f32_to_ordered(a));
-                        atomicMax(&tab_hi[rel], f32_to_ordered(b));
-                    } else {
-                        stat_update(p.stats, p.out_slot_base + rel, bid, a, b);
+                __syncthreads();
+                for (int i = tid; i < I64H_STAT_TAB; i += NT)
+                    if (tab_lo[i] != I64H_ORDERED_ZERO || tab_hi[i] != I64H_ORDERED_ZERO) {
+                        uint32_t* q = p.stats + (int64_t)(p.out_slot_base + i) * I64H_SLOT_WORDS + 2 * (t & (I64H_NSHARD - 1));
+                        atomicMin(q, tab_lo[i]);
+                        atomicMax(q + 1, tab_hi[i]);
                     }
-                }
             }
         }
-        if (st) {
-            __syncthreads();
-            for (int i = tid; i < I64H_STAT_TAB; i += NT)
-                if (tab_lo[i] != I64H_ORDERED_ZERO || tab_hi[i] != I64H_ORDERED_ZERO) {
-                    uint32_t* q = p.stats + (int64_t)(p.out_slot_base + i) * I64H_SLOT_WORDS + 2 * (bid & (I64H_NSHARD - 1));
-                    atomicMin(q, tab_lo[i]);
-                    atomicMax(q + 1, tab_hi[i]);
-                }
-        }
+        if (r == 0) RS_STAMP(4);
     }
-    RS_STAMP(4);
-    if (p.stamps) {  // diagnostics only: when the tile's stores have left the wave
+    if (stamps) {  // diagnostics only: when the last tile's stores have left the wave
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         RS_STAMP(5);
     }
 #undef RS_STAMP
-}
-
-template <int EPI, int D>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void gemm_i8_rs_kernel(GemmI8Pair pp, int nblk_total) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int bid = blockIdx.x;
-    if (bid < pp.nblk0) gemm_i8_rs_body<EPI, D>(pp.p[0], xcd_remap(bid, pp.nblk0), smem);
-    else gemm_i8_rs_body<EPI, D>(pp.p[1], xcd_remap(bid - pp.nblk0, nblk_total - pp.nblk0), smem);
 }
 
 // ---- decode-sized problems: weight-streaming kernel with the quantizer in front ---------------------------------------
@@ -1140,22 +1202,31 @@ static int launch_pair(const i64h_gemm_desc* a, const i64h_gemm_desc* b, hipStre
     return 0;
 }
 
-static int g_rowstream = 4;  // tuning knob: operand prefetch depth of the row-streaming kernel (2 or 4); 0 = kernel off
+static int g_rowstream = 1;  // tuning knob: 0 = row-streaming kernel off, 1 = for SwiGLU problems (where it wins), 2 = for every epilogue
+
+static int g_rs_wgs = 512;     // tuning knob: workgroups the persistent grid may use (two per CU)
+static int g_rs_stagger = 0;   // tuning knob: start delay (cycles) of the second half of the grid
 
 template <int EPI, int D>
 static int launch_rs(const i64h_gemm_desc* a, const i64h_gemm_desc* b, hipStream_t st) {
+    if (b && a->M_total == 0) { a = b; b = nullptr; }  // tiles past the end aim their (unused) loads at the first problem
     GemmI8Pair pp;
     pp.p[0] = to_args(a);
     pp.p[1] = to_args(b ? b : a);
     pp.nblk0 = nblocks_of<RS_BM, RS_BN>(a);
     const int total = pp.nblk0 + (b ? nblocks_of<RS_BM, RS_BN>(b) : 0);
     if (total == 0) return 0;
-    if (g_stamps && g_stamp_cur + total <= g_stamp_cap) {
+    // every workgroup gets the same number of tiles; grid a multiple of 8 (one contiguous run of tiles per XCD and round)
+    int rounds = (total + g_rs_wgs - 1) / g_rs_wgs;
+    if (rounds > RS_MAXR) rounds = RS_MAXR;
+    int nwg = (total + rounds - 1) / rounds;
+    nwg = (nwg + 7) / 8 * 8;
+    if (g_stamps && g_stamp_cur + nwg <= g_stamp_cap) {
         pp.p[0].stamps = pp.p[1].stamps = g_stamps + g_stamp_cur * 8;
-        g_stamp_cur += total;
+        g_stamp_cur += nwg;
     }
-    const size_t lds = 2 * RS_BN * 64 + 16 + RS_BM * 4;
-    hipLaunchKernelGGL((gemm_i8_rs_kernel<EPI, D>), dim3((unsigned)total), dim3(256), lds, st, pp, total);
+    const size_t lds = 2 * RS_BN * 64 + RS_MAXR * 16 + 2 * I64H_STAT_TAB * 4;
+    hipLaunchKernelGGL((gemm_i8_rs_kernel<EPI, D>), dim3((unsigned)nwg), dim3(256), lds, st, pp, total, g_rs_stagger);
     I64H_CHECK_LAUNCH();
     return 0;
 }
@@ -1220,11 +1291,20 @@ int i64h_set_gemm_stage64(int32_t on) {
     return 0;
 }
 
-// tuning knob: operand prefetch depth (2 or 4 K steps; default 4) of the row-streaming kernel that serves int8 operands with
-// at least 1024 rows per group; 0 = use the LDS-tiled kernel for them too
-int i64h_set_gemm_rowstream(int32_t depth) {
-    I64H_CHECK_ARG(depth == 0 || depth == 2 || depth == 4, "set_gemm_rowstream: %d not in {0,2,4}", depth);
-    g_rowstream = depth;
+// tuning knob: which int8 problems with at least 1024 rows per group go to the row-streaming kernel: 0 = none (LDS-tiled
+// kernel), 1 = SwiGLU problems (default), 2 = every epilogue
+int i64h_set_gemm_rowstream(int32_t mode) {
+    I64H_CHECK_ARG(mode >= 0 && mode <= 2, "set_gemm_rowstream: %d not in {0,1,2}", mode);
+    g_rowstream = mode;
+    return 0;
+}
+
+// tuning knobs of the row-streaming kernel: workgroups of its persistent grid (default 512 = two per CU; a large value gives
+// one tile per workgroup) and the start delay in cycles of the second half of the grid (default 0)
+int i64h_set_gemm_rs_grid(int32_t workgroups, int32_t stagger_cycles) {
+    I64H_CHECK_ARG(workgroups >= 8 && stagger_cycles >= 0, "set_gemm_rs_grid: bad values %d, %d", workgroups, stagger_cycles);
+    g_rs_wgs = workgroups;
+    g_rs_stagger = stagger_cycles;
     return 0;
 }
 
@@ -1260,10 +1340,10 @@ int i64h_gemm_i8_pair(const i64h_gemm_desc* a, const i64h_gemm_desc* b, void* st
     hipStream_t st = (hipStream_t)stream;
     if (skinny_ok(a) && (!b || skinny_ok(b)))
         return a->epilogue == EPI_STORE ? launch_skinny_nw<EPI_STORE>(a, b, st) : launch_skinny_nw<EPI_SWIGLU>(a, b, st);
-    if (g_rowstream && rs_ok(a) && (!b || rs_ok(b))) {
-        if (a->epilogue == EPI_STORE) return g_rowstream == 2 ? launch_rs<EPI_STORE, 2>(a, b, st) : launch_rs<EPI_STORE, 4>(a, b, st);
-        return g_rowstream == 2 ? launch_rs<EPI_SWIGLU, 2>(a, b, st) : launch_rs<EPI_SWIGLU, 4>(a, b, st);
-    }
+    // prefill-sized int8 operands: the row-streaming kernel where it is the faster one (measured: SwiGLU problems, -20 %; plain
+    // stores are bound by the output stream and do better with four small workgroups per CU)
+    if (rs_ok(a) && (!b || rs_ok(b)) && (g_rowstream == 2 || (g_rowstream == 1 && a->epilogue == EPI_SWIGLU)))
+        return a->epilogue == EPI_STORE ? launch_rs<EPI_STORE, 2>(a, b, st) : launch_rs<EPI_SWIGLU, 2>(a, b, st);
     const int64_t rows = a->M_total / a->num_groups;
     const bool big = !a->a_fp32 && rows >= 256;  // fp32 operands are meant for small M (quantized per workgroup)
     // short K: a tile's K loop is a handful of steps, so occupancy (4 workgroups per CU) hides the per-tile prologue and
