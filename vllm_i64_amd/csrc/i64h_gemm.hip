@@ -405,8 +405,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE))) void
 // Workgroups are persistent: workgroup w runs tiles w, w + grid, ... (the grid is sized so that every workgroup gets the
 // same number of tiles), all of them located once at the start, and the first loads of the next tile are issued before
 // the epilogue of the current one.  Measured per tile before that: 2.8 k cycles locating it, 6 k waiting for its first
-// loads, 31 k in the K loop (the operand stream out of L2, about 33 B/clk per CU, is what paces it) and 11-20 k in the
-// epilogue, with every workgroup of the chip in the same phase at the same time.
+// loads, 31 k in the K loop and 11-20 k in the epilogue, with every workgroup of the chip in the same phase at the same
+// time.  What paces the K loop is the delivery of the operand stream into the CU: one workgroup alone on a CU needs
+// 1.2 k cycles per step (512 of MFMA), two need 2 k each, and leaving out the operand loads (wrong results) is the one
+// ablation that speeds it up (barriers, LDS reads, wave priority: no change; 128-byte steps that consume whole cache
+// lines: no change).
 // The SwiGLU epilogue evaluates silu through v_exp_f32 / v_rcp_f32 (a few ulp; the exact expf + IEEE divide cost as many
 // VALU cycles per tile as the tile's MFMAs): results differ from the decode-sized kernel's in the last bits only.
 #define RS_BM 256
