@@ -307,7 +307,76 @@ def gen_ops():
     print("ops fixtures written")
 
 
+def gen_checkpoint():
+    """A native export written by the REFERENCE model class (its own state_dict names and layouts), loaded back by the
+    reference's load_checkpoint, and the logits that model then produces.  Data only: model.safetensors + config.json +
+    expected logits.  Also asserts that this repository's loader + oracle reproduce them."""
+    import dataclasses
+    import json
+    from safetensors.torch import save_file
+    from vllm_i64.core.loader import load_checkpoint
+    from vllm_i64_amd import checkpoint as C
+
+    cfg = M.SynthConfig(name="ckpt-tiny", vocab_size=256, hidden_size=64, num_layers=2, num_heads=2, num_kv_heads=1,
+                        intermediate_size=128, num_experts=4, shared_intermediate_size=48, top_k=2, primary_weight=0.7,
+                        routed_scale=1.25, shared_scale=0.5, max_pos=128)
+    out_dir = os.path.join(HERE, "ckpt_tiny")
+    os.makedirs(out_dir, exist_ok=True)
+    rc = ref_config(cfg)
+    rc.routing_strategy = "token_table"
+    src = ComplexityDeepModel(rc).float().eval()
+    g = torch.Generator().manual_seed(2024)
+    with torch.no_grad():
+        for name, prm in src.named_parameters():
+            if prm.dim() >= 2:
+                prm.copy_(torch.empty_like(prm).normal_(0.0, 0.05, generator=g))
+            else:
+                prm.copy_(1.0 + 0.1 * torch.empty_like(prm).normal_(0.0, 1.0, generator=g))
+        for layer in src.layers:
+            t = torch.randint(0, cfg.num_experts, (cfg.top_k, cfg.vocab_size), generator=g)
+            layer.mlp.topk_token_to_expert.copy_(t)
+            layer.mlp.token_to_expert.copy_(t[0])
+    sd = {k: v.detach().clone().contiguous() for k, v in src.state_dict().items()}
+    save_file(sd, os.path.join(out_dir, "model.safetensors"))
+    with open(os.path.join(out_dir, "config.json"), "w", encoding="utf-8") as f:
+        json.dump(dataclasses.asdict(rc), f, indent=1)
+
+    ids = M.make_token_ids(cfg, 19 + 12, seed=11)
+    prompts = [ids[:19], ids[19:]]
+    store = {"prompt_lens": np.array([19, 12]), "token_ids": ids.numpy()}
+    cfg2, w = C.load_checkpoint(out_dir)
+    ocfg = M.SynthConfig(**{f.name: getattr(cfg2, f.name) for f in dataclasses.fields(M.SynthConfig)})
+    report = {}
+    for mode, int8 in (("fp32", False), ("int8", True)):
+        ref = ComplexityDeepModel(ComplexityDeepConfig.from_json(os.path.join(out_dir, "config.json"))).float().eval()
+        stats = load_checkpoint(ref, out_dir, dtype=torch.float32, device="cpu")
+        _fuse_cpu_projection_layers(ref)
+        if int8:
+            ref = _quantize_cpu_dynamic(ref)
+        outs, toks = run_reference_steps(cfg, ref, prompts, 3)
+        last = np.cumsum([19, 12]) - 1
+        store[f"{mode}_prefill_logits"] = outs[0][last]
+        for i in range(1, 4):
+            store[f"{mode}_decode{i}_logits"] = outs[i]
+        store[f"{mode}_tokens"] = np.stack(toks)
+        o = run_oracle_steps(ocfg, w, "fp32" if mode == "fp32" else "int8_torch", prompts, toks)
+        d = [float(np.abs(o[0] - outs[0][last]).max())] + [float(np.abs(o[i] - outs[i]).max()) for i in range(1, 4)]
+        report[f"ckpt-tiny/{mode}"] = max(d)
+        print(f"checkpoint ckpt-tiny [{mode}]: reference loader stats {stats}; own loader + oracle vs reference: max|dlogits| per step = {d}")
+        assert max(d) == 0.0
+    np.savez_compressed(os.path.join(HERE, "ckpt_tiny_expected.npz"), **store)
+    return report
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "checkpoint":  # only the checkpoint fixture (the others stay as committed)
+        rep = gen_checkpoint()
+        with open(os.path.join(HERE, "PINNING.txt"), "a") as f:
+            for k, v in rep.items():
+                f.write(f"{k} (own checkpoint loader + oracle vs reference loader + reference model): {v}\n")
+        print("done")
+        sys.exit(0)
+
     gen_qlinear()
     gen_ops()
     gen_moe_layer()

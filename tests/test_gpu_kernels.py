@@ -158,7 +158,7 @@ def test_gemm_i8_rowstream_swiglu_and_stats(dev, I_, K_, depth):
     assert lohi[0, 0] == 0 and lohi[0, 1] == 0
 
 
-@pytest.mark.parametrize("M_,K_,G_", [(64, 1024, 1), (130, 448, 4), (7, 160, 2)])
+@pytest.mark.parametrize("M_,K_,G_", [(64, 1024, 1), (130, 448, 4), (7, 160, 2), (31, 64, 1), (62, 64, 4), (40, 128, 2), (33, 32, 2)])
 def test_gemm_i8_fused_quantize_matches_two_step(dev, M_, K_, G_):
     """fp32 operand quantized inside the GEMM (per-row stat slots, gathered rows) == quantize kernel + int8 GEMM, bit for bit;
     two problems in one launch == two launches."""
@@ -193,6 +193,20 @@ def test_gemm_i8_fused_quantize_matches_two_step(dev, M_, K_, G_):
         d2 = ops.gemm_desc(x, w[0], ws[:1], out2, a_slot_base=5, epilogue=epi, stats=stats)
         ops.gemm_i8_pair(d, d2)
         assert torch.equal(out, ref) and torch.equal(out2, ref2)
+    # SwiGLU with the statistics of the result folded in (the next call's quantization range): the per-workgroup table shares
+    # LDS with the operand rows, which are smaller than the table for K < 224
+    oslot = torch.randint(0, 3, (M_,), generator=g, dtype=torch.int32).to(dev)
+    st_a, st_b = ops.stats_alloc(8, dev), ops.stats_alloc(8, dev)
+    for st in (st_a, st_b):
+        ops.stats_reset(st)
+        ops.rows_minmax(xs_rows.contiguous(), st, slots=slot.view(-1, 1).contiguous(), slot_base=1)
+    ref = ops.gemm_i8(a, scale, w, ws, group_offsets=off, epilogue=ops.EPI_SWIGLU, row_slot=oslot, slot_base=4, stats=st_a)
+    out = torch.empty_like(ref)
+    d = ops.gemm_desc(x, w, ws, out, a_src_row=src, a_src_mod=n_src, a_row_slot=slot, a_slot_base=1, group_offsets=off,
+                      epilogue=ops.EPI_SWIGLU, stats=st_b, m_total=M_, out_row_slot=oslot, out_slot_base=4, want_stats=True)
+    ops.gemm_i8_pair(d)
+    assert torch.equal(out, ref)
+    assert torch.equal(ops.qparams(st_a, 8)[2], ops.qparams(st_b, 8)[2])
 
 
 # ---- routing / bucketing: bit exact --------------------------------------------------------------------------

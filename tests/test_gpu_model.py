@@ -263,3 +263,36 @@ def test_engine_model_contract_with_engine_owned_cache(dev):
         ref = model.forward(tok.to(dev), posd, slots, (posd + 1).contiguous()).clone()
         assert lg.shape == (len(pos), ocfg.vocab_size) and torch.equal(lg, ref)
     assert cache.seq_lens.tolist() == [0, 10, 0, 34] and cache.allocations == 3 + 1
+
+
+def test_checkpoint_model_against_reference_logits(dev, golden_dir, tmp_path):
+    """Native export (written and read back by the reference, tests/golden/make_golden.py checkpoint) -> this package's loader
+    -> GPU model: logits against the reference's int8 logits at the tier-2 bound; the packed int8 file gives the same bits
+    as packing at start-up."""
+    from vllm_i64_amd import checkpoint as C
+    from vllm_i64_amd.model import GreedyDecoder, I64MoEModel
+    z = np.load(os.path.join(golden_dir, "ckpt_tiny_expected.npz"))
+    cfg, w = C.load_checkpoint(os.path.join(golden_dir, "ckpt_tiny"))
+    packed_path = str(tmp_path / "packed.safetensors")
+    C.save_packed(packed_path, cfg, w)
+    cfg_p, w_p = C.load_packed(packed_path)
+    ids = torch.from_numpy(z["token_ids"])
+    a, b = (int(v) for v in z["prompt_lens"])
+    toks = z["int8_tokens"]
+    runs = []
+    for c, ww in ((cfg, w), (cfg_p, w_p)):
+        model = I64MoEModel(c, ww, device=dev, kv_dtype=torch.float32, max_seqs=2, num_kv_blocks=32)
+        dec = GreedyDecoder(model, 2, use_graph=False)
+        outs = [dec.prefill([ids[:a], ids[a:a + b]], reserve_extra=8).cpu().numpy()]
+        for i in range(1, 4):
+            dec.tokens.copy_(torch.from_numpy(toks[i - 1]))
+            outs.append(dec.step().cpu().numpy())
+        runs.append(outs)
+    for x, y in zip(*runs):
+        assert np.array_equal(x, y)
+    ref = [z["int8_prefill_logits"]] + [z[f"int8_decode{i}_logits"] for i in range(1, 4)]
+    worst = max(np.abs(x - r).max() for x, r in zip(runs[0], ref))
+    gap = np.abs(z["int8_prefill_logits"] - z["fp32_prefill_logits"]).max()
+    agree = [(x.argmax(-1) == t).mean() for x, t in zip(runs[0], toks)]
+    print(f"ckpt-tiny: max|dlogits| vs reference int8 = {worst:.3e}; int8-vs-fp32 gap = {gap:.3e}; argmax agreement {agree}")
+    assert worst <= 0.5 * gap

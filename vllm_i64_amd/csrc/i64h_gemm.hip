@@ -696,6 +696,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 // their 16 up partners), all row fragments.
 #define SK_BM 16  // operand rows per workgroup: one MFMA row fragment (more, smaller workgroups; each reads 1/4 of a 64-row operand)
 #define SK_MF (SK_BM / 16)
+#define SK_AREA_MIN 4096  // >= 2 * I64H_STAT_TAB * 4 (statistics table) and >= 16 * 64 * 4 (head tile)
+static_assert(SK_AREA_MIN >= 2 * I64H_STAT_TAB * 4 && SK_AREA_MIN >= 16 * 64 * 4, "epilogue scratch of the decode-sized kernel");
 
 __device__ __forceinline__ void kv_store(void* cache, int64_t idx, float v, int kv_dtype) {
     switch (kv_dtype) {
@@ -713,9 +715,11 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
     // K steps (64 deep) whose B fragments are in flight together: all of K = 1024 in one batch (half with two fragments per step)
     constexpr int SK_STEPS = 16 / NF;
     const int K = p.K, LDA = K + 32;
-    // LDS: A [64][LDA] int8 | info (16 B) | q_inv[64] q_scale[64] q_zp[64]
-    int* s_info = (int*)(smem + SK_BM * LDA);
-    float* q_inv = (float*)(smem + SK_BM * LDA + 16);
+    // LDS: operand rows [16][LDA] int8, reused by the epilogues (statistics table, head tile of EPI_QKR: SK_AREA_MIN bytes at
+    // least, which matters for K < 224) | info (16 B) | q_inv[16] q_scale[16] q_zp[16]
+    const int area = max(SK_BM * LDA, SK_AREA_MIN);
+    int* s_info = (int*)(smem + area);
+    float* q_inv = (float*)(smem + area + 16);
     float* q_scale = q_inv + SK_BM;
     int* q_zp = (int*)(q_scale + SK_BM);
 
@@ -1263,8 +1267,9 @@ static int launch_skinny(const i64h_gemm_desc* a, const i64h_gemm_desc* b, hipSt
         g_stamp_cur += total;
     }
     const int kmax = b && b->K > a->K ? b->K : a->K;
-    size_t lds = (size_t)SK_BM * (kmax + 32) + 16 + 3 * SK_BM * 4;
-    if (lds < 16 * 64 * 4 + 16 + 3 * SK_BM * 4) lds = 16 * 64 * 4 + 16 + 3 * SK_BM * 4;  // the head tile of EPI_QKR lives in the operand area
+    size_t area = (size_t)SK_BM * (kmax + 32);
+    if (area < SK_AREA_MIN) area = SK_AREA_MIN;  // the epilogues reuse the operand area
+    const size_t lds = area + 16 + 3 * SK_BM * 4;
     hipLaunchKernelGGL((gemm_i8_skinny_kernel<EPI, NW>), dim3((unsigned)total), dim3(NW * 64), lds, st, pp, ta);
     I64H_CHECK_LAUNCH();
     return 0;

@@ -28,9 +28,16 @@ class PackedLinear:
         self.w_q, self.w_s = w_q, w_s
         self.G, self.N, self.K = w_q.shape
 
+    def __getitem__(self, groups: slice) -> "PackedLinear":
+        """A contiguous range of groups (the experts one rank owns)."""
+        return PackedLinear(self.w_q[groups].contiguous(), self.w_s[groups].contiguous())
+
 
 def pack_per_tensor(w: torch.Tensor, device) -> PackedLinear:
-    """w fp32 [N, K] or [G, N, K]; scale_g = max|W_g| / 127.5, W_q = clamp(rne(W * (1/scale)), -128, 127)."""
+    """w fp32 [N, K] or [G, N, K]; scale_g = max|W_g| / 127.5, W_q = clamp(rne(W * (1/scale)), -128, 127).  A matrix that
+    arrives packed (checkpoint.load_packed) is only moved to the device."""
+    if isinstance(w, PackedLinear):
+        return PackedLinear(w.w_q.to(device).contiguous(), w.w_s.to(device=device, dtype=torch.float32).contiguous())
     if w.dim() == 2:
         w = w.unsqueeze(0)
     w = w.to(device=device, dtype=torch.float32)
