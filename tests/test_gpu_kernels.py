@@ -389,7 +389,7 @@ def test_paged_decode_attention_golden(dev, golden_dir, kv_dtype, tol, splits):
     assert np.array_equal(out.cpu().numpy()[2], np.zeros_like(z["pd_out"][2]))
 
 
-@pytest.mark.parametrize("hd,nh,kvh", [(64, 16, 4), (128, 8, 8), (32, 4, 2), (16, 8, 1)])
+@pytest.mark.parametrize("hd,nh,kvh", [(64, 16, 4), (128, 8, 8), (32, 4, 2), (16, 8, 1), (64, 6, 2), (32, 5, 1)])
 def test_paged_attention_random(dev, hd, nh, kvh):
     """Causal rows of several sequences against the oracle's cached attention; block table is a random permutation."""
     ops = _ops()

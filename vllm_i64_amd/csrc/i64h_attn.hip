@@ -86,7 +86,9 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(const float* __restrict
                                                          int max_blocks_per_seq, const int32_t* __restrict__ slot_ids,
                                                          const int32_t* __restrict__ ctx_len, float scale, float* __restrict__ out,
                                                          float* __restrict__ part_o, float* __restrict__ part_ml, int nh, int kvh,
-                                                         int block, int splits) {
+                                                         int block, int splits, int kv_div) {
+    // blockIdx.y = group of GS query heads; its kv head is blockIdx.y / kv_div (kv_div > 1 only with GS == 1: group sizes
+    // without an instantiation of their own run one query head per workgroup)
     constexpr int LPT = HD / 8;    // lanes per token
     constexpr int TPW = 64 / LPT;  // tokens per wave step
     __shared__ float s_m[4][GS], s_l[4][GS], s_o[4][GS][HD];
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(const float* __restrict
             const int tc = max(0, min(t, t_end - 1));
             const int pb = pbn[u];
             live[u] = t < t_end && pb >= 0;
-            const int64_t off = (((int64_t)max(pb, 0) * block + (tc % block)) * kvh + kh) * HD + ch * 8;
+            const int64_t off = (((int64_t)max(pb, 0) * block + (tc % block)) * kvh + kh / kv_div) * HD + ch * 8;
             rk[u].load(k_cache + off);
             rv[u].load(v_cache + off);
         }
@@ -689,8 +691,9 @@ template <int HD, int GS, typename KV>
 static void launch_pa(const float* q, const void* kc, const void* vc, const int32_t* bt, int mbps, const int32_t* slot_ids,
                       const int32_t* ctx_len, float scale, float* out, float* part_o, float* part_ml, int n, int nh, int kvh, int block,
                       int splits, hipStream_t st) {
-    hipLaunchKernelGGL((paged_attn_kernel<HD, GS, KV>), dim3(n, kvh, splits), dim3(256), 0, st, q, (const KV*)kc, (const KV*)vc, bt, mbps,
-                       slot_ids, ctx_len, scale, out, part_o, part_ml, nh, kvh, block, splits);
+    const int kv_div = GS == 1 ? nh / kvh : 1;
+    hipLaunchKernelGGL((paged_attn_kernel<HD, GS, KV>), dim3(n, nh / GS, splits), dim3(256), 0, st, q, (const KV*)kc, (const KV*)vc, bt, mbps,
+                       slot_ids, ctx_len, scale, out, part_o, part_ml, nh, kvh, block, splits, kv_div);
 }
 
 template <int HD, int GS>
@@ -711,13 +714,12 @@ static int dispatch_gs(int gs, int kv_dtype, const float* q, const void* kc, con
                        int kvh, int block, int splits, hipStream_t st) {
 #define GO(G) return dispatch_kv<HD, G>(kv_dtype, q, kc, vc, bt, mbps, slot_ids, ctx_len, scale, out, part_o, part_ml, n, nh, kvh, block, splits, st)
     switch (gs) {
-        case 1: GO(1);
         case 2: GO(2);
         case 4: GO(4);
         case 8: GO(8);
     }
+    GO(1);  // group size 1, and every other size head by head
 #undef GO
-    return 1;
 }
 
 #define PF_MIN_ROWS 256      // from this many rows on, the 16-row-tile matrix-core kernel is used (splits == 1, head_dim 64)
@@ -829,7 +831,7 @@ int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, in
     }
     }
 #undef GO
-    I64H_CHECK_ARG(rc == 0, "paged_attn: GQA group size %d unsupported (1, 2, 4, 8)", gs);
+    I64H_CHECK_ARG(rc == 0, "paged_attn: launch failed for group size %d", gs);
     I64H_CHECK_LAUNCH();
     if (splits > 1 && !(done && arrivals)) {
         hipLaunchKernelGGL(attn_merge_kernel, dim3((unsigned)rows), dim3(256), 0, st, part_o, part_ml, out, (int)num_heads, (int)head_dim,
