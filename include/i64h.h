@@ -148,6 +148,17 @@ int i64h_gemm_w8a32(const float* x, const int8_t* w, const float* w_scale, float
 int i64h_gemm_w8a32_swiglu(const float* x, const int8_t* gate_w, const float* gate_scale, const int8_t* up_w, const float* up_scale,
                            float* out, int64_t M, int32_t I, int32_t K, void* stream);
 
+/* ---- fp8 (OCP e4m3fn) operators: vllm_i64/core/fp8.py ------------------------------------------------------------------
+ * quantize_fp8 (per output channel) and quantize_activations_fp8 (per token) share one arithmetic (fp8.py:77-130):
+ * scale[r] = max(amax|x[r, :]|, 1e-12) / 448, q = e4m3fn(clamp(x / scale, -448, 448)), torch's rounding. */
+int i64h_quantize_fp8_rows(const float* x, int64_t rows, int64_t K, uint8_t* q, float* scale, void* stream);
+/* The torch._scaled_mm branch of fp8_linear / fp8_fused_gate_up (fp8.py:169-193, 230-249) on the fp8 matrix cores:
+ * C[r, c] = (sum_k A[r, k] B[c, k]) * (a_scale[r] * b_scale[c]); A e4m3fn [M, K], B e4m3fn [G][N][K], b_scale [G][N];
+ * group_offsets [G + 1] (device) picks one weight matrix per row range (quantize_experts_fp8, fp8.py:256-283), NULL = one
+ * matrix.  epilogue 0: C fp32 [M, N]; 1: C fp32 [M, N / 2] = silu(C[:, :N/2]) * C[:, N/2:]. */
+int i64h_gemm_fp8(const uint8_t* A, const float* a_scale, const uint8_t* B, const float* b_scale, const int32_t* group_offsets,
+                  int32_t num_groups, int64_t M, int32_t N, int32_t K, float* C, int32_t epilogue, void* stream);
+
 /* ---- one MoE layer behind one call --------------------------------------------------------------------------------------
  * out[n, H] = TokenRoutedMLP(x, token_ids) of the int8 CPU engine: routes = table[:, clamp(ids)], every (route, expert)
  * bucket and the shared expert are dynamic-int8 Linear calls with their own per-call activation parameters, SwiGLU,

@@ -143,3 +143,26 @@ def fused_token_routed_forward_int8(x, gate_up_int8, gate_up_scale, down_int8, d
         t = F.silu(gu[:, :inter]) * gu[:, inter:]
         out[m] = t @ (down_int8[e].float() * down_scale[e].float().unsqueeze(-1))
     return out
+
+
+# ---- fp8 (OCP e4m3fn): vllm_i64/core/fp8.py ---------------------------------------------------------------------------
+def quantize_fp8_rows(x: torch.Tensor):
+    """quantize_fp8(per_channel=True) / quantize_activations_fp8 (fp8.py:77-130): s = max(amax|x|, 1e-12) / 448,
+    q = e4m3fn(clamp(x / s, -448, 448)).  Returns (q float8_e4m3fn [rows, K], s fp32 [rows])."""
+    w = x.float()
+    amax = w.abs().amax(dim=-1, keepdim=True).clamp(min=1e-12)
+    s = amax / 448.0
+    return (w / s).clamp(-448.0, 448.0).to(torch.float8_e4m3fn), s.squeeze(-1)
+
+
+def fp8_linear_scaled_mm(x: torch.Tensor, w_fp8: torch.Tensor, w_scale: torch.Tensor) -> torch.Tensor:
+    """The torch._scaled_mm branch of fp8_linear (fp8.py:169-193) restated: both operands e4m3fn, exact products, the sum
+    in float64 (the hardware sums in fp32 in its own order), times x_scale[m] * w_scale[n].  fp32 [M, N]."""
+    xq, xs = quantize_fp8_rows(x.reshape(-1, x.shape[-1]))
+    acc = xq.double() @ w_fp8.double().t()
+    return (acc * (xs.double().unsqueeze(1) * w_scale.double().unsqueeze(0))).float()
+
+
+def fp8_linear_dequant(x: torch.Tensor, w_fp8: torch.Tensor, w_scale: torch.Tensor) -> torch.Tensor:
+    """The branch the reference takes wherever its SM89 gate is closed (fp8.py:163-167): weights dequantized, fp32 GEMM."""
+    return torch.nn.functional.linear(x.float(), w_fp8.float() * w_scale.unsqueeze(-1))

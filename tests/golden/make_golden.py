@@ -368,6 +368,37 @@ def gen_checkpoint():
     return report
 
 
+def gen_fp8():
+    """core/fp8.py on the CPU: the two quantizers (bit patterns and scales) and the fp8_linear the reference computes where
+    its SM89 gate is closed (weights dequantized).  The _scaled_mm branch needs CUDA and is not captured."""
+    from vllm_i64.core.fp8 import quantize_fp8, quantize_activations_fp8, fp8_linear, quantize_experts_fp8
+    g = torch.Generator().manual_seed(77)
+    store = {}
+    w = torch.empty(40, 96).normal_(0, 0.05, generator=g)
+    w[3] = 0.0            # all-zero channel: scale clamps at 1e-12 / 448
+    w[5, 7] = 30.0        # outlier
+    x = torch.empty(33, 96).normal_(0, 1.5, generator=g)
+    x[4] *= 1e-6
+    x[9, 0] = 1e4
+    wq, ws = quantize_fp8(w)
+    wq_t, ws_t = quantize_fp8(w, per_channel=False)
+    xq, xs = quantize_activations_fp8(x)
+    y = fp8_linear(x, wq, ws)
+    oq, os_ = O.quantize_fp8_rows(w)
+    assert torch.equal(oq.view(torch.uint8), wq.view(torch.uint8)) and torch.equal(os_, ws)
+    oq, os_ = O.quantize_fp8_rows(x)
+    assert torch.equal(oq.view(torch.uint8), xq.view(torch.uint8)) and torch.equal(os_, xs.squeeze(-1))
+    assert torch.equal(O.fp8_linear_dequant(x, wq, ws), y)
+    ex = quantize_experts_fp8(torch.empty(3, 32, 48).normal_(0, 0.05, generator=torch.Generator().manual_seed(5)),
+                              torch.empty(3, 24, 32).normal_(0, 0.05, generator=torch.Generator().manual_seed(6)))
+    store.update(fp8_w=w.numpy(), fp8_wq=wq.view(torch.uint8).numpy(), fp8_ws=ws.numpy(), fp8_wq_tensor=wq_t.view(torch.uint8).numpy(),
+                 fp8_ws_tensor=ws_t.numpy(), fp8_x=x.numpy(), fp8_xq=xq.view(torch.uint8).numpy(), fp8_xs=xs.numpy(), fp8_y_dequant=y.numpy(),
+                 fp8_ex_gu=ex["gate_up_fp8"].view(torch.uint8).numpy(), fp8_ex_gus=ex["gate_up_scale"].numpy(),
+                 fp8_ex_dn=ex["down_fp8"].view(torch.uint8).numpy(), fp8_ex_dns=ex["down_scale"].numpy())
+    np.savez_compressed(os.path.join(HERE, "fp8.npz"), **store)
+    print("fp8 fixtures written")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "checkpoint":  # only the checkpoint fixture (the others stay as committed)
         rep = gen_checkpoint()
@@ -375,6 +406,9 @@ if __name__ == "__main__":
             for k, v in rep.items():
                 f.write(f"{k} (own checkpoint loader + oracle vs reference loader + reference model): {v}\n")
         print("done")
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "fp8":
+        gen_fp8()
         sys.exit(0)
 
     gen_qlinear()

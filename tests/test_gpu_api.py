@@ -254,3 +254,81 @@ def test_i64_ops_pipeline_functions(dev):
     out_sorted = K.i64_expert_forward(sc, gu.to(dev), dn.to(dev), off, cnt, E)
     torch.testing.assert_close(K.i64_gather(out_sorted, si).cpu(), ref, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(K.i64_full_pipeline(tok.to(dev), x.to(dev), gu.to(dev), dn.to(dev), E).cpu(), ref, rtol=1e-4, atol=1e-5)
+
+
+def test_fp8_quantizers_bit_exact_against_reference(dev, golden_dir):
+    """quantize_fp8 / quantize_activations_fp8 / quantize_experts_fp8 (core/fp8.py:77-130, 256-283): e4m3fn bit patterns and
+    scales captured from the reference on the CPU."""
+    from vllm_i64_amd import kernels as K
+    z = np.load(os.path.join(golden_dir, "fp8.npz"))
+    w, x = torch.from_numpy(z["fp8_w"]).to(dev), torch.from_numpy(z["fp8_x"]).to(dev)
+    q, s = K.quantize_fp8(w)
+    assert q.dtype == torch.float8_e4m3fn and s.shape == (40,)
+    assert np.array_equal(q.view(torch.uint8).cpu().numpy(), z["fp8_wq"]) and np.array_equal(s.cpu().numpy(), z["fp8_ws"])
+    q, s = K.quantize_fp8(w, per_channel=False)
+    assert np.array_equal(q.view(torch.uint8).cpu().numpy(), z["fp8_wq_tensor"]) and float(s) == float(z["fp8_ws_tensor"])
+    q, s = K.quantize_activations_fp8(x)
+    assert s.shape == (33, 1)
+    assert np.array_equal(q.view(torch.uint8).cpu().numpy(), z["fp8_xq"]) and np.array_equal(s.cpu().numpy(), z["fp8_xs"])
+    gu = torch.empty(3, 32, 48).normal_(0, 0.05, generator=torch.Generator().manual_seed(5)).to(dev)
+    dn = torch.empty(3, 24, 32).normal_(0, 0.05, generator=torch.Generator().manual_seed(6)).to(dev)
+    ex = K.quantize_experts_fp8(gu, dn)
+    assert np.array_equal(ex["gate_up_fp8"].view(torch.uint8).cpu().numpy(), z["fp8_ex_gu"])
+    assert np.array_equal(ex["gate_up_scale"].cpu().numpy(), z["fp8_ex_gus"])
+    assert np.array_equal(ex["down_fp8"].view(torch.uint8).cpu().numpy(), z["fp8_ex_dn"])
+    assert np.array_equal(ex["down_scale"].cpu().numpy(), z["fp8_ex_dns"])
+
+
+@pytest.mark.parametrize("M_,N_,K_", [(1, 40, 96), (33, 130, 1024), (300, 64, 16), (257, 896, 448)])
+def test_fp8_linear_on_matrix_cores(dev, M_, N_, K_):
+    """fp8 x fp8 -> fp32 with per-token / per-channel scales (the _scaled_mm branch of fp8_linear, fp8.py:169-193; the reference
+    cannot run it here, so the expected value is the restated arithmetic: exact products, float64 sum).  The matrix core sums
+    in fp32 with its own alignment and rounding of the 32 products of an instruction: measured up to 1e-5 of the row's
+    magnitude, bounded here at 3e-5 (the operands themselves carry 3 mantissa bits)."""
+    from vllm_i64_amd import kernels as K
+    g = torch.Generator().manual_seed(M_ + N_)
+    x = torch.empty(M_, K_).normal_(0, 1, generator=g)
+    w = torch.empty(N_, K_).normal_(0, 0.05, generator=g)
+    b = torch.empty(N_).normal_(0, 1, generator=g)
+    wq, ws = O.quantize_fp8_rows(w)
+    ref = O.fp8_linear_scaled_mm(x, wq, ws) + b
+    y = K.fp8_linear(x.to(dev), wq.to(dev), ws.to(dev), b.to(dev)).cpu()
+    rel = ((y - ref).abs() / (ref.abs().amax(dim=-1, keepdim=True) + 1e-7)).max().item()
+    print(f"fp8_linear M={M_} N={N_} K={K_}: max error {rel:.2e} of the row magnitude")
+    assert rel <= 3e-5
+    g1, u1 = K.fp8_fused_gate_up(x.to(dev), wq[: N_ // 2 * 2].to(dev), ws[: N_ // 2 * 2].to(dev), N_ // 2)
+    y0 = K.fp8_linear(x.to(dev), wq.to(dev), ws.to(dev)).cpu()
+    assert torch.equal(torch.cat([g1, u1], dim=-1).cpu(), y0[:, : N_ // 2 * 2])
+
+
+def test_fp8_dense_mlp_and_grouped_experts(dev):
+    """DenseMLP._forward_fp8 (layers/dense_mlp.py:75-83) as quantize -> fused gate/up GEMM with SwiGLU -> quantize -> down, and the
+    grouped form over (ragged, partly empty) expert row ranges against the per-expert calls."""
+    from vllm_i64_amd import kernels as K
+    g = torch.Generator().manual_seed(3)
+    n, H, I = 77, 128, 80
+    x = torch.empty(n, H).normal_(0, 1, generator=g)
+    wg, wu, wd = (torch.empty(I, H).normal_(0, 0.05, generator=g), torch.empty(I, H).normal_(0, 0.05, generator=g),
+                  torch.empty(H, I).normal_(0, 0.05, generator=g))
+    (gq, gs), (uq, us), (dq, ds) = O.quantize_fp8_rows(wg), O.quantize_fp8_rows(wu), O.quantize_fp8_rows(wd)
+    gate, up = O.fp8_linear_scaled_mm(x, gq, gs), O.fp8_linear_scaled_mm(x, uq, us)
+    inter = torch.nn.functional.silu(gate) * up
+    ref = O.fp8_linear_scaled_mm(inter, dq, ds)
+    to = lambda *ts: [t.to(dev) for t in ts]
+    y = K.fp8_dense_mlp(*to(x, gq, gs, uq, us, dq, ds)).cpu()
+    # the intermediate is re-quantized to 3 mantissa bits: a last-bit difference in it can move one fp8 code
+    assert (y - ref).abs().max() <= 2e-2 * ref.abs().max()
+    assert (y - ref).abs().mean() <= 1e-4 * ref.abs().max()
+    E = 4
+    wq = torch.stack([O.quantize_fp8_rows(torch.empty(2 * I, H).normal_(0, 0.05, generator=g))[0] for _ in range(E)])
+    ws = torch.rand(E, 2 * I, generator=g) * 1e-3 + 1e-4
+    off = torch.tensor([0, 30, 30, 31, n], dtype=torch.int32)
+    out = K.fp8_grouped_linear(x.to(dev), wq.to(dev), ws.to(dev), off.to(dev)).cpu()
+    out_s = K.fp8_grouped_linear(x.to(dev), wq.to(dev), ws.to(dev), off.to(dev), swiglu=True).cpu()
+    for e in range(E):
+        a, b = int(off[e]), int(off[e + 1])
+        if a == b:
+            continue
+        r = K.fp8_linear(x[a:b].to(dev), wq[e].to(dev), ws[e].to(dev)).cpu()
+        assert torch.equal(out[a:b], r)
+        torch.testing.assert_close(out_s[a:b], torch.nn.functional.silu(r[:, :I]) * r[:, I:], rtol=2e-6, atol=1e-9)

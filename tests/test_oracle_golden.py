@@ -183,3 +183,21 @@ def test_oracle_pertoken_int8_ops_match_reference_fixtures(golden_dir):
     for n in (9, 130):
         out = O.fused_token_routed_forward_int8(t(f"fe8_x{n}"), t("fe8_gu"), t("fe8_gus"), t("fe8_dn"), t("fe8_dns"), t(f"fe8_eid{n}"), 4, 48)
         assert np.allclose(out.numpy(), z[f"fe8_y{n}"], rtol=1e-4, atol=1e-5)
+
+
+def test_oracle_fp8_ops_match_reference_fixtures(golden_dir):
+    """core/fp8.py captured on the CPU: quantizer bit patterns and scales, and the dequantizing fp8_linear."""
+    z = np.load(os.path.join(golden_dir, "fp8.npz"))
+    w, x = torch.from_numpy(z["fp8_w"]), torch.from_numpy(z["fp8_x"])
+    q, s = O.quantize_fp8_rows(w)
+    assert np.array_equal(q.view(torch.uint8).numpy(), z["fp8_wq"]) and np.array_equal(s.numpy(), z["fp8_ws"])
+    q, s = O.quantize_fp8_rows(x)
+    assert np.array_equal(q.view(torch.uint8).numpy(), z["fp8_xq"]) and np.array_equal(s.numpy(), z["fp8_xs"][:, 0])
+    q, s = O.quantize_fp8_rows(w.reshape(1, -1))
+    assert np.array_equal(q.view(torch.uint8).numpy().reshape(w.shape), z["fp8_wq_tensor"]) and float(s) == float(z["fp8_ws_tensor"])
+    wq = torch.from_numpy(z["fp8_wq"]).view(torch.float8_e4m3fn)
+    assert np.array_equal(O.fp8_linear_dequant(x, wq, torch.from_numpy(z["fp8_ws"])).numpy(), z["fp8_y_dequant"])
+    # the matrix-core form differs from the dequantizing form by the activation rounding only (3 mantissa bits)
+    y = O.fp8_linear_scaled_mm(x, wq, torch.from_numpy(z["fp8_ws"])).numpy()
+    ref = z["fp8_y_dequant"]
+    assert np.linalg.norm(y - ref) <= 0.05 * np.linalg.norm(ref)

@@ -273,3 +273,88 @@ def i64_full_pipeline(token_ids: torch.Tensor, hidden_states: torch.Tensor, gate
     """route -> grouped expert MLP -> original order (i64_ops.py:161-193)."""
     expert_ids = i64_route_tokens(token_ids, num_experts)
     return fused_token_routed_forward(hidden_states, gate_up_weights, down_weights, expert_ids.long(), num_experts, down_weights.shape[1])
+
+
+# ---- fp8 (OCP e4m3fn): vllm_i64/core/fp8.py ---------------------------------------------------------------------------
+def _quantize_fp8_rows(x2: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    x2 = _f32(x2)
+    rows, K = x2.shape
+    q = torch.empty(rows, K, dtype=torch.float8_e4m3fn, device=x2.device)
+    s = torch.empty(rows, dtype=torch.float32, device=x2.device)
+    ops.call("i64h_quantize_fp8_rows", ops.ptr(x2), rows, K, ops.ptr(q), ops.ptr(s), ops._stream())
+    return q, s
+
+
+def quantize_fp8(weight: torch.Tensor, per_channel: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(out, in) float -> (e4m3fn weight, scale): scale = max|w| / 448 per output channel (out,) or per tensor (scalar)
+    (fp8.py:77-113)."""
+    if per_channel:
+        return _quantize_fp8_rows(weight)
+    q, s = _quantize_fp8_rows(weight.reshape(1, -1))
+    return q.reshape(weight.shape), s.reshape(())
+
+
+def quantize_activations_fp8(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(tokens, features) float -> e4m3fn + (tokens, 1) scale (fp8.py:116-130)."""
+    q, s = _quantize_fp8_rows(x)
+    return q, s.unsqueeze(-1)
+
+
+quantize_dense_fp8 = quantize_fp8  # fp8.py:290-299
+
+
+def _gemm_fp8(xq, xs, wq, ws, epilogue=0, group_offsets=None) -> torch.Tensor:
+    if wq.dim() == 2:
+        wq, ws = wq.unsqueeze(0), ws.reshape(1, -1)
+    G, N, K = wq.shape
+    M = xq.shape[0]
+    out = torch.empty(M, N // 2 if epilogue else N, dtype=torch.float32, device=xq.device)
+    ops.call("i64h_gemm_fp8", ops.ptr(xq.contiguous()), ops.ptr(_f32(xs.reshape(-1))), ops.ptr(wq.contiguous()), ops.ptr(_f32(ws)),
+             ops.ptr(group_offsets), G, M, N, K, ops.ptr(out), epilogue, ops._stream())
+    return out
+
+
+def fp8_linear(x: torch.Tensor, weight_fp8: torch.Tensor, weight_scale: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = x @ W^T on the fp8 matrix cores: per-token activation quantization, then acc * (x_scale[m] * w_scale[n]) (+ bias): the
+    torch._scaled_mm branch of the reference (fp8.py:169-193; its own gate, SM89+, never opens on AMD hardware, where it
+    dequantizes the weights instead).  Output fp32."""
+    shape = x.shape
+    xq, xs = quantize_activations_fp8(x.reshape(-1, shape[-1]))
+    out = _gemm_fp8(xq, xs, weight_fp8, weight_scale)
+    if bias is not None:
+        out = out + bias
+    return out.reshape(*shape[:-1], weight_fp8.shape[0])
+
+
+def fp8_fused_gate_up(x: torch.Tensor, fused_fp8: torch.Tensor, fused_scale: torch.Tensor, inter_size: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """One activation quantization + one fp8 GEMM over cat([gate, up]) rows, split at inter_size (fp8.py:196-249)."""
+    out = fp8_linear(x, fused_fp8, fused_scale)
+    gate, up = out.split(inter_size, dim=-1)
+    return gate, up
+
+
+def fp8_dense_mlp(x: torch.Tensor, gate_fp8, gate_scale, up_fp8, up_scale, down_fp8, down_scale) -> torch.Tensor:
+    """DenseMLP._forward_fp8 (layers/dense_mlp.py:75-83): down(silu(gate(x)) * up(x)), every Linear an fp8_linear; gate and up
+    share the activation quantization and run as one GEMM with the SwiGLU in its epilogue."""
+    shape = x.shape
+    xq, xs = quantize_activations_fp8(x.reshape(-1, shape[-1]))
+    inter = _gemm_fp8(xq, xs, torch.cat([gate_fp8, up_fp8], dim=0), torch.cat([gate_scale, up_scale], dim=0), epilogue=1)
+    return fp8_linear(inter, down_fp8, down_scale).reshape(*shape[:-1], down_fp8.shape[0])
+
+
+def quantize_experts_fp8(gate_up: torch.Tensor, down: torch.Tensor) -> dict:
+    """(E, hidden, 2*inter), (E, inter, hidden) -> per-expert e4m3fn tensors with the scales quantize_fp8 gives each expert's
+    2-D slice: per ROW of the slice, i.e. per input channel (fp8.py:256-283)."""
+    E = gate_up.shape[0]
+    gq, gs = _quantize_fp8_rows(gate_up.reshape(-1, gate_up.shape[-1]))
+    dq, ds = _quantize_fp8_rows(down.reshape(-1, down.shape[-1]))
+    return {"method": "fp8", "gate_up_fp8": gq.reshape(gate_up.shape), "gate_up_scale": gs.reshape(E, -1),
+            "down_fp8": dq.reshape(down.shape), "down_scale": ds.reshape(E, -1)}
+
+
+def fp8_grouped_linear(x: torch.Tensor, weight_fp8: torch.Tensor, weight_scale: torch.Tensor, group_offsets: torch.Tensor,
+                       swiglu: bool = False) -> torch.Tensor:
+    """Rows [off[g], off[g+1]) of x against expert g's (N, K) e4m3fn matrix with per-output-channel scales (E, N): the grouped
+    form of fp8_linear for token-routed experts (rows sorted by expert, offsets on the device, no host read)."""
+    xq, xs = quantize_activations_fp8(x)
+    return _gemm_fp8(xq, xs, weight_fp8, weight_scale, epilogue=1 if swiglu else 0, group_offsets=group_offsets)
