@@ -148,6 +148,16 @@ int i64h_gemm_w8a32(const float* x, const int8_t* w, const float* w_scale, float
 int i64h_gemm_w8a32_swiglu(const float* x, const int8_t* gate_w, const float* gate_scale, const int8_t* up_w, const float* up_scale,
                            float* out, int64_t M, int32_t I, int32_t K, void* stream);
 
+/* ---- paged-KV cache operations: PagedKVCache (vllm_i64/core/kv_cache.py) ---------------------------------------------------
+ * write_kv_decode (kv_cache.py:422-459): one new token per sequence, no host reads; physical block = max(block_table[seq,
+ * pos / block], 0); the cast to the cache dtype is the reference's .to(kv_dtype); seq_lens[seq] = max(seq_lens[seq], pos + 1)
+ * when seq_lens is given.  k, v fp32 [n, kv_heads * head_dim]; seq_ids / positions int64 [n]. */
+int i64h_kv_write_decode(const float* k, const float* v, const int64_t* seq_ids, const int64_t* positions, const int32_t* block_table,
+                         int32_t max_blocks_per_seq, void* k_cache, void* v_cache, int32_t kv_dtype, int64_t n, int32_t num_kv_heads,
+                         int32_t head_dim, int32_t block_size, int32_t* seq_lens, void* stream);
+/* The block copy of copy-on-write (_cow_if_shared, kv_cache.py:682-688) for `pairs` (src, dst) block ids of one cache tensor. */
+int i64h_kv_copy_blocks(void* cache, int64_t block_bytes, const int32_t* src, const int32_t* dst, int32_t pairs, void* stream);
+
 /* ---- fp8 (OCP e4m3fn) operators: vllm_i64/core/fp8.py ------------------------------------------------------------------
  * quantize_fp8 (per output channel) and quantize_activations_fp8 (per token) share one arithmetic (fp8.py:77-130):
  * scale[r] = max(amax|x[r, :]|, 1e-12) / 448, q = e4m3fn(clamp(x / scale, -448, 448)), torch's rounding. */

@@ -399,6 +399,27 @@ def gen_fp8():
     print("fp8 fixtures written")
 
 
+def gen_kv():
+    """PagedKVCache.write_kv_decode of the reference on the CPU (bf16 cache): cache contents, block table and sequence lengths
+    after two decode writes, one of them into a table entry that was never allocated (the reference clamps it to block 0)."""
+    g = torch.Generator().manual_seed(21)
+    kv = PagedKVCache(1, 2, 8, block_size=16, num_blocks=8, max_seqs=4, dtype=torch.bfloat16, device="cpu")
+    kv.allocate_blocks(0, 2)
+    kv.allocate_blocks(2, 1)
+    kv.allocate_blocks(3, 3)
+    store = {"kv_block_table": kv.block_table.numpy().copy()}
+    seqs = [torch.tensor([0, 2, 3]), torch.tensor([3, 0, 1])]     # sequence 1 owns no block
+    poss = [torch.tensor([17, 3, 40]), torch.tensor([41, 18, 5])]
+    for i, (sq, ps) in enumerate(zip(seqs, poss)):
+        k = torch.empty(3, 2, 8).normal_(0, 1, generator=g)
+        v = torch.empty(3, 2, 8).normal_(0, 1, generator=g)
+        kv.write_kv_decode(0, sq, ps, k, v)
+        store.update({f"kv_seq{i}": sq.numpy(), f"kv_pos{i}": ps.numpy(), f"kv_k{i}": k.numpy(), f"kv_v{i}": v.numpy()})
+    store.update(kv_kcache=kv.k_caches[0].float().numpy(), kv_vcache=kv.v_caches[0].float().numpy(), kv_seq_lens=kv.seq_lens.numpy().copy())
+    np.savez_compressed(os.path.join(HERE, "kv.npz"), **store)
+    print("kv fixtures written")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "checkpoint":  # only the checkpoint fixture (the others stay as committed)
         rep = gen_checkpoint()
@@ -409,6 +430,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "fp8":
         gen_fp8()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "kv":
+        gen_kv()
         sys.exit(0)
 
     gen_qlinear()

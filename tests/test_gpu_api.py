@@ -332,3 +332,47 @@ def test_fp8_dense_mlp_and_grouped_experts(dev):
         r = K.fp8_linear(x[a:b].to(dev), wq[e].to(dev), ws[e].to(dev)).cpu()
         assert torch.equal(out[a:b], r)
         torch.testing.assert_close(out_s[a:b], torch.nn.functional.silu(r[:, :I]) * r[:, I:], rtol=2e-6, atol=1e-9)
+
+
+class _Cache:
+    """What the engine hands over: the attributes of the reference's PagedKVCache that the device ops read."""
+
+    def __init__(self, dev, layers, blocks, block, kvh, hd, max_seqs, max_blocks, dtype):
+        self.k_caches = [torch.zeros(blocks, block, kvh, hd, dtype=dtype, device=dev) for _ in range(layers)]
+        self.v_caches = [torch.zeros(blocks, block, kvh, hd, dtype=dtype, device=dev) for _ in range(layers)]
+        self.block_table = torch.full((max_seqs, max_blocks), -1, dtype=torch.int32, device=dev)
+        self.seq_lens = torch.zeros(max_seqs, dtype=torch.int32, device=dev)
+        self.block_size = block
+
+
+def test_kv_write_decode_against_reference_cache(dev, golden_dir):
+    """write_kv_decode of the reference's PagedKVCache captured on the CPU (bf16 cache, one write through a table entry that was
+    never allocated): identical cache bytes and sequence lengths."""
+    from vllm_i64_amd import kv_cache as KV
+    z = np.load(os.path.join(golden_dir, "kv.npz"))
+    bt = torch.from_numpy(z["kv_block_table"])
+    c = _Cache(dev, 1, 8, 16, 2, 8, bt.shape[0], bt.shape[1], torch.bfloat16)
+    c.block_table.copy_(bt)
+    for i in range(2):
+        KV.write_kv_decode(c, 0, torch.from_numpy(z[f"kv_seq{i}"]).to(dev), torch.from_numpy(z[f"kv_pos{i}"]).to(dev),
+                           torch.from_numpy(z[f"kv_k{i}"]).to(dev), torch.from_numpy(z[f"kv_v{i}"]).to(dev))
+    assert np.array_equal(c.k_caches[0].float().cpu().numpy(), z["kv_kcache"])
+    assert np.array_equal(c.v_caches[0].float().cpu().numpy(), z["kv_vcache"])
+    assert np.array_equal(c.seq_lens.cpu().numpy(), z["kv_seq_lens"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float8_e4m3fn])
+def test_kv_copy_blocks(dev, dtype):
+    """Copy-on-write data movement (_cow_if_shared, kv_cache.py:682-688): whole blocks, every layer, K and V."""
+    from vllm_i64_amd import kv_cache as KV
+    c = _Cache(dev, 3, 10, 16, 4, 64, 2, 4, dtype)
+    g = torch.Generator().manual_seed(1)
+    for t in c.k_caches + c.v_caches:
+        t.copy_(torch.randn(t.shape, generator=g).to(dtype))
+    before = [t.clone() for t in c.k_caches + c.v_caches]
+    KV.copy_blocks(c, [1, 7, 1], [4, 0, 9])
+    for t, b in zip(c.k_caches + c.v_caches, before):
+        want = b.clone()
+        want[4], want[0], want[9] = b[1], b[7], b[1]
+        assert torch.equal(t.view(torch.uint8), want.view(torch.uint8))
+    KV.copy_blocks(c, [], [])

@@ -142,8 +142,27 @@ def bench_gemm_prefill(only=None):
         print(f"gemm_i8 {name:34s} M={M} N={N} K={K} G={G}: {med:8.1f} us -> {2 * M * N * K / med / 1e6:7.1f} TOP/s ({2 * M * N * K / med / 1e6 / 5000 * 100:4.1f}% of 5 POP/s)")
 
 
+def bench_fp8():
+    """fp8 x fp8 GEMM (operands already quantized) and the per-row quantizer on prefill- and decode-sized problems."""
+    from vllm_i64_amd import kernels as K
+    torch.manual_seed(0)
+    for name, M, N, Kd in (("shared gate_up, prefill chunk", 16384, 3584, 1024), ("qkv, prefill chunk", 16384, 1536, 1024),
+                           ("shared gate_up, decode", 64, 3584, 1024), ("square 4096", 4096, 4096, 4096)):
+        x = torch.randn(M, Kd, device=dev)
+        w = torch.randn(N, Kd, device=dev) * 0.05
+        wq, ws = K.quantize_fp8(w)
+        xq, xs = K.quantize_activations_fp8(x)
+        med, _ = timeit(lambda: K._gemm_fp8(xq, xs, wq, ws), iters=5, warm=2, inner=5)
+        medq, _ = timeit(lambda: K.quantize_activations_fp8(x), iters=5, warm=2, inner=5)
+        print(f"fp8 {name:30s} M={M} N={N} K={Kd}: gemm {med:8.1f} us -> {2 * M * N * Kd / med / 1e6:7.1f} TFLOP/s; "
+              f"row quantizer {medq:7.1f} us -> {M * Kd * 5 / medq / 1e3:6.1f} GB/s")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what == "fp8":
+        bench_fp8()
+        sys.exit(0)
     if what == "gemmw":
         for nw in (2, 4):
             ops.call("i64h_set_skinny_waves", nw)

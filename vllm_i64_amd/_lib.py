@@ -32,6 +32,8 @@ SIGNATURES: Dict[str, str] = {
     "i64h_gemm_f32": "pppplii" + "p",
     "i64h_gemm_w8a32": "pppplii" + "p",
     "i64h_gemm_w8a32_swiglu": "ppppppliip",
+    "i64h_kv_write_decode": "pppppippiliiipp",
+    "i64h_kv_copy_blocks": "plppip",
     "i64h_quantize_fp8_rows": "pllppp",
     "i64h_gemm_fp8": "pppppiliipip",
     "i64h_embedding": "pppli" + "lp",
