@@ -220,12 +220,14 @@ class I64MoEModel:
     # ---- one forward (prefill chunk or decode step) ----
     def forward(self, token_ids: torch.Tensor, positions: torch.Tensor, slot_ids: torch.Tensor, ctx_len: torch.Tensor,
                 logit_rows: Optional[torch.Tensor] = None, max_ctx_hint: int = 0, record: Optional[dict] = None,
-                inject: Optional[Dict[int, torch.Tensor]] = None, kv=None) -> torch.Tensor:
+                inject: Optional[Dict[int, torch.Tensor]] = None, kv=None, rows_are_slots: bool = False) -> torch.Tensor:
         """token_ids int64 [N]; positions / slot_ids / ctx_len int32 [N] (ctx_len = position + 1 for causal rows);
         logit_rows int32 [M] selects the rows whose logits are wanted (None = all).  Returns fp32 logits [M, V].
         record: dict filled with per-layer activations; inject: {layer: hidden [N, H]} replaces the residual stream at the
         entry of a layer (teacher forcing for per-layer parity tests).  kv: a cache other than the runner's own (anything
-        with lists `k`, `v` of per-layer (num_blocks, block, kv_heads, head_dim) tensors and an int32 `block_table`)."""
+        with lists `k`, `v` of per-layer (num_blocks, block, kv_heads, head_dim) tensors and an int32 `block_table`).
+        rows_are_slots: the caller guarantees slot_ids == arange(N) (batch decode), which spares the attention kernel one
+        dependent lookup per workgroup."""
         cfg, st = self.cfg, self.stats
         kvc = kv if kv is not None else self.kv
         n = token_ids.numel()
@@ -267,7 +269,7 @@ class I64MoEModel:
                 self._linear(B.normed, W["qkv"], base + 0, B.xa, B.xs, B.qkv)
                 ops.qk_norm_rope_kv(B.qkv, W["q_norm"], W["k_norm"], 1e-6, self.rope, positions, slot_ids, kvc.block_table,
                                     kvc.k[l], kvc.v[l], cfg.num_heads, cfg.num_kv_heads, cfg.head_dim, q_out=B.q)
-            ops.paged_attn(B.q, kvc.k[l], kvc.v[l], kvc.block_table, ctx_len, slot_ids=slot_ids,
+            ops.paged_attn(B.q, kvc.k[l], kvc.v[l], kvc.block_table, ctx_len, slot_ids=None if rows_are_slots else slot_ids,
                            softmax_scale=1.0 / math.sqrt(cfg.head_dim), splits=splits, out=B.attn, workspace=B.attn_ws,
                            stats=st if splits > 1 else None, stat_slot=base + 1)
             attn2d = B.attn.view(n, H)
@@ -418,7 +420,8 @@ class GreedyDecoder:
         self.max_ctx_hint = max(lens) + reserve_extra
 
     def _step_body(self):
-        self.logits = self.m.forward(self.tokens, self.positions, self.slot_ids, self.ctx_len, max_ctx_hint=self.max_ctx_hint)
+        self.logits = self.m.forward(self.tokens, self.positions, self.slot_ids, self.ctx_len, max_ctx_hint=self.max_ctx_hint,
+                                     rows_are_slots=True)
         ops.argmax_rows(self.logits, out=self.tokens)
         ops.advance(self.positions, self.ctx_len)
 
