@@ -407,6 +407,225 @@ __global__ __launch_bounds__(GS * 64) void paged_attn_prefill_kernel(const float
     }
 }
 
+// ---- prefill form for a bf16 cache: the same tiling on the bf16 matrix cores, at fp32 accuracy -------------------------------
+// K and V are bf16 EXACTLY, so only the fp32 operand of each product has to be widened: Q (and P, the probabilities) is split
+// into three bf16 terms hi + mid + lo (8 + 8 + 8 significant bits: the sum is the fp32 value bit for bit), every bf16 x bf16
+// product is exact in fp32, and three v_mfma_f32_16x16x32_bf16 (16 cycles each, 32 deep) replace eight v_mfma_f32_16x16x4_f32
+// (32 cycles each): 48 instead of 256 matrix-core cycles per 32-deep step.  Measured against float64 the three-term form is
+// closer than the fp32 chain (tools/micro/bf16x3.hip: 8.5e-7 vs 2.2e-6 at depth 64).
+// Same transposed products as above: S^T = K . Q^T (row operand = K rows straight from the bf16 LDS image, 16 B per lane),
+// The softmax normaliser comes out of the matrix core as well: a fifth row-operand fragment of ones sums the probabilities.
+// O^T += V^T . P^T (row operand = V^T through ds_read_b64_tr_b16: the 4 tokens x 16 dims block a 16-lane group needs is
+// exactly the block that instruction transposes; column operand = the lane's own probability registers, no shuffle).
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+
+// fp32 -> three bf16 terms by truncation (exact: a == hi + mid + lo); pair (x, y) packed as (x low half, y high half)
+__device__ __forceinline__ uint32_t top_halves(float x, float y) { return __builtin_amdgcn_perm(__float_as_uint(y), __float_as_uint(x), 0x07060302u); }
+__device__ __forceinline__ void split3_pair(float x, float y, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    const float xr = x - __uint_as_float(__float_as_uint(x) & 0xffff0000u), yr = y - __uint_as_float(__float_as_uint(y) & 0xffff0000u);
+    const float xl = xr - __uint_as_float(__float_as_uint(xr) & 0xffff0000u), yl = yr - __uint_as_float(__float_as_uint(yr) & 0xffff0000u);
+    hi = top_halves(x, y);
+    mid = top_halves(xr, yr);
+    lo = top_halves(xl, yl);
+}
+// LDS images of a 64-token tile, 128-byte rows (64 bf16), 16-byte chunks permuted per row so that both kinds of read are
+// conflict-free: K rows are read whole-chunk by (token c, chunk 4 s + g) lanes, V through the transposing read, where the four
+// lanes of a token row take two neighbouring chunks and eight rows share a 32-lane half
+__device__ __forceinline__ int pb_k(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
+__device__ __forceinline__ int pb_v(int row, int chunk) { return row * 64 + ((chunk ^ (((row >> 1) & 3) << 1)) << 3); }
+
+template <int GS>
+__global__ __launch_bounds__(GS * 64) void paged_attn_prefill_bf16_kernel(const float* __restrict__ q, const __hip_bfloat16* __restrict__ k_cache,
+                                                                          const __hip_bfloat16* __restrict__ v_cache,
+                                                                          const int32_t* __restrict__ block_table, int max_blocks_per_seq,
+                                                                          const int32_t* __restrict__ slot_ids, const int32_t* __restrict__ ctx_len,
+                                                                          float scale, float* __restrict__ out, int n, int kvh, int block) {
+    constexpr int HD = 64, NT = GS * 64, CPT = (PF_TOK * 8 + NT - 1) / NT;  // 16-byte chunks per thread and tensor
+    constexpr float LOG2E = 1.4426950408889634f;
+    __shared__ __attribute__((aligned(16))) unsigned short Kb[PF_TOK * 64];
+    __shared__ __attribute__((aligned(16))) unsigned short Vb[PF_TOK * 64];
+    __shared__ int s_ok[PF_TOK];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int kh = blockIdx.y, head = kh * GS + wid, nh = kvh * GS;
+    const int r = (gridDim.x - 1 - blockIdx.x) * 16 + c;  // this lane's query row (tiles are taken from the back)
+    const bool valid = r < n;
+    const int my_slot = valid ? (slot_ids ? slot_ids[r] : r) : -1;
+    const int my_ctx = valid ? ctx_len[r] : 0;
+    bool done = !valid;
+    const int bshift = (block & (block - 1)) == 0 ? __builtin_ctz(block) : -1;  // power-of-two blocks (the reference's 16): no division
+
+    // Q^T operand of depth step s: dims 32 s + 8 g .. + 7 of query row c, pre-multiplied by scale * log2(e), in three terms
+    uint4 qh[2], qm[2], ql[2];
+    {
+        const float* qp = q + ((int64_t)(valid ? r : 0) * nh + head) * HD;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float4 a = valid ? *(const float4*)(qp + 32 * s2 + 8 * g + 4 * i) : make_float4(0, 0, 0, 0);
+                v[4 * i] = a.x * scale * LOG2E; v[4 * i + 1] = a.y * scale * LOG2E;
+                v[4 * i + 2] = a.z * scale * LOG2E; v[4 * i + 3] = a.w * scale * LOG2E;
+            }
+            split3_pair(v[0], v[1], qh[s2].x, qm[s2].x, ql[s2].x);
+            split3_pair(v[2], v[3], qh[s2].y, qm[s2].y, ql[s2].y);
+            split3_pair(v[4], v[5], qh[s2].z, qm[s2].z, ql[s2].z);
+            split3_pair(v[6], v[7], qh[s2].w, qm[s2].w, ql[s2].w);
+        }
+    }
+
+    while (true) {
+        // rows of one sequence per pass: the first unfinished row picks the sequence
+        const unsigned long long pending = __ballot(!done) & 0xffffull;
+        if (!pending) break;
+        const int lead = __ffsll(pending) - 1;
+        const int cur_slot = __shfl(my_slot, lead);
+        const bool active = !done && my_slot == cur_slot;
+        const int lim = active ? my_ctx : 0;      // causal limit of this lane's query row
+        int kv_end = lim;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) kv_end = max(kv_end, __shfl_xor(kv_end, o));
+        kv_end = __shfl(kv_end, 0);
+        const int32_t* bt = block_table + (int64_t)cur_slot * max_blocks_per_seq;
+        int lim_min = active ? lim : 0x7fffffff;  // a tile below every active row's limit needs no causal mask
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) lim_min = min(lim_min, __shfl_xor(lim_min, o));
+        lim_min = __shfl(lim_min, 0);
+
+        float m = -INFINITY;
+        v4f acc[5];  // acc[j][e] = O^T[dim 16 j + 4 g + e][query row c]; acc[4][*] = the row's normaliser
+#pragma unroll
+        for (int j = 0; j < 5; ++j) acc[j] = (v4f){0, 0, 0, 0};
+
+        v4i32 rk[CPT], rv[CPT];
+        int rok[CPT];
+        auto gload = [&](int t0) {
+#pragma unroll
+            for (int u = 0; u < CPT; ++u) {
+                const int ci = tid + u * NT;
+                const int t = t0 + (ci >> 3), ch = ci & 7;
+                const int tc = max(0, min(t, kv_end - 1));
+                const int bi = bshift >= 0 ? tc >> bshift : tc / block, bo = bshift >= 0 ? tc & (block - 1) : tc % block;
+                const int pb = bt[bi];
+                rok[u] = (t < kv_end && pb >= 0) ? 1 : 0;
+                const int64_t off = (((int64_t)max(pb, 0) * block + bo) * kvh + kh) * HD + ch * 8;
+                rk[u] = *(const v4i32*)(k_cache + off);
+                rv[u] = *(const v4i32*)(v_cache + off);
+            }
+        };
+        if (kv_end > 0) gload(0);
+        for (int t0 = 0; t0 < kv_end; t0 += PF_TOK) {
+            __syncthreads();  // every wave is done with the previous tile
+            int all_ok = 1;
+#pragma unroll
+            for (int u = 0; u < CPT; ++u) {
+                const int ci = tid + u * NT;
+                if (ci < PF_TOK * 8) {
+                    all_ok &= rok[u];
+                    const int tt = ci >> 3, ch = ci & 7;
+                    *(v4i32*)&Kb[pb_k(tt, ch)] = rk[u];
+                    *(v4i32*)&Vb[pb_v(tt, ch)] = rv[u];
+                    if (ch == 0) s_ok[tt] = rok[u];
+                }
+            }
+            const bool plain = __syncthreads_and(all_ok) && (t0 + PF_TOK <= lim_min);
+            if (t0 + PF_TOK < kv_end) gload(t0 + PF_TOK);  // next tile in flight behind the math of this one
+
+            // scores of 64 tokens: S^T tile t holds tokens t0 + 16 t + 4 g + reg of query row c; small terms first
+            v4f sc[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) sc[t] = (v4f){0, 0, 0, 0};
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                v8bf kf[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) kf[t] = __builtin_bit_cast(v8bf, *(const uint4*)&Kb[pb_k(16 * t + c, 4 * s2 + g)]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t], __builtin_bit_cast(v8bf, ql[s2]), sc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t], __builtin_bit_cast(v8bf, qm[s2]), sc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) sc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t], __builtin_bit_cast(v8bf, qh[s2]), sc[t], 0, 0, 0);
+            }
+            float mx = -INFINITY;
+            if (plain) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) mx = fmaxf(mx, fmaxf(fmaxf(sc[t][0], sc[t][1]), fmaxf(sc[t][2], sc[t][3])));
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int tt = 16 * t + 4 * g + e;
+                        const bool live = (t0 + tt < lim) && s_ok[tt];
+                        sc[t][e] = live ? sc[t][e] : -INFINITY;
+                        mx = fmaxf(mx, sc[t][e]);
+                    }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mn = fmaxf(m, mx);
+            if (__ballot(mn != m)) {  // some row's running maximum moved: rescale (rare after the first tiles)
+                const float alpha = (mn == -INFINITY) ? 1.0f : exp2f(m - mn);
+#pragma unroll
+                for (int j = 0; j < 5; ++j) acc[j] *= alpha;
+            }
+            m = mn;
+            const float mref = (mn == -INFINITY) ? 0.0f : mn;  // exp2(-inf - 0) = 0 for masked scores, no per-element test
+#pragma unroll
+            for (int kp = 0; kp < 2; ++kp) {  // 32 tokens per step: the lane's slots are its registers of score tiles 2 kp and 2 kp + 1
+                float pv[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pv[e] = __builtin_amdgcn_exp2f(sc[2 * kp][e] - mref);
+                    pv[4 + e] = __builtin_amdgcn_exp2f(sc[2 * kp + 1][e] - mref);
+                }
+                uint4 ph, pm, pl;
+                split3_pair(pv[0], pv[1], ph.x, pm.x, pl.x);
+                split3_pair(pv[2], pv[3], ph.y, pm.y, pl.y);
+                split3_pair(pv[4], pv[5], ph.z, pm.z, pl.z);
+                split3_pair(pv[6], pv[7], ph.w, pm.w, pl.w);
+                // V^T fragments: lane 4 q + p of the 16-lane group g addresses token 4 g + q, dims 16 j + 4 p .. + 3 and receives dim
+                // 16 j + (its index) of the four tokens; the second block lies 16 tokens further.  The terms go term by term over
+                // the accumulators, so that no MFMA waits on the one just issued.
+                v8bf vf[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    // rows 16 apart share the permutation, so the second block is a constant 16 rows further
+                    const unsigned short* vp = &Vb[pb_v(32 * kp + 4 * g + (c >> 2), 2 * j + ((c >> 1) & 1)) + 4 * (c & 1)];
+                    const v4s lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)vp);
+                    const v4s hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s*)(vp + 16 * 64));
+                    vf[j] = __builtin_bit_cast(v8bf, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+                const v8bf ones = __builtin_bit_cast(v8bf, make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[j], __builtin_bit_cast(v8bf, pl), acc[j], 0, 0, 0);
+                acc[4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, __builtin_bit_cast(v8bf, pl), acc[4], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[j], __builtin_bit_cast(v8bf, pm), acc[j], 0, 0, 0);
+                acc[4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, __builtin_bit_cast(v8bf, pm), acc[4], 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[j], __builtin_bit_cast(v8bf, ph), acc[j], 0, 0, 0);
+                acc[4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, __builtin_bit_cast(v8bf, ph), acc[4], 0, 0, 0);
+            }
+        }
+        const float lsum = acc[4][0];  // every row of the ones fragment carries the normaliser of query row c
+        if (active) {
+            float* op = out + ((int64_t)r * nh + head) * HD + g * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float4 o = make_float4(0, 0, 0, 0);
+                if (lsum > 0.0f) o = make_float4(acc[j][0] / lsum, acc[j][1] / lsum, acc[j][2] / lsum, acc[j][3] / lsum);
+                *(float4*)(op + 16 * j) = o;
+            }
+            done = true;
+        }
+    }
+}
+
 // merge the splits of one query row (all heads) with one workgroup: one float4 of one head per thread and pass;
 // optionally folds min/max of the row into a stat slot
 template <bool COH>
@@ -724,7 +943,7 @@ static int dispatch_gs(int gs, int kv_dtype, const float* q, const void* kc, con
 
 #define PF_MIN_ROWS 256      // from this many rows on, the 16-row-tile matrix-core kernel is used (splits == 1, head_dim 64)
 static unsigned long long* g_attn_stamps = nullptr;  // diagnostics, see i64h_debug_set_attn_stamps
-static int g_prefill_mfma = 1;  // tuning / test knob: 0 = always the row-per-workgroup kernel
+static int g_prefill_mfma = 1;  // tuning / test knob: 0 = always the row-per-workgroup kernel, 1 = matrix cores (bf16 caches: three-term bf16 form), 2 = f32 matrix cores for every cache dtype
 #define ATTN_ARRIVALS 4096  // rows whose splits can be merged by the last-arriving workgroup
 
 extern "C" {
@@ -745,7 +964,8 @@ int i64h_debug_set_attn_stamps(void* buffer) {
 }
 
 int i64h_set_prefill_attn(int32_t on) {
-    g_prefill_mfma = on ? 1 : 0;
+    I64H_CHECK_ARG(on >= 0 && on <= 2, "set_prefill_attn: %d not in {0,1,2}", on);
+    g_prefill_mfma = on;
     return 0;
 }
 
@@ -780,10 +1000,15 @@ int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, in
 #define PF(G, T)                                                                                                                     \
     hipLaunchKernelGGL((paged_attn_prefill_kernel<G, T>), grid, dim3(G * 64), 0, st, q, (const T*)k_cache, (const T*)v_cache, block_table, \
                        (int)max_blocks_per_seq, slot_ids, ctx_len, softmax_scale, out, (int)rows, (int)num_kv_heads, (int)block_size)
+#define PFB(G)                                                                                                                          \
+    hipLaunchKernelGGL((paged_attn_prefill_bf16_kernel<G>), grid, dim3(G * 64), 0, st, q, (const __hip_bfloat16*)k_cache,                 \
+                       (const __hip_bfloat16*)v_cache, block_table, (int)max_blocks_per_seq, slot_ids, ctx_len, softmax_scale, out, (int)rows, \
+                       (int)num_kv_heads, (int)block_size)
 #define PFG(G)                                                  \
     do {                                                        \
         if (kv_dtype == 0) PF(G, float);                        \
         else if (kv_dtype == 1) PF(G, __half);                  \
+        else if (kv_dtype == 2 && g_prefill_mfma == 1) PFB(G);  \
         else if (kv_dtype == 2) PF(G, __hip_bfloat16);          \
         else if (kv_dtype == 3) PF(G, F8E4);                    \
         else PF(G, F8E5);                                       \
@@ -793,6 +1018,7 @@ int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, in
         else if (gs == 4) PFG(4);
         else PFG(8);
 #undef PFG
+#undef PFB
 #undef PF
         I64H_CHECK_LAUNCH();
         return 0;
