@@ -407,8 +407,8 @@ __global__ __launch_bounds__(GS * 64) void paged_attn_prefill_kernel(const float
     }
 }
 
-// ---- prefill form for a bf16 cache: the same tiling on the bf16 matrix cores, at fp32 accuracy -------------------------------
-// K and V are bf16 EXACTLY, so only the fp32 operand of each product has to be widened: Q (and P, the probabilities) is split
+// ---- prefill form for bf16 and 8-bit float caches: the same tiling on the bf16 matrix cores, at fp32 accuracy -------------------------------
+// K and V are bf16 EXACTLY (the 8-bit formats convert to bf16 without rounding), so only the fp32 operand of each product has to be widened: Q (and P, the probabilities) is split
 // into three bf16 terms hi + mid + lo (8 + 8 + 8 significant bits: the sum is the fp32 value bit for bit), every bf16 x bf16
 // product is exact in fp32, and three v_mfma_f32_16x16x32_bf16 (16 cycles each, 32 deep) replace eight v_mfma_f32_16x16x4_f32
 // (32 cycles each): 48 instead of 256 matrix-core cycles per 32-deep step.  Measured against float64 the three-term form is
@@ -436,9 +436,26 @@ __device__ __forceinline__ void split3_pair(float x, float y, uint32_t& hi, uint
 __device__ __forceinline__ int pb_k(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
 __device__ __forceinline__ int pb_v(int row, int chunk) { return row * 64 + ((chunk ^ (((row >> 1) & 3) << 1)) << 3); }
 
-template <int GS>
-__global__ __launch_bounds__(GS * 64) void paged_attn_prefill_bf16_kernel(const float* __restrict__ q, const __hip_bfloat16* __restrict__ k_cache,
-                                                                          const __hip_bfloat16* __restrict__ v_cache,
+// eight cache elements of a token row as eight bf16 (16 bytes): a bf16 cache as it is; the 8-bit float formats convert exactly
+template <typename KV> struct Stage8;
+template <> struct Stage8<__hip_bfloat16> {
+    v4i32 r;
+    __device__ __forceinline__ void load(const __hip_bfloat16* p) { r = *(const v4i32*)p; }
+    __device__ __forceinline__ v4i32 bf16x8() const { return r; }
+};
+template <typename KV> struct Stage8 {
+    Raw8<KV> r;
+    __device__ __forceinline__ void load(const KV* p) { r.load(p); }
+    __device__ __forceinline__ v4i32 bf16x8() const {
+        float f[8];
+        r.get(f);
+        return (v4i32){(int)top_halves(f[0], f[1]), (int)top_halves(f[2], f[3]), (int)top_halves(f[4], f[5]), (int)top_halves(f[6], f[7])};
+    }
+};
+
+template <int GS, typename KV>
+__global__ __launch_bounds__(GS * 64) void paged_attn_prefill_bf16_kernel(const float* __restrict__ q, const KV* __restrict__ k_cache,
+                                                                          const KV* __restrict__ v_cache,
                                                                           const int32_t* __restrict__ block_table, int max_blocks_per_seq,
                                                                           const int32_t* __restrict__ slot_ids, const int32_t* __restrict__ ctx_len,
                                                                           float scale, float* __restrict__ out, int n, int kvh, int block) {
@@ -500,7 +517,7 @@ __global__ __launch_bounds__(GS * 64) void paged_attn_prefill_bf16_kernel(const 
 #pragma unroll
         for (int j = 0; j < 5; ++j) acc[j] = (v4f){0, 0, 0, 0};
 
-        v4i32 rk[CPT], rv[CPT];
+        Stage8<KV> rk[CPT], rv[CPT];
         int rok[CPT];
         auto gload = [&](int t0) {
 #pragma unroll
@@ -512,8 +529,8 @@ __global__ __launch_bounds__(GS * 64) void paged_attn_prefill_bf16_kernel(const 
                 const int pb = bt[bi];
                 rok[u] = (t < kv_end && pb >= 0) ? 1 : 0;
                 const int64_t off = (((int64_t)max(pb, 0) * block + bo) * kvh + kh) * HD + ch * 8;
-                rk[u] = *(const v4i32*)(k_cache + off);
-                rv[u] = *(const v4i32*)(v_cache + off);
+                rk[u].load(k_cache + off);
+                rv[u].load(v_cache + off);
             }
         };
         if (kv_end > 0) gload(0);
@@ -526,8 +543,8 @@ __global__ __launch_bounds__(GS * 64) void paged_attn_prefill_bf16_kernel(const 
                 if (ci < PF_TOK * 8) {
                     all_ok &= rok[u];
                     const int tt = ci >> 3, ch = ci & 7;
-                    *(v4i32*)&Kb[pb_k(tt, ch)] = rk[u];
-                    *(v4i32*)&Vb[pb_v(tt, ch)] = rv[u];
+                    *(v4i32*)&Kb[pb_k(tt, ch)] = rk[u].bf16x8();
+                    *(v4i32*)&Vb[pb_v(tt, ch)] = rv[u].bf16x8();
                     if (ch == 0) s_ok[tt] = rok[u];
                 }
             }
@@ -1000,15 +1017,16 @@ int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, in
 #define PF(G, T)                                                                                                                     \
     hipLaunchKernelGGL((paged_attn_prefill_kernel<G, T>), grid, dim3(G * 64), 0, st, q, (const T*)k_cache, (const T*)v_cache, block_table, \
                        (int)max_blocks_per_seq, slot_ids, ctx_len, softmax_scale, out, (int)rows, (int)num_kv_heads, (int)block_size)
-#define PFB(G)                                                                                                                          \
-    hipLaunchKernelGGL((paged_attn_prefill_bf16_kernel<G>), grid, dim3(G * 64), 0, st, q, (const __hip_bfloat16*)k_cache,                 \
-                       (const __hip_bfloat16*)v_cache, block_table, (int)max_blocks_per_seq, slot_ids, ctx_len, softmax_scale, out, (int)rows, \
-                       (int)num_kv_heads, (int)block_size)
+#define PFB(G, T)                                                                                                                          \
+    hipLaunchKernelGGL((paged_attn_prefill_bf16_kernel<G, T>), grid, dim3(G * 64), 0, st, q, (const T*)k_cache, (const T*)v_cache, block_table, \
+                       (int)max_blocks_per_seq, slot_ids, ctx_len, softmax_scale, out, (int)rows, (int)num_kv_heads, (int)block_size)
 #define PFG(G)                                                  \
     do {                                                        \
         if (kv_dtype == 0) PF(G, float);                        \
         else if (kv_dtype == 1) PF(G, __half);                  \
-        else if (kv_dtype == 2 && g_prefill_mfma == 1) PFB(G);  \
+        else if (kv_dtype == 2 && g_prefill_mfma == 1) PFB(G, __hip_bfloat16); \
+        else if (kv_dtype == 3 && g_prefill_mfma == 1) PFB(G, F8E4);           \
+        else if (kv_dtype == 4 && g_prefill_mfma == 1) PFB(G, F8E5);           \
         else if (kv_dtype == 2) PF(G, __hip_bfloat16);          \
         else if (kv_dtype == 3) PF(G, F8E4);                    \
         else PF(G, F8E5);                                       \
