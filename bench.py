@@ -9,7 +9,8 @@ expert) with every Linear in the reference CPU engine's dynamic int8 scheme; 64 
 one decode step of the whole batch: routing plan, 24 layers, lm_head, argmax, position advance - one HIP graph replay.
 With N GPUs every rank serves its own 64 sequences (weak scaling, no collective on the data path).
 
-Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
+Prints ONE JSON line on rank 0: metric / value / unit / n_gpus / steps / warmup / ms_per_step / scaling / dtype / data / config, plus the
+roofline objects of the dominant decode kernel and of the grouped expert GEMM, and the CPU baseline.
 """
 from __future__ import annotations
 

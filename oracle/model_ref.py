@@ -105,7 +105,7 @@ def named_config(name: str) -> SynthConfig:
 
 
 # ----------------------------------------------------------------------------------------------
-# synthetic weights / tables / ids (SURVEY-defined protocol: N(0, 0.02) on every >=2-D weight, norms = 1)
+# synthetic weights / tables / ids (benchmark protocol: N(0, 0.02) on every >=2-D weight, the config's initializer_range; norms = 1)
 # ----------------------------------------------------------------------------------------------
 
 def make_tables(cfg: SynthConfig) -> List[torch.Tensor]:
