@@ -116,7 +116,10 @@ def main():
     kv_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "fp16": torch.float16, "fp8": torch.float8_e4m3fn,
                 "fp8_e5m2": torch.float8_e5m2}[args.kv_dtype]
     B, P = args.batch, args.prompt_len
-    assert P + args.steps + args.warmup + 2 <= cfg.max_pos, "prompt + decode steps exceed max_pos"
+    need = P + args.steps + args.warmup + 2
+    if need > cfg.max_pos:  # a longer run than the config's position range: extend the range (rope table, block table, cache) for it
+        import dataclasses
+        cfg = dataclasses.replace(cfg, max_pos=(need + 255) // 256 * 256)
     t0 = time.time()
     weights = synth.make_weights(cfg, seed=0)
     ep_mode = args.parallelism == "ep"
