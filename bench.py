@@ -157,6 +157,7 @@ def main():
         dec.set_state(first, [P] * B, reserve_extra=total_len - P)
 
     # ---- decode: W warm-up steps, then exactly K timed steps ----
+    dec.prepare()  # buffer allocation and graph capture are set-up, not steps (no state advances)
     for _ in range(args.warmup):
         dec.step()
     torch.cuda.synchronize()

@@ -431,31 +431,39 @@ class GreedyDecoder:
             self._step_body()
             return self.logits
         if self.graph is None:
-            # warm up eagerly on a side stream (allocates every buffer), restoring the state afterwards, then capture
-            state = (self.tokens.clone(), self.positions.clone(), self.ctx_len.clone())
-            s = torch.cuda.Stream(device=self.m.device)
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                self._step_body()
-            torch.cuda.current_stream().wait_stream(s)
-            for dst, src in zip((self.tokens, self.positions, self.ctx_len), state):
-                dst.copy_(src)
-            torch.cuda.synchronize()
-            self.graph = torch.cuda.CUDAGraph()
-            try:
-                # thread_local: other threads of the process (e.g. a collective library's watchdog) may touch the runtime
-                # while this thread captures
-                with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                    self._step_body()
-            except Exception as e:  # no graph on this platform / in this process: same step, launched eagerly
-                import warnings
-                warnings.warn(f"HIP graph capture of the decode step failed ({e!r}); decoding without a graph")
-                self.graph, self.use_graph = None, False
-                torch.cuda.synchronize()
-            for dst, src in zip((self.tokens, self.positions, self.ctx_len), state):
-                dst.copy_(src)
+            self.prepare()
             if self.graph is None:
                 self._step_body()
                 return self.logits
         self.graph.replay()
         return self.logits
+
+    def prepare(self) -> None:
+        """Set-up of the graph path, state-preserving (tokens / positions / context lengths are restored): allocate every buffer
+        by one eager step on a side stream, then capture the step.  step() calls it on first use; a caller that times steps
+        calls it beforehand."""
+        if not self.use_graph or self.graph is not None:
+            return
+        # warm up eagerly on a side stream (allocates every buffer), restoring the state afterwards, then capture
+        state = (self.tokens.clone(), self.positions.clone(), self.ctx_len.clone())
+        s = torch.cuda.Stream(device=self.m.device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._step_body()
+        torch.cuda.current_stream().wait_stream(s)
+        for dst, src in zip((self.tokens, self.positions, self.ctx_len), state):
+            dst.copy_(src)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        try:
+            # thread_local: other threads of the process (e.g. a collective library's watchdog) may touch the runtime
+            # while this thread captures
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self._step_body()
+        except Exception as e:  # no graph on this platform / in this process: same step, launched eagerly
+            import warnings
+            warnings.warn(f"HIP graph capture of the decode step failed ({e!r}); decoding without a graph")
+            self.graph, self.use_graph = None, False
+            torch.cuda.synchronize()
+        for dst, src in zip((self.tokens, self.positions, self.ctx_len), state):
+            dst.copy_(src)
