@@ -119,6 +119,7 @@ typedef struct i64h_gemm_desc {
     uint32_t* stats;
     int32_t want_stats;
     const float* col_scale;       /* epilogue 0, int8 operand, optional: per-output-channel scale [G][N] replacing w_scale[g] */
+    const int32_t* c_row_map;     /* epilogue 0, optional: operand row r is stored as output row c_row_map[r] (e.g. expert outputs straight back in (route, token) order) */
 } i64h_gemm_desc;
 int i64h_gemm_i8_pair(const i64h_gemm_desc* a, const i64h_gemm_desc* b, void* stream);
 /* Decode-sized fused form (fp32 operand quantized in the kernel from its stat slot, one group, <= 512 rows, K % 64 == 0,
@@ -206,7 +207,7 @@ int i64h_rmsnorm(const float* x, const float* weight, float* out, int64_t rows, 
 /* Residual update + MoE combine + RMSNorm + call statistics in one pass (decoder-layer glue, model.py:349-363, and
  * the weighted combine of TokenRoutedMLP.forward, token_routed_mlp.py:156-185):
  *   v = h (+ add) (+ routed_scale * sum_k w_k * moe_rows[moe_inv[k*n+t]] (+ shared_scale * moe_shared));  h_out = v;
- *   h NULL: no residual stream (v = the bare MoE output);
+ *   h NULL: no residual stream (v = the bare MoE output); moe_inv NULL: moe_rows already lie in (route, token) order, row k*n+t;
  *   normed = rmsnorm(v) (skipped if normed NULL); min/max(normed row) -> slots (skipped if stats NULL).
  * route_weights is a HOST array of top_k floats. */
 int i64h_fused_residual_norm(const float* h, const float* add, const float* moe_rows, const int32_t* moe_inv, const float* moe_shared,

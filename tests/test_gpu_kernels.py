@@ -193,6 +193,16 @@ def test_gemm_i8_fused_quantize_matches_two_step(dev, M_, K_, G_):
         d2 = ops.gemm_desc(x, w[0], ws[:1], out2, a_slot_base=5, epilogue=epi, stats=stats)
         ops.gemm_i8_pair(d, d2)
         assert torch.equal(out, ref) and torch.equal(out2, ref2)
+    # output row map: rows stored scattered (what the down projection of the MoE layer does with the plan's permutation)
+    rmap = torch.randperm(M_ + 5, generator=g)[:M_].to(torch.int32).to(dev)
+    base = ops.gemm_i8(a, scale, w, ws, group_offsets=off)
+    scat = torch.zeros(M_ + 5, base.shape[1], device=dev)
+    d = ops.gemm_desc(x, w, ws, scat, a_src_row=src, a_src_mod=n_src, a_row_slot=slot, a_slot_base=1, group_offsets=off, stats=stats,
+                      m_total=M_, c_row_map=rmap)
+    ops.gemm_i8_pair(d)
+    want = torch.zeros_like(scat)
+    want[rmap.long()] = base
+    assert torch.equal(scat, want)
     # SwiGLU with the statistics of the result folded in (the next call's quantization range): the per-workgroup table shares
     # LDS with the operand rows, which are smaller than the table for K < 224
     oslot = torch.randint(0, 3, (M_,), generator=g, dtype=torch.int32).to(dev)

@@ -42,6 +42,7 @@ struct GemmI8Args {
     const int8_t* B;           // [G][N][K]
     const float* w_scale;      // [G]
     const float* col_scale;    // EPI_STORE, optional: per-output-channel scale [G][N] used instead of w_scale[g]
+    const int32_t* c_row_map;  // EPI_STORE, optional: operand row r is stored as output row c_row_map[r] (not in the row-streaming kernel)
     const int32_t* group_off;  // [G+1] device, or nullptr => one group [0, M_total)
     int G, M_total, N, K;
     float* C;                  // EPI_STORE: [M_total, N]; EPI_SWIGLU: [M_total, N/2]
@@ -313,11 +314,12 @@ __device__ __forceinline__ void gemm_i8_body(const GemmI8Args& p, const int bid,
                 const int r = wm * WM + i * 16 + fq * 4 + reg;
                 if (r >= rows) continue;
                 const float m = q_scale[r] * ws;
+                const int64_t orow = p.c_row_map ? p.c_row_map[row0 + r] : row0 + r;
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
                     const int c = nt * BN + wn * WN + j * 16 + fr;
                     if (c < p.N)
-                        p.C[(int64_t)(row0 + r) * p.N + c] =
+                        p.C[orow * p.N + c] =
                             (float)acc[i][j][reg] * (p.col_scale ? q_scale[r] * p.col_scale[(int64_t)g * p.N + c] : m);
                 }
             }
@@ -782,6 +784,17 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
     // requested before them would have to land before the parameters can be derived
     uint4 sw[I64H_SLOT_WORDS / 4];
     if (tid < rows) stat_load_raw(p.stats, p.a_slot_base + (p.a_row_slot ? p.a_row_slot[row0 + tid] : 0), sw);
+    // output rows of this lane's four accumulator rows (a scatter back to token order spares the consumer an index lookup)
+    int c_row[SK_MF][4];
+    if (EPI == EPI_STORE) {
+#pragma unroll
+        for (int i = 0; i < SK_MF; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = i * 16 + fq * 4 + reg;
+                c_row[i][reg] = (p.c_row_map && r < rows) ? p.c_row_map[row0 + r] : row0 + r;
+            }
+    }
 
     SK_STAMP(7);
     // then the first batch of weight fragments
@@ -886,7 +899,7 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int r = i * 16 + fq * 4 + reg;
-                if (r < rows && col_ok) p.C[(int64_t)(row0 + r) * p.N + col] = (float)acc[i][0][reg] * (q_scale[r] * ws);
+                if (r < rows && col_ok) p.C[(int64_t)c_row[i][reg] * p.N + col] = (float)acc[i][0][reg] * (q_scale[r] * ws);
             }
     } else if constexpr (EPI == EPI_QKR) {
         // The workgroup's 64 columns are exactly one head (launcher: head_dim == 64 == NW * 16), so the per-head RMSNorm, the
@@ -1160,6 +1173,7 @@ struct i64h_gemm_desc {
     uint32_t* stats;
     int32_t want_stats;
     const float* col_scale;
+    const int32_t* c_row_map;
 };
 
 static int check_desc(const i64h_gemm_desc* d, const char* who) {
@@ -1184,6 +1198,7 @@ static GemmI8Args to_args(const i64h_gemm_desc* d) {
     p.stats = d->stats; p.want_stats = d->want_stats;
     p.stamps = nullptr;
     p.col_scale = d->col_scale;
+    p.c_row_map = d->c_row_map;
     return p;
 }
 
@@ -1346,11 +1361,13 @@ int i64h_gemm_i8_pair(const i64h_gemm_desc* a, const i64h_gemm_desc* b, void* st
         I64H_CHECK_ARG(a->epilogue == b->epilogue && a->a_fp32 == b->a_fp32, "gemm_i8_pair: problems must share epilogue and operand kind");
     }
     hipStream_t st = (hipStream_t)stream;
+    const bool mapped = a->c_row_map != nullptr || (b && b->c_row_map != nullptr);
+    I64H_CHECK_ARG(!mapped || a->epilogue == EPI_STORE, "gemm_i8_pair: an output row map needs the plain epilogue");
     if (skinny_ok(a) && (!b || skinny_ok(b)))
         return a->epilogue == EPI_STORE ? launch_skinny_nw<EPI_STORE>(a, b, st) : launch_skinny_nw<EPI_SWIGLU>(a, b, st);
     // prefill-sized int8 operands: the row-streaming kernel where it is the faster one (measured: SwiGLU problems, -20 %; plain
     // stores are bound by the output stream and do better with four small workgroups per CU)
-    if (rs_ok(a) && (!b || rs_ok(b)) && (g_rowstream == 2 || (g_rowstream == 1 && a->epilogue == EPI_SWIGLU)))
+    if (!mapped && rs_ok(a) && (!b || rs_ok(b)) && (g_rowstream == 2 || (g_rowstream == 1 && a->epilogue == EPI_SWIGLU)))
         return a->epilogue == EPI_STORE ? launch_rs<EPI_STORE, 2>(a, b, st) : launch_rs<EPI_SWIGLU, 2>(a, b, st);
     const int64_t rows = a->M_total / a->num_groups;
     const bool big = !a->a_fp32 && rows >= 256;  // fp32 operands are meant for small M (quantized per workgroup)
@@ -1395,7 +1412,7 @@ int i64h_gemm_i8_colscale(const int8_t* A, const float* row_scale, const int8_t*
 // ---- decode-sized fused forms (fp32 operand quantized in the kernel, one group, at most 512 rows) -------------------------
 static int check_fused(const i64h_gemm_desc* d, const char* who) {
     if (int rc = check_desc(d, who)) return rc;
-    I64H_CHECK_ARG(skinny_ok(d) && d->group_offsets == nullptr && d->epilogue == EPI_STORE && d->a_src_row == nullptr,
+    I64H_CHECK_ARG(skinny_ok(d) && d->group_offsets == nullptr && d->epilogue == EPI_STORE && d->a_src_row == nullptr && d->c_row_map == nullptr,
                    "%s: needs an fp32 operand of at most 512 rows, one group, K a multiple of 64 up to 2048, plain epilogue", who);
     return 0;
 }

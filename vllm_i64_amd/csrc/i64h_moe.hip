@@ -123,6 +123,7 @@ int i64h_moe_forward(const float* x, const int64_t* token_ids, int64_t n, const 
         d.A = s.e_inter; d.a_fp32 = 1; d.a_row_slot = s.sorted_bucket; d.a_slot_base = S_B_DN; d.B = L->exp_down; d.w_scale = L->exp_down_scale;
         d.group_offsets = s.expert_offsets; d.num_groups = L->num_experts; d.M_total = R; d.N = L->hidden; d.K = L->expert_inter; d.C = s.e_out;
         d.stats = s.stats;
+        d.c_row_map = s.perm;  // rows go straight back to (route, token) order: the combine below needs no index lookup
         if (shared) {
             sd.A = s.sh_inter; sd.a_fp32 = 1; sd.a_slot_base = S_SH_DN; sd.B = L->shared_down; sd.w_scale = L->shared_down_scale;
             sd.num_groups = 1; sd.M_total = n; sd.N = L->hidden; sd.K = L->shared_inter; sd.C = s.sh_out; sd.stats = s.stats;
@@ -146,7 +147,7 @@ int i64h_moe_forward(const float* x, const int64_t* token_ids, int64_t n, const 
                           nullptr, 0, nullptr, stream));
     }
     // out = routed_scale * sum_k w_k * R_k + shared_scale * shared, in the reference's evaluation order
-    STEP(i64h_fused_residual_norm(nullptr, nullptr, s.e_out, s.inv, shared ? s.sh_out : nullptr, L->route_weights, L->top_k, L->routed_scale,
+    STEP(i64h_fused_residual_norm(nullptr, nullptr, s.e_out, R <= kFuseMaxRows ? nullptr : s.inv, shared ? s.sh_out : nullptr, L->route_weights, L->top_k, L->routed_scale,
                                   L->shared_scale, out, nullptr, 0.0f, nullptr, n, L->hidden, nullptr, 0, 0, nullptr, stream));
 #undef STEP
     return 0;

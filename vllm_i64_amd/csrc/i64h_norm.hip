@@ -83,10 +83,10 @@ __global__ __launch_bounds__(256) void fused_residual_norm_kernel(const float* _
                     a.x = a.x + b.x; a.y = a.y + b.y; a.z = a.z + b.z; a.w = a.w + b.w;
                 }
                 if (mc.rows) {
-                    float4 r0 = ((const float4*)(mc.rows + (int64_t)mc.inv[t] * H))[i];
+                    float4 r0 = ((const float4*)(mc.rows + (int64_t)(mc.inv ? mc.inv[t] : t) * H))[i];
                     float4 o = make_float4(mc.wk[0] * r0.x, mc.wk[0] * r0.y, mc.wk[0] * r0.z, mc.wk[0] * r0.w);
                     for (int k = 1; k < mc.top_k; ++k) {
-                        float4 rk = ((const float4*)(mc.rows + (int64_t)mc.inv[(int64_t)k * n + t] * H))[i];
+                        float4 rk = ((const float4*)(mc.rows + (int64_t)(mc.inv ? mc.inv[(int64_t)k * n + t] : (int64_t)k * n + t) * H))[i];
                         o.x = o.x + mc.wk[k] * rk.x; o.y = o.y + mc.wk[k] * rk.y;
                         o.z = o.z + mc.wk[k] * rk.z; o.w = o.w + mc.wk[k] * rk.w;
                     }
@@ -372,7 +372,7 @@ int i64h_fused_residual_norm(const float* h, const float* add, const float* moe_
     I64H_CHECK_ARG(n >= 0 && H > 0 && H % 4 == 0 && H <= 1024 * FRN_MAXV, "fused_residual_norm: H=%d unsupported (multiple of 4, <= %d)", H,
                    1024 * FRN_MAXV);
     I64H_CHECK_ARG(top_k >= 0 && top_k <= 8, "fused_residual_norm: top_k=%d unsupported", top_k);
-    I64H_CHECK_ARG(moe_rows == nullptr || (moe_inv != nullptr && route_weights != nullptr && top_k > 0), "fused_residual_norm: moe args");
+    I64H_CHECK_ARG(moe_rows == nullptr || (route_weights != nullptr && top_k > 0), "fused_residual_norm: moe args");  // moe_inv NULL: rows already in (route, token) order
     if (n == 0) return 0;
     MoeCombine mc;
     mc.rows = moe_rows;

@@ -298,10 +298,10 @@ class I64MoEModel:
             elif cfg.is_moe:
                 if record is not None:
                     record[f"l{l}.mlp_in"] = B.normed.clone()
-                self._moe(B, W, l, base)
+                moe_inv = self._moe(B, W, l, base)
                 nxt = self.layers[l + 1]["ln1"] if l + 1 < cfg.num_layers else self.final_norm
                 last = l + 1 == cfg.num_layers
-                ops.fused_residual_norm(B.h, nxt, eps, moe_rows=B.e_out, moe_inv=B.plan.inv[l],
+                ops.fused_residual_norm(B.h, nxt, eps, moe_rows=B.e_out, moe_inv=moe_inv,
                                         moe_shared=B.sh_out if cfg.shared_intermediate_size else None, route_weights=rw,
                                         routed_scale=cfg.routed_scale, shared_scale=cfg.shared_scale, h_out=B.h, normed=B.normed,
                                         slot_base=base + spl, stats=None if last else st)
@@ -324,7 +324,8 @@ class I64MoEModel:
 
     def _moe(self, B: _Buffers, W: dict, l: int, base: int):
         """Routed experts (grouped by expert, rows in bucket order) + shared expert; outputs stay in B.e_out / B.sh_out and
-        are combined by the next fused_residual_norm (token_routed_mlp.py:154-187)."""
+        are combined by the next fused_residual_norm (token_routed_mlp.py:154-187).  Returns the inverse map the combine has to
+        read B.e_out through (None: the rows already lie in (route, token) order)."""
         cfg, st, nbk = self.cfg, self.stats, self.nb
         plan = B.plan
         n, R = plan.n, plan.rows
@@ -339,16 +340,19 @@ class I64MoEModel:
             s_gu = ops.gemm_desc(B.normed, W["sh_gu"].w_q, W["sh_gu"].w_s, B.sh_inter, a_slot_base=base + 2, epilogue=ops.EPI_SWIGLU,
                                  out_slot_base=base + 3 + nbk, stats=st, want_stats=True) if shared else None
             ops.gemm_i8_pair(e_gu, s_gu)
+            # the down projection stores its rows straight back in (route, token) order (plan.perm: sorted row -> k * n + t), so
+            # the combine needs no index lookup in front of its row reads
             e_dn = ops.gemm_desc(B.e_inter, W["exp_dn"].w_q, W["exp_dn"].w_s, B.e_out, a_row_slot=plan.sorted_bucket[l],
-                                 a_slot_base=base + 4 + nbk, group_offsets=plan.expert_offsets[l], stats=st, m_total=R)
+                                 a_slot_base=base + 4 + nbk, group_offsets=plan.expert_offsets[l], stats=st, m_total=R,
+                                 c_row_map=plan.perm[l])
             s_dn = ops.gemm_desc(B.sh_inter, W["sh_dn"].w_q, W["sh_dn"].w_s, B.sh_out, a_slot_base=base + 3 + nbk, stats=st) if shared else None
             ops.gemm_i8_pair(e_dn, s_dn)
-            return
+            return None
         if shared:
             self._linear(B.normed, W["sh_gu"], base + 2, B.xa, B.xs, B.sh_inter, epilogue=ops.EPI_SWIGLU, stats_slot=base + 3 + nbk)
             self._linear(B.sh_inter, W["sh_dn"], base + 3 + nbk, B.sha, B.shs, B.sh_out)
         if R == 0:
-            return
+            return plan.inv[l]
         # every (route, expert) bucket is its own Linear call: rows gathered in bucket order, bucket statistics
         ops.call("i64h_quantize_dynamic", ops.ptr(B.normed), R, cfg.hidden_size, ops.ptr(plan.perm[l]), n, ops.ptr(plan.sorted_bucket[l]),
                  base + 3, ops.ptr(st), ops.ptr(B.ea), ops.ptr(B.es), 0, ops._stream())
@@ -357,6 +361,7 @@ class I64MoEModel:
         ops.call("i64h_quantize_dynamic", ops.ptr(B.e_inter), R, cfg.expert_inter, 0, 0, ops.ptr(plan.sorted_bucket[l]), base + 4 + nbk,
                  ops.ptr(st), ops.ptr(B.eia), ops.ptr(B.eis), 0, ops._stream())
         ops.gemm_i8(B.eia, B.eis, W["exp_dn"].w_q, W["exp_dn"].w_s, group_offsets=plan.expert_offsets[l], out=B.e_out)
+        return plan.inv[l]
 
     # ---- stand-alone MoE layer (operator form of TokenRoutedMLP.forward) ----
     def moe_layer(self, l: int, x: torch.Tensor, token_ids: torch.Tensor) -> torch.Tensor:
@@ -369,9 +374,9 @@ class I64MoEModel:
         base = l * self.spl
         B.normed.copy_(x)
         ops.rows_minmax(B.normed, self.stats, slots=B.plan.tok_slots[l], slot_base=base + 2)
-        self._moe(B, self.layers[l], l, base)
+        moe_inv = self._moe(B, self.layers[l], l, base)
         zero = torch.zeros_like(x)
-        out, _ = ops.fused_residual_norm(zero, None, cfg.rms_eps, moe_rows=B.e_out, moe_inv=B.plan.inv[l],
+        out, _ = ops.fused_residual_norm(zero, None, cfg.rms_eps, moe_rows=B.e_out, moe_inv=moe_inv,
                                          moe_shared=B.sh_out if cfg.shared_intermediate_size else None,
                                          route_weights=cfg.route_weights, routed_scale=cfg.routed_scale,
                                          shared_scale=cfg.shared_scale, want_normed=False)
