@@ -10,6 +10,8 @@ from typing import Dict, Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libi64hip.so")
+if os.environ.get("I64H_LIBRARY"):  # another build of the same library (A/B timing of kernel variants)
+    LIB_PATH = os.environ["I64H_LIBRARY"]
 
 _P, _I, _L, _F = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 
@@ -79,7 +81,7 @@ class GemmDesc(ctypes.Structure):
     _fields_ = [("A", _P), ("a_fp32", _I), ("a_src_row", _P), ("a_src_mod", _I), ("row_scale", _P), ("a_row_slot", _P),
                 ("a_slot_base", _I), ("B", _P), ("w_scale", _P), ("group_offsets", _P), ("num_groups", _I), ("M_total", _L),
                 ("N", _I), ("K", _I), ("C", _P), ("epilogue", _I), ("out_row_slot", _P), ("out_slot_base", _I), ("stats", _P),
-                ("want_stats", _I), ("col_scale", _P), ("c_row_map", _P)]
+                ("want_stats", _I), ("col_scale", _P), ("c_row_map", _P), ("a_group_slots", _I)]
 
 
 class MoeLayer(ctypes.Structure):

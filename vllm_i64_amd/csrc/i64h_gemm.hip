@@ -43,6 +43,7 @@ struct GemmI8Args {
     const float* w_scale;      // [G]
     const float* col_scale;    // EPI_STORE, optional: per-output-channel scale [G][N] used instead of w_scale[g]
     const int32_t* c_row_map;  // EPI_STORE, optional: operand row r is stored as output row c_row_map[r] (not in the row-streaming kernel)
+    int a_group_slots;         // a_fp32, optional promise: a_row_slot[r] of a row of group g lies in [g * S, g * S + S) (S = this value)
     const int32_t* group_off;  // [G+1] device, or nullptr => one group [0, M_total)
     int G, M_total, N, K;
     float* C;                  // EPI_STORE: [M_total, N]; EPI_SWIGLU: [M_total, N/2]
@@ -732,26 +733,19 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 #define SK_STAMP(i) do { if (p.stamps && tid == 0) p.stamps[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     SK_STAMP(0);
-    if (tid == 0) {
-        int g = -1, row0 = 0, rows = 0, acc_tiles = 0;
-        const int G = p.group_off ? p.G : 1;
-        for (int i = 0; i < G; ++i) {
-            const int b = p.group_off ? p.group_off[i] : 0;
-            const int e = p.group_off ? p.group_off[i + 1] : p.M_total;
-            const int tiles = (e - b + SK_BM - 1) / SK_BM;
-            if (mt < acc_tiles + tiles) {
-                g = i;
-                row0 = b + (mt - acc_tiles) * SK_BM;
-                rows = min(SK_BM, e - row0);
-                break;
-            }
-            acc_tiles += tiles;
-        }
-        s_info[0] = g; s_info[1] = row0; s_info[2] = rows;
+    int g, row0, rows;
+    if (p.group_off == nullptr) {  // one group: nothing to look up
+        g = 0;
+        row0 = mt * SK_BM;
+        rows = min(SK_BM, p.M_total - row0);
+        if (rows <= 0) return;
+    } else {
+        if (wid == 0) locate_mtile<SK_BM>(p, mt, lane, s_info);  // one round trip: lane i looks at group i
+        __syncthreads();
+        g = s_info[0]; row0 = s_info[1]; rows = s_info[2];
+        if (g < 0) return;
     }
-    __syncthreads();
-    const int g = s_info[0], row0 = s_info[1], rows = s_info[2];
-    if (g < 0) return;
+    const float ws = p.w_scale[g];  // requested now, used by the epilogue
     SK_STAMP(6);
     // EPI_QKR: cache slot and rotation of this wave's rows (wid, wid + 4, ...) are looked up now, far ahead of their use
     int qk_pos[4] = {0, 0, 0, 0}, qk_pb[4] = {0, 0, 0, 0};
@@ -782,8 +776,22 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
 
     // the statistics of the rows' Linear calls are requested first: vector loads retire in order, so everything that is
     // requested before them would have to land before the parameters can be derived
-    uint4 sw[I64H_SLOT_WORDS / 4];
-    if (tid < rows) stat_load_raw(p.stats, p.a_slot_base + (p.a_row_slot ? p.a_row_slot[row0 + tid] : 0), sw);
+    // Rows of a group that can only use the group's own one or two slots (the (route, expert) buckets of an expert): both
+    // candidates are requested now, next to the row's slot index, instead of after it.
+    uint4 sw[I64H_SLOT_WORDS / 4], sw1[I64H_SLOT_WORDS / 4];
+    const bool by_group = p.a_row_slot != nullptr && (p.a_group_slots == 1 || p.a_group_slots == 2);
+    int slot_rel = 0;
+    if (tid < rows) {
+        if (by_group) {
+            stat_load_raw(p.stats, p.a_slot_base + g * p.a_group_slots, sw);
+            if (p.a_group_slots == 2) {
+                stat_load_raw(p.stats, p.a_slot_base + g * 2 + 1, sw1);
+                slot_rel = p.a_row_slot[row0 + tid] - g * 2;
+            }
+        } else {
+            stat_load_raw(p.stats, p.a_slot_base + (p.a_row_slot ? p.a_row_slot[row0 + tid] : 0), sw);
+        }
+    }
     // output rows of this lane's four accumulator rows (a scatter back to token order spares the consumer an index lookup)
     int c_row[SK_MF][4];
     if (EPI == EPI_STORE) {
@@ -838,7 +846,8 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
         q.scale = 0.0f; q.inv_scale = 0.0f; q.zp = 0;
         if (tid < rows) {
             float lo, hi;
-            stat_fold_raw(sw, lo, hi);
+            if (by_group && slot_rel == 1) stat_fold_raw(sw1, lo, hi);
+            else stat_fold_raw(sw, lo, hi);
             q = choose_qparams_u7(lo, hi);
         }
         q_inv[tid] = q.inv_scale; q_scale[tid] = q.scale; q_zp[tid] = q.zp;
@@ -892,7 +901,6 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
     }
 
     SK_STAMP(4);
-    const float ws = p.w_scale[g];
     if constexpr (EPI == EPI_STORE) {
 #pragma unroll
         for (int i = 0; i < SK_MF; ++i)
@@ -1174,6 +1182,7 @@ struct i64h_gemm_desc {
     int32_t want_stats;
     const float* col_scale;
     const int32_t* c_row_map;
+    int32_t a_group_slots;
 };
 
 static int check_desc(const i64h_gemm_desc* d, const char* who) {
@@ -1199,6 +1208,7 @@ static GemmI8Args to_args(const i64h_gemm_desc* d) {
     p.stamps = nullptr;
     p.col_scale = d->col_scale;
     p.c_row_map = d->c_row_map;
+    p.a_group_slots = d->a_group_slots;
     return p;
 }
 

@@ -113,6 +113,7 @@ int i64h_moe_forward(const float* x, const int64_t* token_ids, int64_t n, const 
         e.B = L->exp_gate_up; e.w_scale = L->exp_gate_up_scale; e.group_offsets = s.expert_offsets; e.num_groups = L->num_experts;
         e.M_total = R; e.N = 2 * L->expert_inter; e.K = L->hidden; e.C = s.e_inter; e.epilogue = 1;
         e.out_row_slot = s.sorted_bucket; e.out_slot_base = S_B_DN; e.stats = s.stats; e.want_stats = 1;
+        e.a_group_slots = L->top_k;  // bucket = expert * top_k + route
         if (shared) {
             sh.A = x; sh.a_fp32 = 1; sh.a_slot_base = S_SH_GU; sh.B = L->shared_gate_up; sh.w_scale = L->shared_gate_up_scale;
             sh.num_groups = 1; sh.M_total = n; sh.N = 2 * L->shared_inter; sh.K = L->hidden; sh.C = s.sh_inter; sh.epilogue = 1;
@@ -123,6 +124,7 @@ int i64h_moe_forward(const float* x, const int64_t* token_ids, int64_t n, const 
         d.A = s.e_inter; d.a_fp32 = 1; d.a_row_slot = s.sorted_bucket; d.a_slot_base = S_B_DN; d.B = L->exp_down; d.w_scale = L->exp_down_scale;
         d.group_offsets = s.expert_offsets; d.num_groups = L->num_experts; d.M_total = R; d.N = L->hidden; d.K = L->expert_inter; d.C = s.e_out;
         d.stats = s.stats;
+        d.a_group_slots = L->top_k;
         d.c_row_map = s.perm;  // rows go straight back to (route, token) order: the combine below needs no index lookup
         if (shared) {
             sd.A = s.sh_inter; sd.a_fp32 = 1; sd.a_slot_base = S_SH_DN; sd.B = L->shared_down; sd.w_scale = L->shared_down_scale;

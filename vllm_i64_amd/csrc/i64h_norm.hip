@@ -68,6 +68,15 @@ __global__ __launch_bounds__(256) void fused_residual_norm_kernel(const float* _
         __syncthreads();
     }
     const int nv = H / 4;
+    // one row per workgroup: the row's slot ids are fetched now, so that the statistics update at the end does not start
+    // with a dependent read
+    int early_slot[4] = {0, 0, 0, 0};
+    const bool early = !use_tab && stats != nullptr && slots != nullptr && spr <= 4 && threadIdx.x == 0 && (int64_t)blockIdx.x * rpb < n;
+    if (early) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < spr) early_slot[j] = slots[(int64_t)blockIdx.x * rpb * spr + j];
+    }
     const int64_t t0 = (int64_t)blockIdx.x * rpb;
     const int64_t t1 = t0 + rpb < n ? t0 + rpb : n;
     for (int64_t t = t0; t < t1; ++t) {
@@ -140,7 +149,13 @@ __global__ __launch_bounds__(256) void fused_residual_norm_kernel(const float* _
                 stat_tab_fold(tab_lo, tab_hi, slots ? slots + t * spr : nullptr, slots ? spr : 1, lo, hi, stats, slot_base, blockIdx.x);
             } else {
                 const int ns = slots ? spr : 1;
-                for (int j = 0; j < ns; ++j) stat_update(stats, slot_base + (slots ? slots[t * spr + j] : 0), blockIdx.x, lo, hi);
+                if (early) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (j < ns) stat_update(stats, slot_base + early_slot[j], blockIdx.x, lo, hi);
+                } else {
+                    for (int j = 0; j < ns; ++j) stat_update(stats, slot_base + (slots ? slots[t * spr + j] : 0), blockIdx.x, lo, hi);
+                }
             }
         }
         if (use_tab) __syncthreads();

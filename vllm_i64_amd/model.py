@@ -336,7 +336,7 @@ class I64MoEModel:
             e_gu = ops.gemm_desc(B.normed, W["exp_gu"].w_q, W["exp_gu"].w_s, B.e_inter, a_src_row=plan.perm[l], a_src_mod=n,
                                  a_row_slot=plan.sorted_bucket[l], a_slot_base=base + 3, group_offsets=plan.expert_offsets[l],
                                  epilogue=ops.EPI_SWIGLU, out_row_slot=plan.sorted_bucket[l], out_slot_base=base + 4 + nbk, stats=st,
-                                 want_stats=True, m_total=R)
+                                 want_stats=True, m_total=R, a_group_slots=cfg.top_k)  # bucket = expert * top_k + route
             s_gu = ops.gemm_desc(B.normed, W["sh_gu"].w_q, W["sh_gu"].w_s, B.sh_inter, a_slot_base=base + 2, epilogue=ops.EPI_SWIGLU,
                                  out_slot_base=base + 3 + nbk, stats=st, want_stats=True) if shared else None
             ops.gemm_i8_pair(e_gu, s_gu)
@@ -344,7 +344,7 @@ class I64MoEModel:
             # the combine needs no index lookup in front of its row reads
             e_dn = ops.gemm_desc(B.e_inter, W["exp_dn"].w_q, W["exp_dn"].w_s, B.e_out, a_row_slot=plan.sorted_bucket[l],
                                  a_slot_base=base + 4 + nbk, group_offsets=plan.expert_offsets[l], stats=st, m_total=R,
-                                 c_row_map=plan.perm[l])
+                                 c_row_map=plan.perm[l], a_group_slots=cfg.top_k)
             s_dn = ops.gemm_desc(B.sh_inter, W["sh_dn"].w_q, W["sh_dn"].w_s, B.sh_out, a_slot_base=base + 3 + nbk, stats=st) if shared else None
             ops.gemm_i8_pair(e_dn, s_dn)
             return None

@@ -213,7 +213,7 @@ def gemm_i8(a: torch.Tensor, row_scale: torch.Tensor, w: torch.Tensor, w_scale: 
 def gemm_desc(a: torch.Tensor, w: torch.Tensor, w_scale: torch.Tensor, out: torch.Tensor, *, row_scale=None, a_src_row=None,
               a_src_mod: int = 0, a_row_slot=None, a_slot_base: int = 0, group_offsets=None, epilogue: int = EPI_STORE,
               out_row_slot=None, out_slot_base: int = 0, stats=None, want_stats: bool = False, m_total: Optional[int] = None,
-              c_row_map=None):
+              c_row_map=None, a_group_slots: int = 0):
     """Build an i64h_gemm_desc.  a is int8 [M, K] (with row_scale) or fp32 [*, K] (quantized on the fly from the stat slots)."""
     if w.dim() == 2:
         w = w.unsqueeze(0)
@@ -226,7 +226,7 @@ def gemm_desc(a: torch.Tensor, w: torch.Tensor, w_scale: torch.Tensor, out: torc
     d.M_total = m_total if m_total is not None else a.shape[0]
     d.N, d.K, d.C, d.epilogue = N, K, ptr(out), epilogue
     d.out_row_slot, d.out_slot_base, d.stats, d.want_stats = ptr(out_row_slot), out_slot_base, ptr(stats), int(want_stats)
-    d.c_row_map = ptr(c_row_map)
+    d.c_row_map, d.a_group_slots = ptr(c_row_map), a_group_slots
     return d
 
 
