@@ -203,6 +203,9 @@ int i64h_moe_forward(const float* x, const int64_t* token_ids, int64_t n, const 
 /* ---- row kernels -------------------------------------------------------------------------------------------------------
  * nn.Embedding lookup (model.py:415). */
 int i64h_embedding(const int64_t* ids, const float* table, float* out, int64_t n, int32_t H, int64_t V, void* stream);
+/* The embedding rows and, in the same launch, i64h_stats_reset(stats, n_slots): the first two launches of a forward in one. */
+int i64h_embedding_stats_reset(const int64_t* ids, const float* table, float* out, int64_t n, int32_t H, int64_t V, uint32_t* stats,
+                               int64_t n_slots, void* stream);
 /* x * rsqrt(mean(x^2) + eps) * w : I64_rmsnorm_forward (csrc/I64_rmsnorm.cu:41-91), nn.RMSNorm in the model. */
 int i64h_rmsnorm(const float* x, const float* weight, float* out, int64_t rows, int32_t H, float eps, void* stream);
 /* Residual update + MoE combine + RMSNorm + call statistics in one pass (decoder-layer glue, model.py:349-363, and
@@ -236,6 +239,8 @@ int i64h_silu_mul_q7(const float* gate, const float* up, float* out, int64_t tot
  * vllm_i64/core/sampling.py:435-436); positions[i] += 1, ctx_len[i] += 1 (what scheduler.update_after_step does to a
  * decoding sequence, vllm_i64/engine/i64_scheduler.py:505-546). */
 int i64h_argmax_rows(const float* x, int64_t* out, int64_t rows, int32_t D, void* stream);
+/* Greedy step tail in one launch: the argmax of every row, and positions[r] += 1, ctx_len[r] += 1 (both or neither). */
+int i64h_argmax_rows_advance(const float* x, int64_t* out, int64_t rows, int32_t D, int32_t* positions, int32_t* ctx_len, void* stream);
 int i64h_advance(int32_t* positions, int32_t* ctx_len, int64_t n, void* stream);
 
 /* ---- attention -----------------------------------------------------------------------------------------------------------

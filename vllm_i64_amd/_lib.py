@@ -39,6 +39,7 @@ SIGNATURES: Dict[str, str] = {
     "i64h_quantize_fp8_rows": "pllppp",
     "i64h_gemm_fp8": "pppppiliipip",
     "i64h_embedding": "pppli" + "lp",
+    "i64h_embedding_stats_reset": "pppli" + "lplp",
     "i64h_rmsnorm": "ppplifp",
     "i64h_fused_residual_norm": "ppppppiffppfplipiipp",
     "i64h_qk_norm_rope_kv": "pppfppppipppiliiiip",
@@ -47,6 +48,7 @@ SIGNATURES: Dict[str, str] = {
     "i64h_softmax_q7": "pplipp",
     "i64h_silu_mul_q7": "ppplpp",
     "i64h_argmax_rows": "pplip",
+    "i64h_argmax_rows_advance": "pplippp",
     "i64h_advance": "pplp",
     "i64h_paged_attn": "pppipippfppliiiiipip",
     "i64h_paged_attn_workspace_init": "pp",

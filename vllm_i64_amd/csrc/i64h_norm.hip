@@ -7,7 +7,11 @@
 
 // ---- embedding ---------------------------------------------------------------------------------------
 __global__ void embedding_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table, float* __restrict__ out, int H,
-                                 int64_t V) {
+                                 int64_t V, uint32_t* __restrict__ stats, int64_t stat_words) {
+    // optionally also the start-of-forward reset of the stat slots (one launch less per step)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < stat_words; i += (int64_t)gridDim.x * blockDim.x)
+        stats[i] = I64H_ORDERED_ZERO;
+    if (H == 0) return;  // reset only
     const int64_t t = blockIdx.x;
     int64_t id = ids[t];
     id = id < 0 ? 0 : (id >= V ? V - 1 : id);
@@ -302,7 +306,8 @@ __global__ void silu_mul_q7_kernel(const float* __restrict__ gate, const float* 
 }
 
 // ---- greedy sampling glue: first index of the row maximum; position / context advance ------------------------------
-__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int64_t* __restrict__ out, int D) {
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int64_t* __restrict__ out, int D,
+                                                          int32_t* __restrict__ positions, int32_t* __restrict__ ctx_len) {
     __shared__ float sv[4];
     __shared__ int si[4];
     const int64_t r = blockIdx.x;
@@ -335,6 +340,10 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
         for (int w = 1; w < 4; ++w)
             if (sv[w] > bv || (sv[w] == bv && si[w] < bi)) { bv = sv[w]; bi = si[w]; }
         out[r] = bi == 0x7fffffff ? 0 : bi;
+        if (positions) {  // greedy decoding: the row's sequence moves on by one token
+            positions[r] += 1;
+            ctx_len[r] += 1;
+        }
     }
 }
 
@@ -349,12 +358,18 @@ __global__ void advance_kernel(int32_t* __restrict__ positions, int32_t* __restr
 // =====================================================================================================
 extern "C" {
 
-int i64h_argmax_rows(const float* x, int64_t* out, int64_t rows, int32_t D, void* stream) {
+// out[r] = first index of the row maximum; positions / ctx_len (both or neither; int32 [rows]) are incremented by one in the same launch
+int i64h_argmax_rows_advance(const float* x, int64_t* out, int64_t rows, int32_t D, int32_t* positions, int32_t* ctx_len, void* stream) {
     I64H_CHECK_ARG(rows >= 0 && D > 0, "argmax_rows: bad sizes");
+    I64H_CHECK_ARG((positions == nullptr) == (ctx_len == nullptr), "argmax_rows_advance: positions and ctx_len go together");
     if (rows == 0) return 0;
-    hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, out, (int)D);
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, out, (int)D, positions, ctx_len);
     I64H_CHECK_LAUNCH();
     return 0;
+}
+
+int i64h_argmax_rows(const float* x, int64_t* out, int64_t rows, int32_t D, void* stream) {
+    return i64h_argmax_rows_advance(x, out, rows, D, nullptr, nullptr, stream);
 }
 
 int i64h_advance(int32_t* positions, int32_t* ctx_len, int64_t n, void* stream) {
@@ -364,12 +379,23 @@ int i64h_advance(int32_t* positions, int32_t* ctx_len, int64_t n, void* stream) 
     return 0;
 }
 
-int i64h_embedding(const int64_t* ids, const float* table, float* out, int64_t n, int32_t H, int64_t V, void* stream) {
+// the embedding rows and, in the same launch, the reset of n_slots stat slots (stats NULL or n_slots 0: embedding only)
+int i64h_embedding_stats_reset(const int64_t* ids, const float* table, float* out, int64_t n, int32_t H, int64_t V, uint32_t* stats,
+                               int64_t n_slots, void* stream) {
     I64H_CHECK_ARG(n >= 0 && H > 0 && H % 4 == 0, "embedding: H must be a multiple of 4");
-    if (n == 0) return 0;
-    hipLaunchKernelGGL(embedding_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, ids, table, out, (int)H, V);
+    I64H_CHECK_ARG(n_slots >= 0, "embedding_stats_reset: bad slot count");
+    const int64_t words = stats ? n_slots * I64H_SLOT_WORDS : 0;
+    if (n == 0) {
+        if (words == 0) return 0;
+    }
+    const unsigned grid = n > 0 ? (unsigned)n : (unsigned)i64h_cdiv(words, 256);
+    hipLaunchKernelGGL(embedding_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, ids, table, out, n > 0 ? (int)H : 0, V, stats, words);
     I64H_CHECK_LAUNCH();
     return 0;
+}
+
+int i64h_embedding(const int64_t* ids, const float* table, float* out, int64_t n, int32_t H, int64_t V, void* stream) {
+    return i64h_embedding_stats_reset(ids, table, out, n, H, V, nullptr, 0, stream);
 }
 
 int i64h_rmsnorm(const float* x, const float* weight, float* out, int64_t rows, int32_t H, float eps, void* stream) {

@@ -242,8 +242,7 @@ class I64MoEModel:
             ep_plans = self._ep.build_plans(ids_all, self.tables, sizes, self.ep_layers[0].rank, cfg.num_experts)
         elif cfg.is_moe:
             B.plan.run(token_ids, self.tables)
-        ops.stats_reset(st)
-        ops.embedding(token_ids, self.embed, out=B.h)
+        ops.embedding(token_ids, self.embed, out=B.h, reset_stats=st)  # + the reset of the step's stat slots
         # attention splits: enough workgroups to fill the chip when few rows carry long contexts (decode)
         splits = 1
         if max_ctx_hint >= 256 and n <= 256:
@@ -427,8 +426,7 @@ class GreedyDecoder:
     def _step_body(self):
         self.logits = self.m.forward(self.tokens, self.positions, self.slot_ids, self.ctx_len, max_ctx_hint=self.max_ctx_hint,
                                      rows_are_slots=True)
-        ops.argmax_rows(self.logits, out=self.tokens)
-        ops.advance(self.positions, self.ctx_len)
+        ops.argmax_rows(self.logits, out=self.tokens, positions=self.positions, ctx_len=self.ctx_len)  # + position advance
 
     def step(self) -> torch.Tensor:
         """One decode step for the whole batch; returns the logits of the step (valid until the next step)."""

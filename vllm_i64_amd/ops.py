@@ -271,13 +271,15 @@ def gemm_w8a32_swiglu(x, gate_w, gate_s, up_w, up_s) -> torch.Tensor:
 
 
 # ---- row kernels ------------------------------------------------------------------------------------------------
-def embedding(ids: torch.Tensor, table: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def embedding(ids: torch.Tensor, table: torch.Tensor, out: Optional[torch.Tensor] = None, reset_stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """reset_stats: stat slots to reset in the same launch (the start of a forward)."""
     _chk(ids, torch.int64, "ids"), _chk(table, torch.float32, "table")
     V, H = table.shape
     n = ids.numel()
     if out is None:
         out = torch.empty(n, H, dtype=torch.float32, device=table.device)
-    call("i64h_embedding", ptr(ids), ptr(table), ptr(out), n, H, V, _stream())
+    call("i64h_embedding_stats_reset", ptr(ids), ptr(table), ptr(out), n, H, V, ptr(reset_stats),
+         reset_stats.numel() // slot_words() if reset_stats is not None else 0, _stream())
     return out
 
 
@@ -382,12 +384,17 @@ def paged_attn(q, k_cache, v_cache, block_table, ctx_len, slot_ids=None, softmax
 
 
 # ---- greedy step glue ---------------------------------------------------------------------------------------------
-def argmax_rows(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def argmax_rows(x: torch.Tensor, out: Optional[torch.Tensor] = None, positions: Optional[torch.Tensor] = None,
+                ctx_len: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """positions / ctx_len (int32 [rows]): incremented by one in the same launch (the tail of a greedy decode step)."""
     _chk(x, torch.float32, "x")
     rows, D = x.shape
     if out is None:
         out = torch.empty(rows, dtype=torch.int64, device=x.device)
-    call("i64h_argmax_rows", ptr(x), ptr(out), rows, D, _stream())
+    if positions is not None:
+        _chk(positions, torch.int32, "positions"), _chk(ctx_len, torch.int32, "ctx_len")
+        assert positions.numel() == rows and ctx_len.numel() == rows
+    call("i64h_argmax_rows_advance", ptr(x), ptr(out), rows, D, ptr(positions), ptr(ctx_len), _stream())
     return out
 
 
