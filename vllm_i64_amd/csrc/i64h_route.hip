@@ -149,6 +149,90 @@ __global__ __launch_bounds__(PLAN_THREADS) void bucket_place_kernel(
     }
 }
 
+// ---- all three phases in one launch when one wave covers the rows (decode-sized steps: R <= ROWS_PER_WAVE) -----------------
+// One workgroup per layer; wave 0 runs phases A and C exactly as the kernels above do for their single wave, the scan of phase B
+// degenerates to the bucket offsets.  Same keys, offsets, permutation: the results are identical to the three-launch path.
+template <bool TABLE>
+__global__ __launch_bounds__(MAX_BUCKETS) void bucket_plan_small_kernel(
+    const int64_t* __restrict__ ids, const int64_t* __restrict__ tables, int64_t table_layer_stride,
+    const int32_t* __restrict__ keys_in, int32_t* __restrict__ keys, int64_t* __restrict__ routes, int32_t* __restrict__ tok_slots,
+    int32_t* __restrict__ wave_counts, int32_t* __restrict__ offsets, int32_t* __restrict__ group_offsets, int32_t* __restrict__ perm,
+    int32_t* __restrict__ inv, int32_t* __restrict__ sorted_bucket, int n, int top_k, int64_t V, int nb) {
+    __shared__ int hist[MAX_BUCKETS], cursor[MAX_BUCKETS];
+    __shared__ int skey[ROWS_PER_WAVE];
+    const int l = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int R = n * top_k;
+    if (tid < nb) hist[tid] = 0;
+    __syncthreads();
+    if (tid < 64) {
+        for (int s = lane; s < R; s += 64) {
+            int key;
+            if (TABLE) {
+                const int k = s / n, t = s - k * n;
+                int64_t id = ids[t];
+                id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+                const int64_t e = tables[(int64_t)l * table_layer_stride + (int64_t)k * V + id];
+                if (routes) routes[(int64_t)l * R + s] = e;
+                key = (int)e * top_k + k;
+                key = key < 0 ? 0 : (key >= nb ? nb - 1 : key);
+                if (tok_slots) {
+                    int32_t* ts = tok_slots + ((int64_t)l * n + t) * (1 + top_k);
+                    ts[1 + k] = 1 + key;
+                    if (k == 0) ts[0] = 0;
+                }
+            } else {
+                key = keys_in[s];
+            }
+            key = key < 0 ? 0 : (key >= nb ? nb - 1 : key);
+            keys[(int64_t)l * R + s] = key;
+            skey[s] = key;
+            atomicAdd(&hist[key], 1);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        int32_t* o = offsets + (int64_t)l * (nb + 1);
+        for (int i = 0; i < nb; ++i) {
+            o[i] = run;
+            cursor[i] = run;
+            run += hist[i];
+        }
+        o[nb] = run;
+        if (group_offsets) {
+            int32_t* go = group_offsets + (int64_t)l * (nb / top_k + 1);
+            for (int i = 0; i <= nb / top_k; ++i) go[i] = o[i * top_k];
+        }
+    }
+    if (tid < nb) wave_counts[(int64_t)l * nb + tid] = 0;  // what phase B leaves behind for a single wave
+    __syncthreads();
+    if (tid >= 64) return;  // wave-uniform
+    const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int base = 0; base < R; base += 64) {
+        const int s = base + lane;
+        const bool valid = s < R;
+        const int key = valid ? skey[s] : -1;
+        uint64_t todo = __ballot(valid);
+        int pos = 0;
+        while (todo) {
+            const int leader = __ffsll((unsigned long long)todo) - 1;
+            const int b = __shfl(key, leader);
+            const uint64_t m = __ballot(valid && key == b);
+            const int start = cursor[b];
+            if (key == b) pos = start + __popcll(m & lt);
+            __builtin_amdgcn_wave_barrier();
+            if (lane == leader) cursor[b] = start + __popcll(m);
+            __builtin_amdgcn_wave_barrier();
+            todo &= ~m;
+        }
+        if (valid) {
+            perm[(int64_t)l * R + pos] = (int32_t)s;
+            inv[(int64_t)l * R + s] = pos;
+            if (sorted_bucket) sorted_bucket[(int64_t)l * R + pos] = key;
+        }
+    }
+}
+
 // ---- row gather: dst[i] = src[idx[i]] (rows of row_bytes bytes) ------------------------------------------
 __global__ void gather_rows_kernel(const char* __restrict__ src, const int32_t* __restrict__ idx, char* __restrict__ dst,
                                    int64_t n_rows, int64_t row_bytes, int vec16) {
@@ -216,6 +300,16 @@ static int bucketize_common(bool table, const int64_t* ids, const int64_t* table
     I64H_CHECK_ARG(R < (1ll << 31), "bucketize: too many rows");
     int num_waves = (int)((R + ROWS_PER_WAVE - 1) / ROWS_PER_WAVE);
     if (num_waves < 1) num_waves = 1;
+    if (R > 0 && R <= ROWS_PER_WAVE) {  // one wave covers the rows: the three phases in one launch
+        if (table)
+            hipLaunchKernelGGL(bucket_plan_small_kernel<true>, dim3(L), dim3(MAX_BUCKETS), 0, st, ids, tables, layer_stride, keys_in, keys,
+                               routes, tok_slots, workspace, offsets, group_offsets, perm, inv, sorted_bucket, n, top_k, V, nb);
+        else
+            hipLaunchKernelGGL(bucket_plan_small_kernel<false>, dim3(L), dim3(MAX_BUCKETS), 0, st, ids, tables, layer_stride, keys_in, keys,
+                               routes, tok_slots, workspace, offsets, group_offsets, perm, inv, sorted_bucket, n, top_k, V, nb);
+        I64H_CHECK_LAUNCH();
+        return 0;
+    }
     const int wpb = PLAN_THREADS / 64;
     dim3 grid(i64h_cdiv(num_waves, wpb), L);
     if (table)
