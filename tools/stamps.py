@@ -11,6 +11,7 @@ dev = torch.device("cuda:0")
 cfg = C.trhash500m_synth()
 B, P = 64, 2048
 model = I64MoEModel(cfg, synth.make_weights(cfg, seed=0), device=dev, kv_dtype=torch.bfloat16, max_seqs=B)
+model.fuse_qkr = False  # four gemm_i8_pair launches per layer, the order the marks below assume
 dec = GreedyDecoder(model, B, use_graph=False)
 ids = synth.make_token_ids(cfg, B, seed=7)
 dec.set_state(ids.to(dev), [P] * B, reserve_extra=16)
