@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--synthetic-kv", action="store_true", help="fill the KV cache with random values instead of a real prefill")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=32)
+    ap.add_argument("--skinny-waves", type=int, default=0, help="tuning: waves per workgroup of the decode-sized GEMM (0 = library default)")
     ap.add_argument("--cpu-ctx", type=int, default=128)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--zipf", type=float, default=0.0, help="prompt ids from a Zipf(s) distribution instead of uniform (bucket skew)")
@@ -112,6 +113,8 @@ def main():
     if lib.i64h_device_check() != 0:
         raise SystemExit(lib.i64h_last_error().decode())
 
+    if args.skinny_waves:
+        ops.call("i64h_set_skinny_waves", args.skinny_waves)
     cfg = get_config(args.config)
     kv_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "fp16": torch.float16, "fp8": torch.float8_e4m3fn,
                 "fp8_e5m2": torch.float8_e5m2}[args.kv_dtype]
