@@ -242,6 +242,20 @@ __device__ __forceinline__ int quantize_u7_signed(float x, const QParams& q) {
     return max(-128, min(127, v));
 }
 
+// Four elements at once, packed as the four bytes of a word; the same values as quantize_u7_signed for every input that is not a
+// NaN.  t = rne(fma(x, inv, zp)); the conversion saturates to [0, 255]; capping t at 127 + zp first keeps
+// t - zp <= 127; the per-byte subtraction of zp borrows nothing across bytes (high bit forced on, restored afterwards).
+__device__ __forceinline__ uint32_t quantize4_u7_signed(float4 x, const QParams& q) {
+    const float zpf = (float)q.zp, cap = 127.0f + zpf;
+    uint32_t a = 0;
+    a = __builtin_amdgcn_cvt_pk_u8_f32(fminf(rintf(__builtin_fmaf(x.x, q.inv_scale, zpf)), cap), 0, a);
+    a = __builtin_amdgcn_cvt_pk_u8_f32(fminf(rintf(__builtin_fmaf(x.y, q.inv_scale, zpf)), cap), 1, a);
+    a = __builtin_amdgcn_cvt_pk_u8_f32(fminf(rintf(__builtin_fmaf(x.z, q.inv_scale, zpf)), cap), 2, a);
+    a = __builtin_amdgcn_cvt_pk_u8_f32(fminf(rintf(__builtin_fmaf(x.w, q.inv_scale, zpf)), cap), 3, a);
+    const uint32_t b = (uint32_t)q.zp * 0x01010101u;  // zp <= 127: no high bits
+    return ((a | 0x80808080u) - b) ^ (~a & 0x80808080u);
+}
+
 __device__ __forceinline__ QParams slot_qparams(const uint32_t* stats, int slot) {
     float lo, hi;
     stat_read(stats, slot, lo, hi);

@@ -863,11 +863,7 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
             q.inv_scale = q_inv[rr[u]]; q.zp = q_zp[rr[u]]; q.scale = 0.0f;
             uint32_t w[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float4 v = f[u][e];
-                w[e] = (uint32_t)(quantize_u7_signed(v.x, q) & 255) | ((uint32_t)(quantize_u7_signed(v.y, q) & 255) << 8) |
-                       ((uint32_t)(quantize_u7_signed(v.z, q) & 255) << 16) | ((uint32_t)(quantize_u7_signed(v.w, q) & 255) << 24);
-            }
+            for (int e = 0; e < 4; ++e) w[e] = quantize4_u7_signed(f[u][e], q);
             *(uint4*)(smem + rr[u] * LDA + kc[u] * 16) = make_uint4(w[0], w[1], w[2], w[3]);
         }
         if (c0 + NT * 4 < total_chunks) a_issue(c0 + NT * 4);
