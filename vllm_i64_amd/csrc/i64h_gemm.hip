@@ -230,11 +230,7 @@ __device__ __forceinline__ void gemm_i8_body(const GemmI8Args& p, const int bid,
                 q.inv_scale = q_inv[r]; q.zp = q_zp[r]; q.scale = 0.0f;
                 uint32_t w[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float4 f = fa[i][e];
-                    w[e] = (uint32_t)(quantize_u7_signed(f.x, q) & 255) | ((uint32_t)(quantize_u7_signed(f.y, q) & 255) << 8) |
-                           ((uint32_t)(quantize_u7_signed(f.z, q) & 255) << 16) | ((uint32_t)(quantize_u7_signed(f.w, q) & 255) << 24);
-                }
+                for (int e = 0; e < 4; ++e) w[e] = quantize4_u7_signed(fa[i][e], q);
                 // rows outside the tile and the K tail are staged as 0.0f, and quantize(0) - zp is exactly 0
                 v = make_uint4(w[0], w[1], w[2], w[3]);
             } else {

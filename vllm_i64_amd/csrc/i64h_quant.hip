@@ -85,10 +85,7 @@ __global__ __launch_bounds__(256) void quantize_dynamic_kernel(const float* __re
     if ((K & 3) == 0) {
         for (int i = threadIdx.x * 4; i < K; i += 1024) {
             float4 v = *(const float4*)(xr + i);
-            int q0 = quantize_u7_signed(v.x, q), q1 = quantize_u7_signed(v.y, q);
-            int q2 = quantize_u7_signed(v.z, q), q3 = quantize_u7_signed(v.w, q);
-            uint32_t pk = (uint32_t)(q0 & 255) | ((uint32_t)(q1 & 255) << 8) | ((uint32_t)(q2 & 255) << 16) | ((uint32_t)(q3 & 255) << 24);
-            *(uint32_t*)(ar + i) = pk;
+            *(uint32_t*)(ar + i) = quantize4_u7_signed(v, q);
         }
     } else {
         for (int i = threadIdx.x; i < K; i += 256) ar[i] = (int8_t)quantize_u7_signed(xr[i], q);
