@@ -759,6 +759,9 @@ __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* _
     const int ctx = ctx_len[row];
     const int slot = slot_ids ? slot_ids[row] : row;
     const int32_t* bt = block_table + (int64_t)slot * max_blocks_per_seq;
+    // the block size is a power of two (host-checked): the per-token block index and offset are a shift and a mask
+    const int bsh = __builtin_ctz(block);
+    const float sl2 = scale * LOG2E;  // scores are kept in log2 units: exp2 is one instruction
     const int nblk = (ctx + block - 1) / block;
     const int bps = (nblk + splits - 1) / splits;
     const int t_begin = sp * bps * block;
@@ -783,7 +786,7 @@ __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* _
 #pragma unroll
         for (int u = 0; u < PD_U; ++u) {
             const int tc = max(0, min(t0 + u * TPS + tl, t_end - 1));
-            pb[u] = bt[tc / block];
+            pb[u] = bt[tc >> bsh];
         }
     };
     // the K/V rows of iteration i+1 are requested before the math of iteration i (and the block-table entries one
@@ -798,7 +801,7 @@ __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* _
             const int tc = max(0, min(t, t_end - 1));
             const int pb = pbn[u];
             nlive[u] = t < t_end && pb >= 0;
-            const int64_t off = ((int64_t)max(pb, 0) * block + (tc % block)) * (KVH * HD) + (lane % LPT) * 8;
+            const int64_t off = ((int64_t)max(pb, 0) * block + (tc & (block - 1))) * (KVH * HD) + (lane % LPT) * 8;
             nk[u].load(k_cache + off);
             nv[u].load(v_cache + off);
         }
@@ -813,11 +816,12 @@ __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* _
 #pragma unroll
         for (int u = 0; u < PD_U; ++u) { rk[u] = nk[u]; rv[u] = nv[u]; live[u] = nlive[u]; }
         if (t0 + 4 * TPI < t_end) issue(t0 + 4 * TPI);
-        float s[PD_U][GS];
+        float s[PD_U][GS], msafe[GS];
 #pragma unroll
         for (int u = 0; u < PD_U; ++u) {
             float kf[8];
             rk[u].get(kf);
+            const float dead = live[u] ? 0.0f : -INFINITY;  // added to the score inside one fma
 #pragma unroll
             for (int h = 0; h < GS; ++h) {
                 v2f a2 = (v2f){0.0f, 0.0f};
@@ -825,7 +829,7 @@ __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* _
                 for (int d = 0; d < 4; ++d) a2 = __builtin_elementwise_fma(qr[h][d], (v2f){kf[2 * d], kf[2 * d + 1]}, a2);
                 float a = a2.x + a2.y;
                 a = group_sum(a, CPH);
-                s[u][h] = live[u] ? (a * scale) * LOG2E : -INFINITY;  // scores kept in log2 units: exp2 is one instruction
+                s[u][h] = __builtin_fmaf(a, sl2, dead);
             }
         }
 #pragma unroll
@@ -839,8 +843,9 @@ __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* _
                 for (int o = LPT; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
             }
             const float mn = fmaxf(m[h], mx);           // identical in the lanes of one kv head
-            const float alpha = (mn == -INFINITY) ? 1.0f : exp2f(m[h] - mn);
+            const float alpha = (mn == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m[h] - mn);
             m[h] = mn;
+            msafe[h] = (mn == -INFINITY) ? 0.0f : mn;  // nothing live yet: keeps -inf - m from being a NaN
             l[h] *= alpha;
 #pragma unroll
             for (int d = 0; d < 4; ++d) acc[h][d] *= alpha;
@@ -851,7 +856,8 @@ __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* _
             rv[u].get(vf);
 #pragma unroll
             for (int h = 0; h < GS; ++h) {
-                const float p = live[u] ? exp2f(s[u][h] - m[h]) : 0.0f;
+                // bare v_exp_f32: results below 2^-126 flush to 0; a dead token's score is -inf and its p therefore 0
+                const float p = __builtin_amdgcn_exp2f(s[u][h] - msafe[h]);
                 l[h] += p;
 #pragma unroll
                 for (int d = 0; d < 4; ++d) acc[h][d] = __builtin_elementwise_fma((v2f){p, p}, (v2f){vf[2 * d], vf[2 * d + 1]}, acc[h][d]);
@@ -1043,12 +1049,13 @@ int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, in
     }
     // decode form (few rows, long contexts): all kv heads per workgroup, fully coalesced token rows
     bool done = false;
+    const bool bp2 = block_size > 0 && (block_size & (block_size - 1)) == 0;  // other block sizes take the per-head kernel
 #define AH_T(HD_, KVH_, GS_, T)                                                                                                       \
     hipLaunchKernelGGL((paged_attn_allheads_kernel<HD_, KVH_, GS_, T>), grid, dim3(256), 0, st, q, (const T*)k_cache, (const T*)v_cache, \
                        block_table, max_blocks_per_seq, slot_ids, ctx_len, softmax_scale, out, part_o, part_ml, block_size, splits,      \
                        arrivals, stats, stat_slot, g_attn_stamps)
 #define AH(HD_, KVH_, GS_)                                                                       \
-    if (!done && splits > 1 && head_dim == HD_ && num_kv_heads == KVH_ && gs == GS_) {            \
+    if (!done && splits > 1 && bp2 && head_dim == HD_ && num_kv_heads == KVH_ && gs == GS_) {     \
         dim3 grid((unsigned)rows, (unsigned)splits);                                              \
         if (kv_dtype == 0) AH_T(HD_, KVH_, GS_, float);                                           \
         else if (kv_dtype == 1) AH_T(HD_, KVH_, GS_, __half);                                     \

@@ -10,6 +10,7 @@ torch is used for device memory, streams and graphs only; every arithmetic step 
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -204,6 +205,7 @@ class I64MoEModel:
 
     FUSE_MAX_ROWS = 256  # up to this many operand rows the quantizer runs inside the GEMM (one launch per Linear call)
     fuse_qkr = True   # decode-sized steps: QK norm / RoPE / cache write inside the qkv GEMM
+    attn_target_wgs = int(os.environ.get("I64H_ATTN_WGS", "512"))  # decode attention: rows x splits aimed at (tuning)
 
     def _linear(self, x, pl: PackedLinear, slot: int, xa, xs, out, epilogue=ops.EPI_STORE, stats_slot: Optional[int] = None):
         """One dense dynamic-int8 Linear call: quantize with the call's statistics, int8 GEMM, fp32 rescale."""
@@ -246,7 +248,7 @@ class I64MoEModel:
         # attention splits: enough workgroups to fill the chip when few rows carry long contexts (decode)
         splits = 1
         if max_ctx_hint >= 256 and n <= 256:
-            splits = max(1, min(32, 512 // n, max_ctx_hint // 64))
+            splits = max(1, min(32, self.attn_target_wgs // n, max_ctx_hint // 64))
         if splits > 1 and (B.attn_ws is None or B.attn_splits != splits):
             B.attn_ws = ops.attn_workspace(n, cfg.num_heads, cfg.head_dim, splits, self.device)
             B.attn_splits = splits
