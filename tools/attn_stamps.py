@@ -5,7 +5,8 @@ import torch
 from vllm_i64_amd import ops
 
 dev = torch.device("cuda:0")
-B, ctx, nh, kvh, hd, splits = 64, int(sys.argv[1]) if len(sys.argv) > 1 else 2048, 16, 4, 64, 8
+B, ctx, nh, kvh, hd = 64, int(sys.argv[1]) if len(sys.argv) > 1 else 2048, 16, 4, 64
+splits = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 nblk = B * (ctx // 16 + 2)
 kc = torch.randn(nblk, 16, kvh, hd, device=dev).to(torch.bfloat16)
 vc = torch.randn(nblk, 16, kvh, hd, device=dev).to(torch.bfloat16)

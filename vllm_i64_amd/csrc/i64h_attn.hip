@@ -648,10 +648,10 @@ __global__ __launch_bounds__(GS * 64) void paged_attn_prefill_bf16_kernel(const 
 template <bool COH>
 __device__ __forceinline__ void attn_merge_row(const float* part_o, const float* part_ml, float* __restrict__ out,
                                                int64_t row, int nh, int HD, int splits, uint32_t* __restrict__ stats, int stat_slot, int base2) {
-    __shared__ float rlo[4], rhi[4];
+    __shared__ float rlo[8], rhi[8];  // up to 8 waves
     float lo = 0.0f, hi = 0.0f;
     const int per_head = HD / 4;
-    for (int i = threadIdx.x; i < nh * per_head; i += 256) {
+    for (int i = threadIdx.x; i < nh * per_head; i += blockDim.x) {
         const int64_t head = row * nh + i / per_head;
         const int d = (i % per_head) * 4;
         const float* ml = part_ml + head * splits * 2;
@@ -715,8 +715,7 @@ __device__ __forceinline__ void attn_merge_row(const float* part_o, const float*
     if ((threadIdx.x & 63) == 0) { rlo[threadIdx.x >> 6] = lo; rhi[threadIdx.x >> 6] = hi; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        lo = fminf(fminf(rlo[0], rlo[1]), fminf(rlo[2], rlo[3]));
-        hi = fmaxf(fmaxf(rhi[0], rhi[1]), fmaxf(rhi[2], rhi[3]));
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { lo = fminf(lo, rlo[w]); hi = fmaxf(hi, rhi[w]); }
         stat_update(stats, stat_slot, (int)row, lo, hi);
     }
 }
@@ -730,14 +729,19 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict
 // ---- decode form: one workgroup = (query row, split), ALL kv heads --------------------------------------------------
 // In the cache a token's K (or V) for all kv heads is one contiguous KVH*HD-element row, so a wave-instruction that
 // covers whole token rows is fully coalesced (512-B segments at 4 x 64 bf16) instead of one 128-B piece per token.
-// Lane = (token in step, kv head, 8-dim chunk); a wave step covers TPS = 64 / (KVH*HD/8) tokens; PD_U steps are loaded
-// together and share one online-softmax update.  Waves of a workgroup take interleaved token groups.
+// Lane = (token in step, kv head, chunk lane); a lane owns CH 8-dim chunks, a wave step covers TPS = 64 / (KVH*HD/(8*CH))
+// tokens; PD_U steps are loaded together and share one online-softmax update.  Waves of a workgroup take interleaved
+// token groups.  Measured at batch 64, 2k contexts, bf16 cache: CH = 2 needs 385 VALU instructions per 8 KB of cache
+// against 497 at CH = 1 (same time: the loop is no longer issue-bound); 4 waves per workgroup at one workgroup per CU
+// beat 8 waves (34.8 against 33.8 us) and twice the loads in flight per wave (39.2 us, 322 registers).
 // The splits of a row are merged by whichever of the row's workgroups finishes last: partial results are written with
 // device-coherent stores and drained (vmcnt) before the workgroup's arrival is counted, and read back with
 // device-coherent loads; the counter is left at zero for the next launch.
-#define PD_U 4
-template <int HD, int KVH, int GS, typename KV>
-__global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* __restrict__ q, const KV* __restrict__ k_cache,
+#ifndef I64H_AH_PDU
+#define I64H_AH_PDU 4  // 8-dim chunks per lane requested together (PD_U = this / CH)
+#endif
+template <int HD, int KVH, int GS, int CH, int NW, typename KV>
+__global__ __launch_bounds__(NW * 64) void paged_attn_allheads_kernel(const float* __restrict__ q, const KV* __restrict__ k_cache,
                                                                   const KV* __restrict__ v_cache, const int32_t* __restrict__ block_table,
                                                                   int max_blocks_per_seq, const int32_t* __restrict__ slot_ids,
                                                                   const int32_t* __restrict__ ctx_len, float scale, float* __restrict__ out,
@@ -746,13 +750,17 @@ __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* _
                                                                   int stat_slot, unsigned long long* __restrict__ stamps) {
 #define PA_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     PA_STAMP(0);
-    constexpr int CPH = HD / 8;         // chunk lanes per head
+    // A lane owns CH chunks of 8 dims of one kv head of one token: chunk j covers dims [(j * CPH + ch) * 8, +8), so one load
+    // instruction reads CPH * 8 consecutive elements per head.  More dims per lane = fewer lanes per score: the cross-lane sums,
+    // the exponentials and the softmax bookkeeping are per (lane, head, token) and shrink with 1 / CH per cached byte.
+    constexpr int CPH = HD / (8 * CH);  // chunk lanes per head
     constexpr int LPT = KVH * CPH;      // lanes per token
     constexpr int TPS = 64 / LPT;       // tokens per wave step
     constexpr int NH = KVH * GS;
+    constexpr int PD_U = I64H_AH_PDU / CH;  // steps loaded together
     constexpr float LOG2E = 1.4426950408889634f;
-    static_assert(64 % LPT == 0, "token row must fit a wave");
-    __shared__ float s_m[4][NH], s_l[4][NH], s_o[4][NH][HD];
+    static_assert(64 % LPT == 0 && CPH >= 1 && (CH == 1 || CH == 2), "token row must fit a wave");
+    __shared__ float s_m[NW][NH], s_l[NW][NH], s_o[NW][NH][HD];
     const int row = blockIdx.x, sp = blockIdx.y;
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ch = lane % CPH, kh = (lane / CPH) % KVH, tl = lane / LPT;
@@ -766,20 +774,25 @@ __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* _
     const int bps = (nblk + splits - 1) / splits;
     const int t_begin = sp * bps * block;
     const int t_end = min(ctx, (sp + 1) * bps * block);
+    const int lane_off = kh * HD + ch * 8;  // element offset of the lane's chunk 0 inside a token row
 
-    // dims are handled in pairs so that the dot products and the value accumulation compile to packed fp32 FMAs
-    v2f qr[GS][4], acc[GS][4];
+    // dims are handled in pairs so that the dot products and the value accumulation compile to packed fp32 FMAs.
+    // Every token lane runs an online softmax of its own (m, l, acc); the token lanes are merged once, after the loop.
+    v2f qr[GS][CH][4], acc[GS][CH][4];
     float m[GS], l[GS];
 #pragma unroll
     for (int h = 0; h < GS; ++h) {
-        const float* qp = q + ((int64_t)row * NH + kh * GS + h) * HD + ch * 8;
-        float4 a = *(const float4*)qp, b = *(const float4*)(qp + 4);
-        qr[h][0] = (v2f){a.x, a.y}; qr[h][1] = (v2f){a.z, a.w};
-        qr[h][2] = (v2f){b.x, b.y}; qr[h][3] = (v2f){b.z, b.w};
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const float* qp = q + ((int64_t)row * NH + kh * GS + h) * HD + (j * CPH + ch) * 8;
+            float4 a = *(const float4*)qp, b = *(const float4*)(qp + 4);
+            qr[h][j][0] = (v2f){a.x, a.y}; qr[h][j][1] = (v2f){a.z, a.w};
+            qr[h][j][2] = (v2f){b.x, b.y}; qr[h][j][3] = (v2f){b.z, b.w};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) acc[h][j][d] = (v2f){0.0f, 0.0f};
+        }
         m[h] = -INFINITY;
         l[h] = 0.0f;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) acc[h][d] = (v2f){0.0f, 0.0f};
     }
     constexpr int TPI = PD_U * TPS;  // tokens per wave iteration
     auto fetch_blocks = [&](int t0, int (&pb)[PD_U]) {
@@ -792,7 +805,7 @@ __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* _
     // the K/V rows of iteration i+1 are requested before the math of iteration i (and the block-table entries one
     // iteration before that), so the loop never waits for a whole memory round trip
     int pbn[PD_U];
-    Raw8<KV> nk[PD_U], nv[PD_U];
+    Raw8<KV> nk[PD_U][CH], nv[PD_U][CH];
     bool nlive[PD_U];
     auto issue = [&](int t0) {
 #pragma unroll
@@ -801,100 +814,122 @@ __global__ __launch_bounds__(256) void paged_attn_allheads_kernel(const float* _
             const int tc = max(0, min(t, t_end - 1));
             const int pb = pbn[u];
             nlive[u] = t < t_end && pb >= 0;
-            const int64_t off = ((int64_t)max(pb, 0) * block + (tc & (block - 1))) * (KVH * HD) + (lane % LPT) * 8;
-            nk[u].load(k_cache + off);
-            nv[u].load(v_cache + off);
+            const int64_t off = ((int64_t)max(pb, 0) * block + (tc & (block - 1))) * (KVH * HD) + lane_off;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                nk[u][j].load(k_cache + off + j * CPH * 8);
+                nv[u][j].load(v_cache + off + j * CPH * 8);
+            }
         }
-        fetch_blocks(t0 + 4 * TPI, pbn);
+        fetch_blocks(t0 + NW * TPI, pbn);
     };
     fetch_blocks(t_begin + wid * TPI, pbn);
     issue(t_begin + wid * TPI);
     PA_STAMP(1);
-    for (int t0 = t_begin + wid * TPI; t0 < t_end; t0 += 4 * TPI) {
-        Raw8<KV> rk[PD_U], rv[PD_U];
+    for (int t0 = t_begin + wid * TPI; t0 < t_end; t0 += NW * TPI) {
+        Raw8<KV> rk[PD_U][CH], rv[PD_U][CH];
         bool live[PD_U];
 #pragma unroll
-        for (int u = 0; u < PD_U; ++u) { rk[u] = nk[u]; rv[u] = nv[u]; live[u] = nlive[u]; }
-        if (t0 + 4 * TPI < t_end) issue(t0 + 4 * TPI);
+        for (int u = 0; u < PD_U; ++u) {
+#pragma unroll
+            for (int j = 0; j < CH; ++j) { rk[u][j] = nk[u][j]; rv[u][j] = nv[u][j]; }
+            live[u] = nlive[u];
+        }
+        if (t0 + NW * TPI < t_end) issue(t0 + NW * TPI);
         float s[PD_U][GS], msafe[GS];
 #pragma unroll
         for (int u = 0; u < PD_U; ++u) {
-            float kf[8];
-            rk[u].get(kf);
+            float kf[CH][8];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) rk[u][j].get(kf[j]);
             const float dead = live[u] ? 0.0f : -INFINITY;  // added to the score inside one fma
 #pragma unroll
             for (int h = 0; h < GS; ++h) {
                 v2f a2 = (v2f){0.0f, 0.0f};
 #pragma unroll
-                for (int d = 0; d < 4; ++d) a2 = __builtin_elementwise_fma(qr[h][d], (v2f){kf[2 * d], kf[2 * d + 1]}, a2);
+                for (int j = 0; j < CH; ++j)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) a2 = __builtin_elementwise_fma(qr[h][j][d], (v2f){kf[j][2 * d], kf[j][2 * d + 1]}, a2);
                 float a = a2.x + a2.y;
                 a = group_sum(a, CPH);
                 s[u][h] = __builtin_fmaf(a, sl2, dead);
             }
         }
 #pragma unroll
-        for (int h = 0; h < GS; ++h) {  // one online-softmax update per head for the PD_U * TPS tokens of the iteration
+        for (int h = 0; h < GS; ++h) {  // one online-softmax update per head for the PD_U tokens of this lane
             float mx = s[0][h];
 #pragma unroll
             for (int u = 1; u < PD_U; ++u) mx = fmaxf(mx, s[u][h]);
-            if (LPT == 32) mx = half_swap_max(mx);
-            else {
-#pragma unroll
-                for (int o = LPT; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-            }
-            const float mn = fmaxf(m[h], mx);           // identical in the lanes of one kv head
+            const float mn = fmaxf(m[h], mx);           // identical in the chunk lanes of one (token lane, kv head)
             const float alpha = (mn == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m[h] - mn);
             m[h] = mn;
             msafe[h] = (mn == -INFINITY) ? 0.0f : mn;  // nothing live yet: keeps -inf - m from being a NaN
             l[h] *= alpha;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) acc[h][d] *= alpha;
+            for (int j = 0; j < CH; ++j)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) acc[h][j][d] *= alpha;
         }
 #pragma unroll
         for (int u = 0; u < PD_U; ++u) {
-            float vf[8];
-            rv[u].get(vf);
+            float vf[CH][8];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) rv[u][j].get(vf[j]);
 #pragma unroll
             for (int h = 0; h < GS; ++h) {
                 // bare v_exp_f32: results below 2^-126 flush to 0; a dead token's score is -inf and its p therefore 0
                 const float p = __builtin_amdgcn_exp2f(s[u][h] - msafe[h]);
                 l[h] += p;
 #pragma unroll
-                for (int d = 0; d < 4; ++d) acc[h][d] = __builtin_elementwise_fma((v2f){p, p}, (v2f){vf[2 * d], vf[2 * d + 1]}, acc[h][d]);
+                for (int j = 0; j < CH; ++j)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+                        acc[h][j][d] = __builtin_elementwise_fma((v2f){p, p}, (v2f){vf[j][2 * d], vf[j][2 * d + 1]}, acc[h][j][d]);
             }
         }
     }
     PA_STAMP(2);
-    // reduce over the token lanes (same kv head and chunk), then over waves through LDS
+    // merge the token lanes (same kv head and chunk, each with its own running maximum), then the waves through LDS
 #pragma unroll
     for (int h = 0; h < GS; ++h) {
 #pragma unroll
         for (int o = LPT; o < 64; o <<= 1) {
+            const float mm = fmaxf(m[h], __shfl_xor(m[h], o));
+            const float f = (m[h] == -INFINITY) ? 0.0f : __builtin_amdgcn_exp2f(m[h] - mm);
+            m[h] = mm;
+            l[h] *= f;
             l[h] += __shfl_xor(l[h], o);
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                acc[h][d].x += __shfl_xor(acc[h][d].x, o);
-                acc[h][d].y += __shfl_xor(acc[h][d].y, o);
-            }
+            for (int j = 0; j < CH; ++j)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    acc[h][j][d] *= f;
+                    acc[h][j][d].x += __shfl_xor(acc[h][j][d].x, o);
+                    acc[h][j][d].y += __shfl_xor(acc[h][j][d].y, o);
+                }
         }
         if (tl == 0) {
             const int head = kh * GS + h;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                s_o[wid][head][ch * 8 + 2 * d] = acc[h][d].x;
-                s_o[wid][head][ch * 8 + 2 * d + 1] = acc[h][d].y;
-            }
+            for (int j = 0; j < CH; ++j)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    s_o[wid][head][(j * CPH + ch) * 8 + 2 * d] = acc[h][j][d].x;
+                    s_o[wid][head][(j * CPH + ch) * 8 + 2 * d + 1] = acc[h][j][d].y;
+                }
             if (ch == 0) { s_m[wid][head] = m[h]; s_l[wid][head] = l[h]; }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < NH * HD / 2; i += 256) {  // two adjacent dims per thread: 8-byte stores
+    for (int i = threadIdx.x; i < NH * HD / 2; i += NW * 64) {  // two adjacent dims per thread: 8-byte stores
         const int h = i / (HD / 2), d = (i % (HD / 2)) * 2;
-        float mm = fmaxf(fmaxf(s_m[0][h], s_m[1][h]), fmaxf(s_m[2][h], s_m[3][h]));
+        float mm = s_m[0][h];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) mm = fmaxf(mm, s_m[w][h]);
         float lt = 0.0f, o0 = 0.0f, o1 = 0.0f;
         if (mm != -INFINITY) {
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
+            for (int w = 0; w < NW; ++w) {
                 const float f = (s_m[w][h] == -INFINITY) ? 0.0f : exp2f(s_m[w][h] - mm);
                 lt = __builtin_fmaf(f, s_l[w][h], lt);
                 o0 = __builtin_fmaf(f, s_o[w][h][d], o0);
@@ -1048,27 +1083,33 @@ int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, in
         return 0;
     }
     // decode form (few rows, long contexts): all kv heads per workgroup, fully coalesced token rows
+#ifndef I64H_AH_NW
+#define I64H_AH_NW 4  // waves per workgroup of that kernel
+#endif
+#ifndef I64H_AH_CH
+#define I64H_AH_CH 2  // 8-dim chunks per lane of the decode kernel at head_dim 64, 4 kv heads
+#endif
     bool done = false;
     const bool bp2 = block_size > 0 && (block_size & (block_size - 1)) == 0;  // other block sizes take the per-head kernel
-#define AH_T(HD_, KVH_, GS_, T)                                                                                                       \
-    hipLaunchKernelGGL((paged_attn_allheads_kernel<HD_, KVH_, GS_, T>), grid, dim3(256), 0, st, q, (const T*)k_cache, (const T*)v_cache, \
+#define AH_T(HD_, KVH_, GS_, CH_, NW_, T)                                                                                            \
+    hipLaunchKernelGGL((paged_attn_allheads_kernel<HD_, KVH_, GS_, CH_, NW_, T>), grid, dim3(NW_ * 64), 0, st, q, (const T*)k_cache, (const T*)v_cache, \
                        block_table, max_blocks_per_seq, slot_ids, ctx_len, softmax_scale, out, part_o, part_ml, block_size, splits,      \
                        arrivals, stats, stat_slot, g_attn_stamps)
-#define AH(HD_, KVH_, GS_)                                                                       \
+#define AH(HD_, KVH_, GS_, CH_, NW_)                                                                \
     if (!done && splits > 1 && bp2 && head_dim == HD_ && num_kv_heads == KVH_ && gs == GS_) {     \
         dim3 grid((unsigned)rows, (unsigned)splits);                                              \
-        if (kv_dtype == 0) AH_T(HD_, KVH_, GS_, float);                                           \
-        else if (kv_dtype == 1) AH_T(HD_, KVH_, GS_, __half);                                     \
-        else if (kv_dtype == 2) AH_T(HD_, KVH_, GS_, __hip_bfloat16);                             \
-        else if (kv_dtype == 3) AH_T(HD_, KVH_, GS_, F8E4);                                       \
-        else AH_T(HD_, KVH_, GS_, F8E5);                                                          \
+        if (kv_dtype == 0) AH_T(HD_, KVH_, GS_, CH_, NW_, float);                                      \
+        else if (kv_dtype == 1) AH_T(HD_, KVH_, GS_, CH_, NW_, __half);                                \
+        else if (kv_dtype == 2) AH_T(HD_, KVH_, GS_, CH_, NW_, __hip_bfloat16);                        \
+        else if (kv_dtype == 3) AH_T(HD_, KVH_, GS_, CH_, NW_, F8E4);                                  \
+        else AH_T(HD_, KVH_, GS_, CH_, NW_, F8E5);                                                     \
         done = true;                                                                              \
         rc = 0;                                                                                   \
     }
-    AH(64, 4, 4)
-    AH(32, 2, 2)
-    AH(16, 2, 2)
-    AH(128, 4, 2)
+    AH(64, 4, 4, I64H_AH_CH, I64H_AH_NW)
+    AH(32, 2, 2, 1, 4)
+    AH(16, 2, 2, 1, 4)
+    AH(128, 4, 2, 1, 4)
 #undef AH
 #undef AH_T
     if (!done) {
