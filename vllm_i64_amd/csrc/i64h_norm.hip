@@ -83,6 +83,13 @@ __global__ __launch_bounds__(256) void fused_residual_norm_kernel(const float* _
     }
     const int64_t t0 = (int64_t)blockIdx.x * rpb;
     const int64_t t1 = t0 + rpb < n ? t0 + rpb : n;
+    // the norm weights are requested together with the first row: behind the barrier they would be a round trip of their own
+    float4 gw[FRN_MAXV];
+#pragma unroll
+    for (int j = 0; j < FRN_MAXV; ++j) {
+        const int i = threadIdx.x + j * 256;
+        gw[j] = (normed && i < nv) ? ((const float4*)w)[i] : make_float4(0, 0, 0, 0);
+    }
     for (int64_t t = t0; t < t1; ++t) {
         float4 v[FRN_MAXV];
         float ss = 0.0f;
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(256) void fused_residual_norm_kernel(const float* _
         for (int j = 0; j < FRN_MAXV; ++j) {
             const int i = threadIdx.x + j * 256;
             if (i < nv) {
-                float4 g = ((const float4*)w)[i];
+                const float4 g = gw[j];
                 float4 a = v[j];
                 a.x = a.x * rr * g.x; a.y = a.y * rr * g.y; a.z = a.z * rr * g.z; a.w = a.w * rr * g.w;
                 ((float4*)(normed + t * H))[i] = a;
