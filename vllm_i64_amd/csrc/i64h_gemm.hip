@@ -811,32 +811,47 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
             for (int f = 0; f < NF; ++f) bq[f][s] = *(const v4i*)(bp[f] + st * 64);
         }
     };
-    bload(0);
-    SK_STAMP(1);
 
-    // the operand rows are requested first (their addresses do not depend on the parameters), then the quantization
-    // parameters of the rows are derived while those loads are in flight
+    // the operand rows are requested before the weights (loads return in order: the rows, which come from the cache levels,
+    // can then be quantized while the weight fragments are still on their way from HBM), then the quantization parameters of
+    // the rows are derived while all of it is in flight
     const int mfr = (rows + 15) / 16;          // live row fragments
     const int cpr = K / 16;                    // 16-element chunks per row
     const int total_chunks = mfr * 16 * cpr;   // rows padded to whole fragments (padding rows are zero)
     float4 f[4][4];
     int rr[4], kc[4];
+    bool aok[4];
+    // every load is issued (clamped to a valid address) so that the compiler can count the loads in flight; rows outside the
+    // tile are zeroed when they are used
     auto a_issue = [&](int c0) {
+        int src[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int c = c0 + u * NT;
-            rr[u] = c / cpr;
-            kc[u] = c - rr[u] * cpr;
-            const bool ok = c < total_chunks && rr[u] < rows;
-            int64_t src = row0 + (ok ? rr[u] : 0);
-            if (p.a_src_row) src = p.a_src_row[src];
-            if (p.a_src_mod > 0) src = src % p.a_src_mod;
-            const float* ap = (const float*)p.A + src * K + kc[u] * 16;
+            const int cc = min(c, total_chunks - 1);
+            rr[u] = cc / cpr;
+            kc[u] = cc - rr[u] * cpr;
+            aok[u] = c < total_chunks && rr[u] < rows;
+            src[u] = row0 + (rr[u] < rows ? rr[u] : 0);
+        }
+        if (p.a_src_row) {  // all four indices are requested before the first one is waited for
 #pragma unroll
-            for (int e = 0; e < 4; ++e) f[u][e] = ok ? *(const float4*)(ap + e * 4) : make_float4(0, 0, 0, 0);
+            for (int u = 0; u < 4; ++u) src[u] = p.a_src_row[src[u]];
+        }
+        if (p.a_src_mod > 0) {  // source rows are int32 entries or tile rows: 32-bit arithmetic
+#pragma unroll
+            for (int u = 0; u < 4; ++u) src[u] = (int)((uint32_t)src[u] % (uint32_t)p.a_src_mod);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float* ap = (const float*)p.A + (int64_t)src[u] * K + kc[u] * 16;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f[u][e] = *(const float4*)(ap + e * 4);
         }
     };
     a_issue(tid);
+    bload(0);
+    SK_STAMP(1);
     if (tid < SK_BM) {
         QParams q;
         q.scale = 0.0f; q.inv_scale = 0.0f; q.zp = 0;
@@ -859,7 +874,7 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
             q.inv_scale = q_inv[rr[u]]; q.zp = q_zp[rr[u]]; q.scale = 0.0f;
             uint32_t w[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) w[e] = quantize4_u7_signed(f[u][e], q);
+            for (int e = 0; e < 4; ++e) w[e] = aok[u] ? quantize4_u7_signed(f[u][e], q) : 0u;
             *(uint4*)(smem + rr[u] * LDA + kc[u] * 16) = make_uint4(w[0], w[1], w[2], w[3]);
         }
         if (c0 + NT * 4 < total_chunks) a_issue(c0 + NT * 4);
