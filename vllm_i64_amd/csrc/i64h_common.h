@@ -87,19 +87,58 @@ __device__ __forceinline__ void stat_fold_raw(const uint4 (&w)[I64H_SLOT_WORDS /
     hi = ordered_to_f32(b);
 }
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+// min / max over the 16 lanes of a row, every lane ends with the result (DPP: lane ^ 1, lane ^ 2, half-row mirror, row mirror)
+#define I64H_DPPF(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, true))
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, I64H_DPPF(v, 0xB1)); v = fmaxf(v, I64H_DPPF(v, 0x4E));
+    v = fmaxf(v, I64H_DPPF(v, 0x141)); v = fmaxf(v, I64H_DPPF(v, 0x140));
     return v;
+}
+__device__ __forceinline__ float row16_min(float v) {
+    v = fminf(v, I64H_DPPF(v, 0xB1)); v = fminf(v, I64H_DPPF(v, 0x4E));
+    v = fminf(v, I64H_DPPF(v, 0x141)); v = fminf(v, I64H_DPPF(v, 0x140));
+    return v;
+}
+// v exchanged with itself across wave halves / adjacent rows: {value of the lower partner, value of the upper partner} in
+// every lane.  The swap instructions exchange the contents of two registers in place, so the value is first copied into
+// two registers that the compiler must keep apart (both are in-out operands of the one asm statement); the waits around the
+// swap cover the VALU-write -> lane-exchange hazards, which the compiler does not track inside asm.
+struct PairF { float lo, hi; };
+__device__ __forceinline__ PairF swap_halves(float v) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return PairF{__builtin_bit_cast(float, a), __builtin_bit_cast(float, b)};
+}
+__device__ __forceinline__ PairF swap_rows(float v) {
+    unsigned a = __builtin_bit_cast(unsigned, v), b = a;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return PairF{__builtin_bit_cast(float, a), __builtin_bit_cast(float, b)};
+}
+__device__ __forceinline__ float wave_max(float v) {  // register-to-register lane exchanges only (no LDS round trips)
+    v = row16_max(v);
+    PairF a = swap_rows(v);
+    v = fmaxf(a.lo, a.hi);
+    PairF b = swap_halves(v);
+    return fmaxf(b.lo, b.hi);
 }
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-    return v;
+    v = row16_min(v);
+    PairF a = swap_rows(v);
+    v = fminf(a.lo, a.hi);
+    PairF b = swap_halves(v);
+    return fminf(b.lo, b.hi);
 }
+// Butterfly sum in the order lane ^ 32, ^ 16, ^ 8, ^ 4, ^ 2, ^ 1 (every lane ends with the same bits) without LDS round trips:
+// half and row swaps, then DPP.  After the ^ 8 step a row's values have period 8, so the rotation by 4 delivers lane ^ 4.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    PairF b = swap_halves(v);
+    v = b.lo + b.hi;
+    PairF a = swap_rows(v);
+    v = a.lo + a.hi;
+    v += I64H_DPPF(v, 0x128);  // row_ror:8
+    v += I64H_DPPF(v, 0x124);  // row_ror:4
+    v += I64H_DPPF(v, 0x4E);   // quad_perm [2,3,0,1]
+    v += I64H_DPPF(v, 0xB1);   // quad_perm [1,0,3,2]
     return v;
 }
 __device__ __forceinline__ int wave_sum_i(int v) {
@@ -125,8 +164,8 @@ __device__ __forceinline__ float group_sum(float v, int lanes) {  // lanes in {1
 }
 // max over lanes l and l ^ 32 (both halves of the wave end with the result)
 __device__ __forceinline__ float half_swap_max(float v) {
-    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
-    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+    PairF r = swap_halves(v);
+    return fmaxf(r.lo, r.hi);
 }
 
 // Device-coherent accesses for data handed from one workgroup to another inside a launch: relaxed agent-scope atomics

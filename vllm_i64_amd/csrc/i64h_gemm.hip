@@ -351,8 +351,8 @@ __device__ __forceinline__ void gemm_i8_body(const GemmI8Args& p, const int bid,
                     }
                 }
                 if (st) {
-#pragma unroll
-                    for (int o = 8; o > 0; o >>= 1) { a = fminf(a, __shfl_xor(a, o)); b = fmaxf(b, __shfl_xor(b, o)); }
+                    a = row16_min(a);
+                    b = row16_max(b);
                     if (fr == 0 && rok) {
                         const int rel = p.out_row_slot ? p.out_row_slot[row0 + r] : 0;
                         if (rel >= 0 && rel < I64H_STAT_TAB) {
@@ -799,6 +799,18 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
                 c_row[i][reg] = (p.c_row_map && r < rows) ? p.c_row_map[row0 + r] : row0 + r;
             }
     }
+    // SwiGLU with statistics: the slot of each of this lane's four output rows, requested now (the epilogue would otherwise
+    // start with a dependent read)
+    int o_rel[SK_MF][4];
+    if (EPI == EPI_SWIGLU) {
+#pragma unroll
+        for (int i = 0; i < SK_MF; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = i * 16 + fq * 4 + reg;
+                o_rel[i][reg] = (p.want_stats != 0 && p.out_row_slot && r < rows) ? p.out_row_slot[row0 + r] : 0;
+            }
+    }
 
     SK_STAMP(7);
     // then the first batch of weight fragments
@@ -981,10 +993,10 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
                     b = fmaxf(0.0f, v);
                 }
                 if (st) {
-#pragma unroll
-                    for (int o = 8; o > 0; o >>= 1) { a = fminf(a, __shfl_xor(a, o)); b = fmaxf(b, __shfl_xor(b, o)); }
+                    a = row16_min(a);
+                    b = row16_max(b);
                     if (fr == 0 && rok) {
-                        const int rel = p.out_row_slot ? p.out_row_slot[row0 + r] : 0;
+                        const int rel = o_rel[i][reg];
                         if (rel >= 0 && rel < I64H_STAT_TAB) {
                             atomicMin(&tab_lo[rel], f32_to_ordered(a));
                             atomicMax(&tab_hi[rel], f32_to_ordered(b));
