@@ -114,6 +114,12 @@ __device__ __forceinline__ PairF swap_rows(float v) {
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
     return PairF{__builtin_bit_cast(float, a), __builtin_bit_cast(float, b)};
 }
+// the value of lane ^ o: register exchanges for o = 16 and 32 (compile-time o), the LDS shuffle otherwise
+__device__ __forceinline__ float lane_xor(float v, int o) {
+    if (o == 32) { PairF r = swap_halves(v); return (threadIdx.x & 32) ? r.lo : r.hi; }
+    if (o == 16) { PairF r = swap_rows(v); return (threadIdx.x & 16) ? r.lo : r.hi; }
+    return __shfl_xor(v, o);
+}
 __device__ __forceinline__ float wave_max(float v) {  // register-to-register lane exchanges only (no LDS round trips)
     v = row16_max(v);
     PairF a = swap_rows(v);

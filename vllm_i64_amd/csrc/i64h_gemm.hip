@@ -654,8 +654,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
                     }
                 }
                 if (st) {
-                    a = fminf(a, __shfl_xor(a, 16)); b = fmaxf(b, __shfl_xor(b, 16));
-                    a = fminf(a, __shfl_xor(a, 32)); b = fmaxf(b, __shfl_xor(b, 32));
+                    a = fminf(a, lane_xor(a, 16)); b = fmaxf(b, lane_xor(b, 16));
+                    a = fminf(a, lane_xor(a, 32)); b = fmaxf(b, lane_xor(b, 32));
                     if (fq == 0 && rok) {
                         const int sl = p.out_row_slot ? rel[i] : 0;
                         if (sl >= 0 && sl < I64H_STAT_TAB) {
@@ -960,7 +960,7 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
             ss = wave_sum(ss);
             const float rr = w ? rsqrtf(ss / (float)hd + ta.qk_eps) : 1.0f;
             const float self = w ? x * rr * w[lane] : x;
-            const float partner = __shfl_xor(self, 32);
+            const float partner = lane_xor(self, 32);
             const float c = qk_c[j], sn = qk_s[j];
             const float other = lane < half ? -partner : partner;
             const float o = self * c + other * sn;
