@@ -774,7 +774,10 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_allheads_kernel(const floa
     const int bps = (nblk + splits - 1) / splits;
     const int t_begin = sp * bps * block;
     const int t_end = min(ctx, (sp + 1) * bps * block);
-    const int lane_off = kh * HD + ch * 8;  // element offset of the lane's chunk 0 inside a token row
+    const int lane_off = kh * HD;  // element offset of the lane's kv head inside a token row
+    // first dim of the lane's chunk j.  16- and 32-bit caches: chunk j of all chunk lanes is one run of CPH * 8 elements
+    // (whole 64-byte pieces per load instruction); 8-bit caches: a lane's chunks are adjacent, i.e. one 16-byte load per lane.
+    auto cdim = [&](int j) { return sizeof(KV) == 1 ? (ch * CH + j) * 8 : (j * CPH + ch) * 8; };
 
     // dims are handled in pairs so that the dot products and the value accumulation compile to packed fp32 FMAs.
     // Every token lane runs an online softmax of its own (m, l, acc); the token lanes are merged once, after the loop.
@@ -784,7 +787,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_allheads_kernel(const floa
     for (int h = 0; h < GS; ++h) {
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-            const float* qp = q + ((int64_t)row * NH + kh * GS + h) * HD + (j * CPH + ch) * 8;
+            const float* qp = q + ((int64_t)row * NH + kh * GS + h) * HD + cdim(j);
             float4 a = *(const float4*)qp, b = *(const float4*)(qp + 4);
             qr[h][j][0] = (v2f){a.x, a.y}; qr[h][j][1] = (v2f){a.z, a.w};
             qr[h][j][2] = (v2f){b.x, b.y}; qr[h][j][3] = (v2f){b.z, b.w};
@@ -817,8 +820,8 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_allheads_kernel(const floa
             const int64_t off = ((int64_t)max(pb, 0) * block + (tc & (block - 1))) * (KVH * HD) + lane_off;
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
-                nk[u][j].load(k_cache + off + j * CPH * 8);
-                nv[u][j].load(v_cache + off + j * CPH * 8);
+                nk[u][j].load(k_cache + off + cdim(j));
+                nv[u][j].load(v_cache + off + cdim(j));
             }
         }
         fetch_blocks(t0 + NW * TPI, pbn);
@@ -914,8 +917,8 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_allheads_kernel(const floa
             for (int j = 0; j < CH; ++j)
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    s_o[wid][head][(j * CPH + ch) * 8 + 2 * d] = acc[h][j][d].x;
-                    s_o[wid][head][(j * CPH + ch) * 8 + 2 * d + 1] = acc[h][j][d].y;
+                    s_o[wid][head][cdim(j) + 2 * d] = acc[h][j][d].x;
+                    s_o[wid][head][cdim(j) + 2 * d + 1] = acc[h][j][d].y;
                 }
             if (ch == 0) { s_m[wid][head] = m[h]; s_l[wid][head] = l[h]; }
         }
