@@ -770,10 +770,13 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_allheads_kernel(const floa
     // the block size is a power of two (host-checked): the per-token block index and offset are a shift and a mask
     const int bsh = __builtin_ctz(block);
     const float sl2 = scale * LOG2E;  // scores are kept in log2 units: exp2 is one instruction
-    const int nblk = (ctx + block - 1) / block;
-    const int bps = (nblk + splits - 1) / splits;
-    const int t_begin = sp * bps * block;
-    const int t_end = min(ctx, (sp + 1) * bps * block);
+    // The splits of a row interleave: workgroup iteration i of split sp covers tokens [(i * splits + sp) * NW * TPI, + NW * TPI).
+    // The share of a split is balanced for any context length and its first tokens do not depend on the length, so the first
+    // block-table entries are requested together with the length instead of after it.
+    constexpr int TPI = (I64H_AH_PDU / CH) * TPS;  // tokens per wave iteration
+    const int stride = splits * NW * TPI;
+    const int t_begin = sp * NW * TPI;
+    const int t_end = ctx;
     const int lane_off = kh * HD;  // element offset of the lane's kv head inside a token row
     // first dim of the lane's chunk j.  16- and 32-bit caches: chunk j of all chunk lanes is one run of CPH * 8 elements
     // (whole 64-byte pieces per load instruction); 8-bit caches: a lane's chunks are adjacent, i.e. one 16-byte load per lane.
@@ -797,7 +800,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_allheads_kernel(const floa
         m[h] = -INFINITY;
         l[h] = 0.0f;
     }
-    constexpr int TPI = PD_U * TPS;  // tokens per wave iteration
+    static_assert(TPI == PD_U * TPS, "tokens per wave iteration");
     auto fetch_blocks = [&](int t0, int (&pb)[PD_U]) {
 #pragma unroll
         for (int u = 0; u < PD_U; ++u) {
@@ -824,12 +827,23 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_allheads_kernel(const floa
                 nv[u][j].load(v_cache + off + cdim(j));
             }
         }
-        fetch_blocks(t0 + NW * TPI, pbn);
+        fetch_blocks(t0 + stride, pbn);
     };
-    fetch_blocks(t_begin + wid * TPI, pbn);
+    {
+        // first iteration: entries by token index alone (clamped to the table's width); lanes beyond the context, if any, then
+        // take the entry of the row's last token like every later iteration does (a second, dependent lookup: tails only)
+        bool beyond = false;
+#pragma unroll
+        for (int u = 0; u < PD_U; ++u) {
+            const int t = t_begin + wid * TPI + u * TPS + tl;
+            pbn[u] = bt[min(t >> bsh, max_blocks_per_seq - 1)];
+            beyond |= t >= t_end;
+        }
+        if (__any(beyond)) fetch_blocks(t_begin + wid * TPI, pbn);
+    }
     issue(t_begin + wid * TPI);
     PA_STAMP(1);
-    for (int t0 = t_begin + wid * TPI; t0 < t_end; t0 += NW * TPI) {
+    for (int t0 = t_begin + wid * TPI; t0 < t_end; t0 += stride) {
         Raw8<KV> rk[PD_U][CH], rv[PD_U][CH];
         bool live[PD_U];
 #pragma unroll
@@ -838,7 +852,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_allheads_kernel(const floa
             for (int j = 0; j < CH; ++j) { rk[u][j] = nk[u][j]; rv[u][j] = nv[u][j]; }
             live[u] = nlive[u];
         }
-        if (t0 + NW * TPI < t_end) issue(t0 + NW * TPI);
+        if (t0 + stride < t_end) issue(t0 + stride);
         float s[PD_U][GS], msafe[GS];
 #pragma unroll
         for (int u = 0; u < PD_U; ++u) {
