@@ -429,6 +429,34 @@ def test_paged_attention_random(dev, hd, nh, kvh):
         torch.testing.assert_close(out[i], ref, rtol=1e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("block,splits,kv_dtype", [(16, 4, torch.float32), (16, 7, torch.bfloat16), (32, 5, torch.bfloat16), (12, 4, torch.float32),
+                                                   (8, 16, torch.float32)])
+def test_paged_attention_split_interleave(dev, block, splits, kv_dtype):
+    """Long and ragged contexts over many split iterations (and a block size that is not a power of two, which takes the
+    per-head kernel): every split count and block size gives the oracle's cached attention."""
+    ops = _ops()
+    hd, nh, kvh = 64, 16, 4
+    g = torch.Generator().manual_seed(block * 100 + splits)
+    lens = [1, 31, 257, 700, 64, 129]
+    per = [(n + block - 1) // block for n in lens]
+    nblk = sum(per) + 3
+    kc = torch.empty(nblk, block, kvh, hd).normal_(0, 1, generator=g).to(kv_dtype)
+    vc = torch.empty(nblk, block, kvh, hd).normal_(0, 1, generator=g).to(kv_dtype)
+    perm = torch.randperm(nblk, generator=g).to(torch.int32)
+    bt = torch.full((len(lens), max(per) + 1), -1, dtype=torch.int32)
+    used = 0
+    for s_, nb in enumerate(per):
+        bt[s_, :nb] = perm[used:used + nb]
+        used += nb
+    q = torch.empty(len(lens), nh, hd).normal_(0, 1, generator=g)
+    out = ops.paged_attn(q.to(dev), kc.to(dev), vc.to(dev), bt.to(dev), torch.tensor(lens, dtype=torch.int32, device=dev), splits=splits).cpu()
+    for i, c in enumerate(lens):
+        kf = kc[bt[i, :per[i]].long()].reshape(-1, kvh, hd)[:c].float()
+        vf = vc[bt[i, :per[i]].long()].reshape(-1, kvh, hd)[:c].float()
+        ref = M.cached_attention(q[i:i + 1], kf, vf, nh // kvh, torch.tensor([c - 1]), 1.0 / hd ** 0.5)[0]
+        torch.testing.assert_close(out[i], ref, rtol=1e-5, atol=3e-6)
+
+
 @pytest.mark.parametrize("nh,kvh,kv_dtype,tol", [(16, 4, torch.float32, 3e-6), (16, 4, torch.bfloat16, 3e-6), (8, 8, torch.float16, 3e-6),
                                                  (4, 2, torch.float32, 3e-6), (8, 1, torch.bfloat16, 3e-6)])
 def test_prefill_attention_matrix_core_kernel(dev, nh, kvh, kv_dtype, tol):
