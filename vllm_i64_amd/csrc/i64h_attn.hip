@@ -732,8 +732,9 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict
 // Lane = (token in step, kv head, chunk lane); a lane owns CH 8-dim chunks, a wave step covers TPS = 64 / (KVH*HD/(8*CH))
 // tokens; PD_U steps are loaded together and share one online-softmax update.  Waves of a workgroup take interleaved
 // token groups.  Measured at batch 64, 2k contexts, bf16 cache: CH = 2 needs 385 VALU instructions per 8 KB of cache
-// against 497 at CH = 1 (same time: the loop is no longer issue-bound); 4 waves per workgroup at one workgroup per CU
-// beat 8 waves (34.8 against 33.8 us) and twice the loads in flight per wave (39.2 us, 322 registers).
+// against 497 at CH = 1, but the loop is not issue-bound and CH = 1 (twice the token lanes, half the registers) is 1 % of a
+// decode step faster once the splits interleave; 8-bit caches take CH = 2 for the 16-byte lane loads.  4 waves per
+// workgroup at one workgroup per CU beat 8 waves (34.8 against 33.8 us) and twice the loads in flight per wave (39.2 us).
 // The splits of a row are merged by whichever of the row's workgroups finishes last: partial results are written with
 // device-coherent stores and drained (vmcnt) before the workgroup's arrival is counted, and read back with
 // device-coherent loads; the counter is left at zero for the next launch.
@@ -1104,7 +1105,8 @@ int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, in
 #define I64H_AH_NW 4  // waves per workgroup of that kernel
 #endif
 #ifndef I64H_AH_CH
-#define I64H_AH_CH 2  // 8-dim chunks per lane of the decode kernel at head_dim 64, 4 kv heads
+#define I64H_AH_CH 2  // 8-dim chunks per lane of the decode kernel at head_dim 64, 4 kv heads, for 8-bit caches (one 16-byte
+                      // load per lane); 16- and 32-bit caches use one chunk: measured 1.1 % of a decode step better than two
 #endif
     bool done = false;
     const bool bp2 = block_size > 0 && (block_size & (block_size - 1)) == 0;  // other block sizes take the per-head kernel
@@ -1115,9 +1117,9 @@ int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, in
 #define AH(HD_, KVH_, GS_, CH_, NW_)                                                                \
     if (!done && splits > 1 && bp2 && head_dim == HD_ && num_kv_heads == KVH_ && gs == GS_) {     \
         dim3 grid((unsigned)rows, (unsigned)splits);                                              \
-        if (kv_dtype == 0) AH_T(HD_, KVH_, GS_, CH_, NW_, float);                                      \
-        else if (kv_dtype == 1) AH_T(HD_, KVH_, GS_, CH_, NW_, __half);                                \
-        else if (kv_dtype == 2) AH_T(HD_, KVH_, GS_, CH_, NW_, __hip_bfloat16);                        \
+        if (kv_dtype == 0) AH_T(HD_, KVH_, GS_, 1, NW_, float);                                        \
+        else if (kv_dtype == 1) AH_T(HD_, KVH_, GS_, 1, NW_, __half);                                  \
+        else if (kv_dtype == 2) AH_T(HD_, KVH_, GS_, 1, NW_, __hip_bfloat16);                          \
         else if (kv_dtype == 3) AH_T(HD_, KVH_, GS_, CH_, NW_, F8E4);                                  \
         else AH_T(HD_, KVH_, GS_, CH_, NW_, F8E5);                                                     \
         done = true;                                                                              \
