@@ -48,9 +48,9 @@ __device__ __forceinline__ float ordered_to_f32(uint32_t k) {
 }
 #define I64H_ORDERED_ZERO 0x80000000u  // f32_to_ordered(+0.0f)
 
-// A stat slot is sharded: I64H_NSHARD (min, max) pairs, 16 words per slot.  Producers spread their atomics over
+// A stat slot is sharded: I64H_NSHARD (min, max) pairs, 64 words per slot.  Producers spread their atomics over
 // the shards (contended same-address atomics serialise at ~100 ns each on this chip), consumers fold the shards.
-#define I64H_NSHARD 8
+#define I64H_NSHARD 32
 #define I64H_SLOT_WORDS (2 * I64H_NSHARD)
 
 __device__ __forceinline__ void stat_update(uint32_t* stats, int slot, int shard, float lo, float hi) {
