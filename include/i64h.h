@@ -200,6 +200,17 @@ int64_t i64h_moe_forward_workspace_bytes(int64_t n, const i64h_moe_layer* layer)
 int i64h_moe_forward(const float* x, const int64_t* token_ids, int64_t n, const i64h_moe_layer* layer, float* out, void* workspace,
                      int64_t workspace_bytes, void* stream);
 
+/* The same layer out of the library's own scratch memory, for callers that cannot allocate (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The workspace is a
+ * file-scope device array of i64h_moe_forward_static_max_bytes() = 8 MiB that every GPU the library runs on holds until
+ * the process ends; a call whose i64h_moe_forward_workspace_bytes(n, layer) exceeds it is rejected with an error (use
+ * i64h_moe_forward).  The call allocates nothing and frees nothing.  All calls on one GPU share that GPU's array: calls
+ * that overlap in time on one GPU race.  i64h_moe_forward_static_init() looks up the array's device address for the
+ * current device (the first call on a device does it by itself; do it beforehand when the call will be captured). */
+int64_t i64h_moe_forward_static_max_bytes(void);
+int i64h_moe_forward_static_init(void);
+int i64h_moe_forward_static(const float* x, const int64_t* token_ids, int64_t n, const i64h_moe_layer* layer, float* out, void* stream);
+
 /* ---- row kernels -------------------------------------------------------------------------------------------------------
  * nn.Embedding lookup (model.py:415). */
 int i64h_embedding(const int64_t* ids, const float* table, float* out, int64_t n, int32_t H, int64_t V, void* stream);

@@ -58,6 +58,8 @@ SIGNATURES: Dict[str, str] = {
     "i64h_gemm_i8_qkv_rope_kv": "pppfpppp" + "ipppiiiiip",
     "i64h_gemm_i8_colscale": "ppppliipp",
     "i64h_moe_forward": "pplppplp",
+    "i64h_moe_forward_static": "pplppp",
+    "i64h_moe_forward_static_init": "",
     "i64h_set_skinny_waves": "i",
     "i64h_debug_set_stamps": "pl",
     "i64h_set_gemm_stage64": "i",
@@ -75,7 +77,7 @@ class I64HError(RuntimeError):
 
 def exported_symbols():
     return ["i64h_last_error", "i64h_version", "i64h_device_check", "i64h_bucketize_workspace_bytes",
-            "i64h_paged_attn_workspace_floats", "i64h_stats_words_per_slot", "i64h_moe_forward_workspace_bytes", "i64h_debug_stamp_cursor", *SIGNATURES.keys()]
+            "i64h_paged_attn_workspace_floats", "i64h_stats_words_per_slot", "i64h_moe_forward_workspace_bytes", "i64h_moe_forward_static_max_bytes", "i64h_debug_stamp_cursor", *SIGNATURES.keys()]
 
 
 class GemmDesc(ctypes.Structure):
@@ -117,6 +119,8 @@ def load() -> ctypes.CDLL:
     lib.i64h_stats_words_per_slot.argtypes = []
     lib.i64h_debug_stamp_cursor.restype = _L
     lib.i64h_debug_stamp_cursor.argtypes = []
+    lib.i64h_moe_forward_static_max_bytes.restype = _L
+    lib.i64h_moe_forward_static_max_bytes.argtypes = []
     lib.i64h_moe_forward_workspace_bytes.restype = _L
     lib.i64h_moe_forward_workspace_bytes.argtypes = [_L, _P]
     for name, sig in SIGNATURES.items():

@@ -6,8 +6,13 @@
 #include "i64h.h"
 #include "i64h_common.h"
 
+#define I64H_MOE_STATIC_BYTES (8ll << 20)
+static __device__ __align__(256) unsigned char scratch[I64H_MOE_STATIC_BYTES];
+
 namespace {
 
+constexpr int64_t kStaticBytes = I64H_MOE_STATIC_BYTES;
+constexpr int kMaxDevices = 64;
 constexpr int64_t kAlign = 256;
 constexpr int kFuseMaxRows = 256;  // decode-sized calls: quantizer fused into the weight-streaming GEMM, two launches per layer
 
@@ -61,6 +66,28 @@ MoeScratch carve(void* ws, int64_t n, const i64h_moe_layer* L) {
     s.shs = c.take<float>(big && L->shared_inter > 0 ? n : 0);
     s.bytes = c.off;
     return s;
+}
+
+// ---- the workspace of the entry point that allocates nothing -------------------------------------------------------------
+// One array per GPU, held by the code object from the moment the library is loaded on that GPU until the process ends.
+// In host code the array's name is only a stand-in for the symbol: its device address is looked up once per device
+// (scratch_of) and only that address is ever handed to kernels.
+void* g_scratch_ptr[kMaxDevices] = {};
+
+// device address of the current device's copy of `scratch` (looked up on first use per device; the lookup is idempotent, so
+// two threads racing through it store the same value)
+int scratch_of(void** out) {
+    int dev = -1;
+    I64H_CHECK_HIP(hipGetDevice(&dev));
+    I64H_CHECK_ARG(dev >= 0 && dev < kMaxDevices, "static scratch: device ordinal %d unsupported", dev);
+    void* p = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+    if (p == nullptr) {
+        I64H_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        I64H_CHECK_ARG(p != nullptr && ((uintptr_t)p & (kAlign - 1)) == 0, "static scratch: bad symbol address");
+        __atomic_store_n(&g_scratch_ptr[dev], p, __ATOMIC_RELEASE);
+    }
+    *out = p;
+    return 0;
 }
 
 int check_layer(const i64h_moe_layer* L, const char* who) {
@@ -153,6 +180,34 @@ int i64h_moe_forward(const float* x, const int64_t* token_ids, int64_t n, const 
                                   L->shared_scale, out, nullptr, 0.0f, nullptr, n, L->hidden, nullptr, 0, 0, nullptr, stream));
 #undef STEP
     return 0;
+}
+
+int64_t i64h_moe_forward_static_max_bytes(void) { return kStaticBytes; }
+
+// Set-up of the entry point below for the current device: looks up the device address of the library's scratch array.  Cheap
+// and idempotent; i64h_moe_forward_static does it by itself on its first call on a device, a caller that will capture the
+// call into a HIP graph does it beforehand.
+int i64h_moe_forward_static_init(void) {
+    void* p = nullptr;
+    return scratch_of(&p);
+}
+
+// i64h_moe_forward out of the library's own per-GPU scratch array instead of a caller workspace: no hipMalloc / hipFree, no
+// allocating routine, nothing to size.  Rejects calls whose workspace would not fit the array.  All calls on one GPU share
+// the array: two calls that overlap in time on one GPU (different streams, different threads) race.
+int i64h_moe_forward_static(const float* x, const int64_t* token_ids, int64_t n, const i64h_moe_layer* L, float* out, void* stream) {
+    if (int rc = check_layer(L, "moe_forward_static")) return rc;
+    I64H_CHECK_ARG(n >= 0 && n * L->top_k < (1ll << 30), "moe_forward_static: bad token count");
+    const int64_t need = carve(nullptr, n, L).bytes;
+    I64H_CHECK_ARG(need <= kStaticBytes,
+                   "moe_forward_static: %lld tokens of this layer need %lld workspace bytes, the static scratch holds %lld; use "
+                   "i64h_moe_forward with a caller workspace",
+                   (long long)n, (long long)need, (long long)kStaticBytes);
+    void* ws = nullptr;
+    if (int rc = scratch_of(&ws)) return rc;
+    // every word the layer reads from the workspace is written earlier in the same call (the plan, the statistics reset, the
+    // intermediates), so the previous call's contents need no clearing
+    return i64h_moe_forward(x, token_ids, n, L, out, ws, kStaticBytes, stream);
 }
 
 }  // extern "C"
