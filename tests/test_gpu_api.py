@@ -60,6 +60,9 @@ def test_get_i64_cuda_ops_surface(dev, golden_dir):
     assert (back.cpu() - torch.from_numpy(z["rms_x"])).abs().max() <= s.max().item()
     qw, sw = k.quantize_perchannel_int8(d("rms_x"))
     assert qw.dtype == torch.int8 and int(qw.min()) >= -128 and int(qw.max()) <= 127      # tests/test_utils.py:104-128
+    # per-output-channel weight codes and scales: bit exact against the reference's quantize_int8 (core/quantization.py:80-91)
+    assert np.array_equal(sw.cpu().numpy(), z["q8_ws"]) and np.array_equal(qw.cpu().numpy(), z["q8_w"])
+    assert np.array_equal(q.cpu().numpy(), z["q8_a"])
     assert np.array_equal(k.rope_integer_forward(d("rope_x"), d("rope_cq"), d("rope_sq")).cpu().numpy(), z["rope_int_out"])
     assert np.allclose(k.rope_forward(d("rope_x"), d("rope_cos"), d("rope_sin")).cpu().numpy(), z["rope_out"], atol=1e-6)
     g = torch.Generator().manual_seed(2)
