@@ -211,6 +211,55 @@ int64_t i64h_moe_forward_static_max_bytes(void);
 int i64h_moe_forward_static_init(void);
 int i64h_moe_forward_static(const float* x, const int64_t* token_ids, int64_t n, const i64h_moe_layer* layer, float* out, void* stream);
 
+/* ---- decode-sized steps: everything between two attention calls in one launch --------------------------------------------
+ * For n <= 256 rows (one token per sequence): o projection, residual + RMSNorm, gate_up and down projections of the routed
+ * experts and of the shared expert (or of a dense MLP), weighted combine + residual + next RMSNorm, and optionally the NEXT
+ * layer's qkv projection with per-head RMSNorm, RoPE and paged-KV write - the decoder-layer glue of
+ * vllm_i64/models/complexity_deep/model.py:349-369 around TokenRoutedMLP.forward (vllm_i64/layers/token_routed_mlp.py:154-187)
+ * with the dynamic int8 Linears of vllm_i64/core/loader.py:57-94 - as phases of ONE resident grid separated by grid barriers
+ * instead of six launches; bit-identical to the launch-per-call path (i64h_gemm_i8_pair / i64h_fused_residual_norm /
+ * i64h_gemm_i8_qkv_rope_kv with the same arguments).  Stat slot layout relative to slot_base: 0 qkv input, 1 o input (filled
+ * by the attention call), 2 shared gate_up (dense: gate_up) input, 3 + b bucket gate_up input (b = expert * top_k + route),
+ * 3 + nb shared down (dense: down) input, 4 + nb + b bucket down input (nb = num_experts * top_k); the statistics of `normed`
+ * at the end go to next_slot_base when want_next_stats.  The routing plan (perm, sorted_bucket, expert_offsets, tok_slots) is
+ * this layer's slice of i64h_moe_plan's outputs.  sync: i64h_decode_sync_words() uint32, zeroed once by the caller; every
+ * launch leaves them zero except word 1, a sticky error flag set when a barrier wait exceeded its budget (results are then
+ * invalid).  Launches sharing one sync buffer must not overlap.  The grid is one workgroup per CU at most, so the launch
+ * must not run concurrently with other work that could keep some of its workgroups from being scheduled. */
+typedef struct i64h_decode_tail {
+    int32_t n, hidden, num_experts /* 0: dense MLP */, top_k, expert_inter, mlp_inter /* shared expert or dense MLP width, 0: none */;
+    int32_t slot_base, next_slot_base, want_next_stats;
+    int32_t workgroups; /* 0 = one per CU */
+    float rms_eps, routed_scale, shared_scale;
+    float route_weights[8];
+    /* residual stream [n, hidden] (updated in place), attention output [n, hidden], scratch / outputs, all fp32 */
+    float *h, *normed, *o_buf, *e_inter /* [n * top_k, expert_inter] */, *e_out /* [n * top_k, hidden] */, *sh_inter /* [n, mlp_inter] */,
+        *sh_out /* [n, hidden] */;
+    const float* attn;
+    const int8_t *o_w, *exp_gu, *exp_dn, *sh_gu, *sh_dn;           /* [N][K] per matrix; experts [E][N][K] */
+    const float *o_s, *exp_gu_s, *exp_dn_s, *sh_gu_s, *sh_dn_s;    /* one scale per fused matrix ([E] for experts) */
+    const float *ln2, *next_norm;                                  /* RMSNorm weights [hidden] */
+    const int32_t *perm, *sorted_bucket, *expert_offsets, *tok_slots;
+    uint32_t *stats, *sync;
+    /* next layer's qkv projection (qkv_w NULL: none); arguments as i64h_gemm_i8_qkv_rope_kv */
+    const int8_t* qkv_w;
+    const float *qkv_s, *q_norm, *k_norm, *rope_tab;
+    float qk_eps;
+    const int32_t *positions, *slot_ids, *block_table;
+    int32_t max_blocks_per_seq, kv_dtype, num_heads, num_kv_heads, head_dim, block_size;
+    float* q_out;
+    void *k_cache, *v_cache;
+} i64h_decode_tail;
+int64_t i64h_decode_sync_words(void);
+/* Two steps: i64h_decode_tail_prepare (set-up, synchronous: validates, lays out the phases, writes the kernel's argument
+ * block of i64h_decode_tail_args_bytes() bytes to args_dev, fills launch[0..1]) once per layer and batch shape - nothing in the
+ * description changes from step to step, the per-step inputs are device buffers - then i64h_decode_tail_run per step
+ * (one launch, no allocation, no synchronisation: graph-capturable). */
+int64_t i64h_decode_tail_args_bytes(void);
+int i64h_decode_tail_prepare(const i64h_decode_tail* t, void* args_dev, int32_t* launch);
+int i64h_decode_tail_run(const void* args_dev, const int32_t* launch, void* stream);
+int i64h_debug_set_decode_stamps(void* buffer); /* diagnostics: 16 uint64 of s_memtime phase stamps per workgroup, written by launches prepared after this call; NULL = off */
+
 /* ---- row kernels -------------------------------------------------------------------------------------------------------
  * nn.Embedding lookup (model.py:415). */
 int i64h_embedding(const int64_t* ids, const float* table, float* out, int64_t n, int32_t H, int64_t V, void* stream);

@@ -59,6 +59,9 @@ SIGNATURES: Dict[str, str] = {
     "i64h_gemm_i8_colscale": "ppppliipp",
     "i64h_moe_forward": "pplppplp",
     "i64h_moe_forward_static": "pplppp",
+    "i64h_decode_tail_prepare": "ppp",
+    "i64h_decode_tail_run": "ppp",
+    "i64h_debug_set_decode_stamps": "p",
     "i64h_moe_forward_static_init": "",
     "i64h_set_skinny_waves": "i",
     "i64h_debug_set_stamps": "pl",
@@ -77,7 +80,7 @@ class I64HError(RuntimeError):
 
 def exported_symbols():
     return ["i64h_last_error", "i64h_version", "i64h_device_check", "i64h_bucketize_workspace_bytes",
-            "i64h_paged_attn_workspace_floats", "i64h_stats_words_per_slot", "i64h_moe_forward_workspace_bytes", "i64h_moe_forward_static_max_bytes", "i64h_debug_stamp_cursor", *SIGNATURES.keys()]
+            "i64h_paged_attn_workspace_floats", "i64h_stats_words_per_slot", "i64h_moe_forward_workspace_bytes", "i64h_moe_forward_static_max_bytes", "i64h_decode_sync_words", "i64h_decode_tail_args_bytes", "i64h_debug_stamp_cursor", *SIGNATURES.keys()]
 
 
 class GemmDesc(ctypes.Structure):
@@ -94,6 +97,21 @@ class MoeLayer(ctypes.Structure):
                 ("shared_inter", _I), ("exp_gate_up", _P), ("exp_gate_up_scale", _P), ("exp_down", _P), ("exp_down_scale", _P),
                 ("shared_gate_up", _P), ("shared_gate_up_scale", _P), ("shared_down", _P), ("shared_down_scale", _P),
                 ("route_weights", _P), ("routed_scale", ctypes.c_float), ("shared_scale", ctypes.c_float)]
+
+
+class DecodeTail(ctypes.Structure):
+    """Mirror of i64h_decode_tail (include/i64h.h)."""
+    _fields_ = ([(n, _I) for n in ("n", "hidden", "num_experts", "top_k", "expert_inter", "mlp_inter", "slot_base", "next_slot_base",
+                                   "want_next_stats", "workgroups")]
+                + [("rms_eps", _F), ("routed_scale", _F), ("shared_scale", _F), ("route_weights", _F * 8)]
+                + [(n, _P) for n in ("h", "normed", "o_buf", "e_inter", "e_out", "sh_inter", "sh_out", "attn", "o_w", "exp_gu", "exp_dn",
+                                     "sh_gu", "sh_dn", "o_s", "exp_gu_s", "exp_dn_s", "sh_gu_s", "sh_dn_s", "ln2", "next_norm", "perm",
+                                     "sorted_bucket", "expert_offsets", "tok_slots", "stats", "sync", "qkv_w", "qkv_s", "q_norm",
+                                     "k_norm", "rope_tab")]
+                + [("qk_eps", _F)]
+                + [(n, _P) for n in ("positions", "slot_ids", "block_table")]
+                + [(n, _I) for n in ("max_blocks_per_seq", "kv_dtype", "num_heads", "num_kv_heads", "head_dim", "block_size")]
+                + [(n, _P) for n in ("q_out", "k_cache", "v_cache")])
 
 
 def load() -> ctypes.CDLL:
@@ -120,6 +138,9 @@ def load() -> ctypes.CDLL:
     lib.i64h_debug_stamp_cursor.restype = _L
     lib.i64h_debug_stamp_cursor.argtypes = []
     lib.i64h_moe_forward_static_max_bytes.restype = _L
+    for name in ("i64h_decode_sync_words", "i64h_decode_tail_args_bytes"):
+        getattr(lib, name).restype = _L
+        getattr(lib, name).argtypes = []
     lib.i64h_moe_forward_static_max_bytes.argtypes = []
     lib.i64h_moe_forward_workspace_bytes.restype = _L
     lib.i64h_moe_forward_workspace_bytes.argtypes = [_L, _P]

@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libi64hip.so")
-SOURCES = ["i64h_api.hip", "i64h_route.hip", "i64h_quant.hip", "i64h_norm.hip", "i64h_gemm.hip", "i64h_attn.hip", "i64h_moe.hip", "i64h_fp8.hip", "i64h_kv.hip"]
+SOURCES = ["i64h_api.hip", "i64h_route.hip", "i64h_quant.hip", "i64h_norm.hip", "i64h_gemm.hip", "i64h_attn.hip", "i64h_moe.hip", "i64h_fp8.hip", "i64h_kv.hip", "i64h_decode.hip"]
 # -ffp-contract=off: a*b+c stays two roundings unless the source says fmaf, so fp32 element-wise math has the
 # same rounding steps as the reference's CPU ops.
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
@@ -26,7 +26,8 @@ def _stale(obj: str, src: str) -> bool:
         return True
     t = os.path.getmtime(obj)
     # every object depends on both headers: the public one carries structs that cross translation units
-    deps = [src, os.path.join(CSRC, "i64h_common.h"), os.path.join(os.path.dirname(HERE), "include", "i64h.h"), os.path.abspath(__file__)]
+    deps = [src, os.path.join(os.path.dirname(HERE), "include", "i64h.h"), os.path.abspath(__file__)]
+    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -17,58 +17,8 @@
 //
 // gemm_f32_kernel: C = A[M,K] @ B[N,K]^T in fp32 on v_mfma_f32_16x16x4_f32 (tied lm_head; bit-for-bit a k-ordered
 //   fmaf chain per output).  gemm_w8a32_kernel: fp32 activations x dequantised int8 weights (operator API).
-#include "i64h_common.h"
-#include <hip/hip_bf16.h>
-#include <hip/hip_fp16.h>
+#include "i64h_gemm_dev.h"
 
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-
-#define EPI_STORE 0
-#define EPI_SWIGLU 1
-// decode-sized kernel only:
-#define EPI_QKR 2  // fused qkv projection: a 64-column tile is one head -> per-head RMSNorm + RoPE, q to q_out, K/V into the paged cache
-#define BK 128
-#define MAX_GROUPS 256
-
-// One grouped GEMM problem (device-side view of i64h_gemm_desc).
-struct GemmI8Args {
-    const void* A;             // int8 [M_total, K] (a_fp32 == 0) or fp32 [*, K] (a_fp32 == 1: quantized while staged)
-    const int32_t* a_src_row;  // a_fp32: source row of operand row r (nullptr: r), taken modulo a_src_mod when > 0
-    int a_src_mod;
-    const float* row_scale;    // a_fp32 == 0: [M_total]
-    const int32_t* a_row_slot; // a_fp32 == 1: stat slot of row r = a_slot_base + (a_row_slot ? a_row_slot[r] : 0)
-    int a_slot_base;
-    const int8_t* B;           // [G][N][K]
-    const float* w_scale;      // [G]
-    const float* col_scale;    // EPI_STORE, optional: per-output-channel scale [G][N] used instead of w_scale[g]
-    const int32_t* c_row_map;  // EPI_STORE, optional: operand row r is stored as output row c_row_map[r] (not in the row-streaming kernel)
-    int a_group_slots;         // a_fp32, optional promise: a_row_slot[r] of a row of group g lies in [g * S, g * S + S) (S = this value)
-    const int32_t* group_off;  // [G+1] device, or nullptr => one group [0, M_total)
-    int G, M_total, N, K;
-    float* C;                  // EPI_STORE: [M_total, N]; EPI_SWIGLU: [M_total, N/2]
-    const int32_t* out_row_slot;  // EPI_SWIGLU statistics: slot of row r = out_slot_base + (out_row_slot ? out_row_slot[r] : 0)
-    int out_slot_base;
-    uint32_t* stats;           // stat slots (input parameters for a_fp32, output statistics for EPI_SWIGLU); may be nullptr
-    int want_stats;
-    unsigned long long* stamps;  // diagnostics: per-workgroup phase timestamps (nullptr = off)
-};
-// What the row-wise epilogue of the decode-sized kernel needs beyond the GEMM itself.
-struct RowTailArgs {
-    // EPI_QKR (the arguments of i64h_qk_norm_rope_kv)
-    const int32_t* positions;
-    const int32_t* slot_ids;
-    const int32_t* block_table;
-    int max_blocks_per_seq;
-    const float* rope_tab;
-    const float* qw;
-    const float* kw;
-    float qk_eps;
-    float* q_out;
-    void* k_cache;
-    void* v_cache;
-    int kv_dtype, nh, kvh, block;
-};
 struct GemmI8Pair {
     GemmI8Args p[2];
     int nblk0;  // workgroups [0, nblk0) run p[0], the rest p[1]
@@ -80,39 +30,6 @@ __device__ __forceinline__ int swz(int row, int chunk) { return row * BK + ((chu
 __device__ __forceinline__ int swz64(int row, int chunk) { return row * 64 + ((chunk ^ (((row >> 2) & 1) * 3)) << 4); }
 template <int BKT>
 __device__ __forceinline__ int swzt(int row, int chunk) { return BKT == 128 ? swz(row, chunk) : swz64(row, chunk); }
-
-// Wave-wide search for m-tile mt of a grouped problem: lane i looks at group c0 + i, 64 groups per pass; writes
-// (group or -1, first row, rows in the tile) to s_info.  The grid is an upper bound on the number of m-tiles.
-template <int BM>
-__device__ __forceinline__ void locate_mtile(const GemmI8Args& p, const int mt, const int lane, int* s_info) {
-    int g = -1, row0 = 0, rows = 0, base = 0;
-    const int G = p.group_off ? p.G : 1;
-    for (int c0 = 0; c0 < G && g < 0; c0 += 64) {
-        const int i = c0 + lane;
-        int b = 0, e = 0;
-        if (i < G) {
-            b = p.group_off ? p.group_off[i] : 0;
-            e = p.group_off ? p.group_off[i + 1] : p.M_total;
-        }
-        const int tiles = (e - b + BM - 1) / BM;
-        int incl = tiles;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o);
-            if (lane >= o) incl += t;
-        }
-        const int excl = base + incl - tiles;
-        const unsigned long long hit = __ballot(i < G && mt >= excl && mt < excl + tiles);
-        if (hit) {
-            const int src = __ffsll(hit) - 1;
-            g = c0 + src;
-            row0 = __shfl(b, src) + (mt - __shfl(excl, src)) * BM;
-            rows = min(BM, __shfl(e, src) - row0);
-        }
-        base += __shfl(incl, 63);
-    }
-    if (lane == 0) { s_info[0] = g; s_info[1] = row0; s_info[2] = rows; }
-}
 
 // BKT = K bytes per LDS stage: 128 (two MFMA K steps per barrier, fragment reads software-pipelined) or 64 (one step per
 // barrier, half the LDS and fewer registers: four 128 x 128 workgroups per CU, which is what hides the per-tile prologue
@@ -697,16 +614,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #define SK_MF (SK_BM / 16)
 #define SK_AREA_MIN 4096  // >= 2 * I64H_STAT_TAB * 4 (statistics table) and >= 16 * 64 * 4 (head tile)
 static_assert(SK_AREA_MIN >= 2 * I64H_STAT_TAB * 4 && SK_AREA_MIN >= 16 * 64 * 4, "epilogue scratch of the decode-sized kernel");
-
-__device__ __forceinline__ void kv_store(void* cache, int64_t idx, float v, int kv_dtype) {
-    switch (kv_dtype) {
-        case 0: ((float*)cache)[idx] = v; break;
-        case 1: ((__half*)cache)[idx] = __float2half(v); break;
-        case 2: ((__hip_bfloat16*)cache)[idx] = __float2bfloat16(v); break;
-        case 3: ((uint8_t*)cache)[idx] = f32_to_e4m3fn(v); break;
-        default: ((uint8_t*)cache)[idx] = f32_to_e5m2(v); break;
-    }
-}
 
 template <int EPI, int NW>
 __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const int bid, char* smem, const RowTailArgs& ta) {

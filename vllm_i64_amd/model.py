@@ -138,6 +138,7 @@ class _Buffers:
         self.logits = torch.empty(n_logit_rows, cfg.vocab_size, **f32)
         self.attn_ws: Optional[torch.Tensor] = None
         self.attn_splits = 1
+        self.tails: Dict[tuple, list] = {}   # prepared persistent-launch descriptions per set of external buffers
 
 
 class I64MoEModel:
@@ -195,6 +196,7 @@ class I64MoEModel:
         self.spl = 4 + 2 * self.nb if cfg.is_moe else 4       # stat slots per layer
         self.stats = ops.stats_alloc(self.spl * cfg.num_layers + 1, dev)
         self._bufs: Dict[tuple, _Buffers] = {}
+        self.dec_sync = ops.decode_sync_alloc(dev)
 
     # ---- helpers ----
     def buffers(self, n: int, n_logit_rows: int) -> _Buffers:
@@ -206,6 +208,79 @@ class I64MoEModel:
     FUSE_MAX_ROWS = 256  # up to this many operand rows the quantizer runs inside the GEMM (one launch per Linear call)
     fuse_qkr = True   # decode-sized steps: QK norm / RoPE / cache write inside the qkv GEMM
     attn_target_wgs = int(os.environ.get("I64H_ATTN_WGS", "256"))  # decode attention: rows x splits aimed at = one 4-wave workgroup per CU (measured: 256 beats 512 and 1024 at batch 64, ctx 2048)
+
+    # decode-sized steps: everything between two attention calls (o projection ... next layer's qkv projection) as one
+    # persistent launch (i64h_decode_tail_run) instead of six.  Bit-identical to the launch-per-call path; off by default:
+    # measured on MI355X it is the slower form (each phase is a chain of memory round trips either way, a grid barrier costs
+    # what a dependent kernel boundary costs, and in-launch hand-offs read through device-coherent loads)
+    use_tail = os.environ.get("I64H_DECODE_TAIL", "0") == "1"
+    TAIL_MAX_ROWS = 256
+
+    def _tail_supported(self, n: int) -> bool:
+        cfg = self.cfg
+        H = cfg.hidden_size
+        if not (self.use_tail and self.ep_layers is None and 1 <= n <= self.TAIL_MAX_ROWS and cfg.head_dim == 64):
+            return False
+        if H % 64 or not 256 <= H <= 2048:
+            return False
+        if cfg.is_moe:
+            S = cfg.shared_intermediate_size or 0
+            return cfg.expert_inter % 64 == 0 and 64 <= cfg.expert_inter <= 2016 and S % 64 == 0 and cfg.top_k <= 8 and cfg.num_experts <= 64
+        return cfg.intermediate_size % 64 == 0 and 16 * (cfg.intermediate_size + 32) <= 128 * 1024
+
+    def _tails(self, B: _Buffers, kvc, positions, slot_ids) -> list:
+        """The prepared per-layer persistent launches for this buffer set and these external buffers (built on first use:
+        set-up is synchronous, so not under graph capture - GreedyDecoder.prepare runs one eager step first)."""
+        key = (positions.data_ptr(), slot_ids.data_ptr(), kvc.block_table.data_ptr(), kvc.k[0].data_ptr(), kvc.v[0].data_ptr())
+        if key in B.tails:
+            return B.tails[key]
+        if len(B.tails) >= 8:  # callers that pass fresh position / slot tensors every step: keep the cache bounded
+            B.tails.clear()
+        from . import _lib
+        cfg, L, spl = self.cfg, self.cfg.num_layers, self.spl
+        n = B.h.shape[0]
+        tails = []
+        for l, W in enumerate(self.layers):
+            d = _lib.DecodeTail()
+            d.n, d.hidden, d.top_k = n, cfg.hidden_size, cfg.top_k if cfg.is_moe else 0
+            d.slot_base, d.next_slot_base, d.want_next_stats, d.workgroups = l * spl, (l + 1) * spl, int(l + 1 < L), 0
+            d.rms_eps = cfg.rms_eps
+            d.h, d.normed, d.o_buf, d.attn = ops.ptr(B.h), ops.ptr(B.normed), ops.ptr(B.o), ops.ptr(B.attn)
+            d.o_w, d.o_s, d.ln2 = ops.ptr(W["o"].w_q), ops.ptr(W["o"].w_s), ops.ptr(W["ln2"])
+            d.next_norm = ops.ptr(self.layers[l + 1]["ln1"] if l + 1 < L else self.final_norm)
+            d.stats, d.sync = ops.ptr(self.stats), ops.ptr(self.dec_sync)
+            if cfg.is_moe:
+                S = cfg.shared_intermediate_size or 0
+                d.num_experts, d.expert_inter, d.mlp_inter = cfg.num_experts, cfg.expert_inter, S
+                d.routed_scale, d.shared_scale = cfg.routed_scale, cfg.shared_scale
+                for k, wk in enumerate(cfg.route_weights):
+                    d.route_weights[k] = float(wk)
+                d.e_inter, d.e_out = ops.ptr(B.e_inter), ops.ptr(B.e_out)
+                d.exp_gu, d.exp_gu_s = ops.ptr(W["exp_gu"].w_q), ops.ptr(W["exp_gu"].w_s)
+                d.exp_dn, d.exp_dn_s = ops.ptr(W["exp_dn"].w_q), ops.ptr(W["exp_dn"].w_s)
+                if S:
+                    d.sh_inter, d.sh_out = ops.ptr(B.sh_inter), ops.ptr(B.sh_out)
+                    d.sh_gu, d.sh_gu_s = ops.ptr(W["sh_gu"].w_q), ops.ptr(W["sh_gu"].w_s)
+                    d.sh_dn, d.sh_dn_s = ops.ptr(W["sh_dn"].w_q), ops.ptr(W["sh_dn"].w_s)
+                plan = B.plan
+                d.perm, d.sorted_bucket = ops.ptr(plan.perm[l]), ops.ptr(plan.sorted_bucket[l])
+                d.expert_offsets, d.tok_slots = ops.ptr(plan.expert_offsets[l]), ops.ptr(plan.tok_slots[l])
+            else:
+                d.num_experts, d.expert_inter, d.mlp_inter = 0, 0, cfg.intermediate_size
+                d.sh_inter, d.sh_out = ops.ptr(B.d_inter), ops.ptr(B.d_out)
+                d.sh_gu, d.sh_gu_s = ops.ptr(W["gu"].w_q), ops.ptr(W["gu"].w_s)
+                d.sh_dn, d.sh_dn_s = ops.ptr(W["dn"].w_q), ops.ptr(W["dn"].w_s)
+            if l + 1 < L:
+                Wn = self.layers[l + 1]
+                d.qkv_w, d.qkv_s = ops.ptr(Wn["qkv"].w_q), ops.ptr(Wn["qkv"].w_s)
+                d.q_norm, d.k_norm, d.rope_tab, d.qk_eps = ops.ptr(Wn["q_norm"]), ops.ptr(Wn["k_norm"]), ops.ptr(self.rope), 1e-6
+                d.positions, d.slot_ids, d.block_table = ops.ptr(positions), ops.ptr(slot_ids), ops.ptr(kvc.block_table)
+                d.max_blocks_per_seq, d.kv_dtype = kvc.block_table.shape[1], ops.KV_DTYPE_CODE[kvc.k[l + 1].dtype]
+                d.num_heads, d.num_kv_heads, d.head_dim, d.block_size = cfg.num_heads, cfg.num_kv_heads, cfg.head_dim, kvc.k[l + 1].shape[1]
+                d.q_out, d.k_cache, d.v_cache = ops.ptr(B.q), ops.ptr(kvc.k[l + 1]), ops.ptr(kvc.v[l + 1])
+            tails.append(ops.DecodeTail(d, self.device, keep=(positions, slot_ids, kvc.block_table)))
+        B.tails[key] = tails
+        return tails
 
     def _linear(self, x, pl: PackedLinear, slot: int, xa, xs, out, epilogue=ops.EPI_STORE, stats_slot: Optional[int] = None):
         """One dense dynamic-int8 Linear call: quantize with the call's statistics, int8 GEMM, fp32 rescale."""
@@ -253,8 +328,23 @@ class I64MoEModel:
             B.attn_ws = ops.attn_workspace(n, cfg.num_heads, cfg.head_dim, splits, self.device)
             B.attn_splits = splits
         ops.fused_residual_norm(B.h, self.layers[0]["ln1"], eps, h_out=B.h, normed=B.normed, slot_base=0, stats=st)
+        tails = None
+        if fuse_rows and record is None and inject is None and self._tail_supported(n):
+            tails = self._tails(B, kvc, positions, slot_ids)
         for l, W in enumerate(self.layers):
             base = l * spl
+            if tails is not None:
+                if l == 0:
+                    ops.gemm_i8_qkv_rope_kv(ops.gemm_desc(B.normed, W["qkv"].w_q, W["qkv"].w_s, B.qkv, a_slot_base=0, stats=st),
+                                            W["q_norm"], W["k_norm"], 1e-6, self.rope, positions, slot_ids, kvc.block_table, kvc.k[0], kvc.v[0],
+                                            B.q, cfg.num_heads, cfg.num_kv_heads, cfg.head_dim)
+                ops.paged_attn(B.q, kvc.k[l], kvc.v[l], kvc.block_table, ctx_len, slot_ids=None if rows_are_slots else slot_ids,
+                               softmax_scale=1.0 / math.sqrt(cfg.head_dim), splits=splits, out=B.attn, workspace=B.attn_ws,
+                               stats=st if splits > 1 else None, stat_slot=base + 1)
+                if splits == 1:
+                    ops.rows_minmax(B.attn.view(n, H), st, slot_base=base + 1)
+                tails[l].run()  # o projection ... combine + next norm (+ the next layer's qkv projection, RoPE, cache write)
+                continue
             if inject is not None and l in inject:
                 B.h.copy_(inject[l])
                 ops.stats_reset(ops.stats_view(st, base))

@@ -270,6 +270,26 @@ def gemm_w8a32_swiglu(x, gate_w, gate_s, up_w, up_s) -> torch.Tensor:
     return out
 
 
+# ---- decode-sized steps: the launches between two attention calls as one persistent launch ----------------------------------
+def decode_sync_alloc(device) -> torch.Tensor:
+    """Barrier words of i64h_decode_tail_run (zeroed once; every launch leaves them zero; word 1 = sticky error flag)."""
+    return torch.zeros(_lib.load().i64h_decode_sync_words(), dtype=torch.int32, device=device)
+
+
+class DecodeTail:
+    """One prepared i64h_decode_tail (see include/i64h.h): prepare once (synchronous), run() per step (one launch)."""
+
+    def __init__(self, desc: "_lib.DecodeTail", device, keep=()):
+        lib = _lib.load()
+        self.desc, self.keep = desc, keep  # keep: tensors whose addresses the description holds
+        self.args = torch.empty(lib.i64h_decode_tail_args_bytes(), dtype=torch.uint8, device=device)
+        self.launch = (ctypes.c_int32 * 2)()
+        call("i64h_decode_tail_prepare", ctypes.addressof(desc), ptr(self.args), ctypes.addressof(self.launch))
+
+    def run(self):
+        call("i64h_decode_tail_run", ptr(self.args), ctypes.addressof(self.launch), _stream())
+
+
 # ---- row kernels ------------------------------------------------------------------------------------------------
 def embedding(ids: torch.Tensor, table: torch.Tensor, out: Optional[torch.Tensor] = None, reset_stats: Optional[torch.Tensor] = None) -> torch.Tensor:
     """reset_stats: stat slots to reset in the same launch (the start of a forward)."""
