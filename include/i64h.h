@@ -295,6 +295,27 @@ int i64h_softmax_q7(const float* logits, float* out, int64_t rows, int32_t D, co
 /* silu_multiply_integer (vllm_i64/layers/integer_activations.py:53-66), table of 2049 entries supplied by the host. */
 int i64h_silu_mul_q7(const float* gate, const float* up, float* out, int64_t total, const int32_t* silu_lut_2049, void* stream);
 
+/* silu_integer / sigmoid_integer / softplus_integer (vllm_i64/layers/integer_activations.py:38-50, 87-99, 120-133): Q7 int32 in,
+ * Q7 int32 out through the function's 2049-entry table (index = clamp(x, -1024, 1024) + 1024, supplied by the host, built with the
+ * reference's formula); beyond +-8.0: mode 0 SiLU -> x / 0, mode 1 sigmoid -> 128 / 0, mode 2 softplus -> x / 0. */
+int i64h_act_q7(const int32_t* x_q7, int32_t* out, int64_t total, const int32_t* lut_2049, int32_t mode, void* stream);
+/* RMSNorm._forward_integer (vllm_i64/layers/rmsnorm.py:89-103): float rsqrt(mean(x^2) + eps), Q7 normalised values times the
+ * Q12 int16 weights of quantize_rmsnorm (106-110) in int32, back to float by / (128 * 4096). */
+int i64h_rmsnorm_q7q12(const float* x, const int16_t* weight_q12, float eps, float* out, int64_t rows, int32_t H, void* stream);
+/* Attention variants of the layer library over the paged cache (fp32 / fp16 / bf16): row r sees keys [ctx_start[r], ctx_end[r])
+ * of the ctx_total[r] keys its sequence holds (ctx_start NULL: 0; ctx_total NULL: ctx_end; max_total = the largest ctx_total).
+ * integer_softmax 0: float softmax over the visible keys - the sliding_window option of naive_varlen_attention /
+ * naive_cached_attention (vllm_i64/layers/attention.py:172-178, 236-239).  integer_softmax 1: naive_integer_varlen_attention /
+ * naive_integer_cached_attention / naive_integer_paged_decode_attention (attention.py:265-466): float scores, -1e4 added to
+ * masked keys, softmax_integer (vllm_i64/layers/moe.py:52-82, table supplied by the host) over ALL ctx_total keys, float V
+ * product - masked keys keep the table's smallest weight, as they do in the reference.  A plain row-per-workgroup kernel: these
+ * variants are not on the registered models' path. */
+int i64h_paged_attn_variant(const float* q, const void* k_cache, const void* v_cache, int32_t kv_dtype, const int32_t* block_table,
+                            int32_t max_blocks_per_seq, const int32_t* slot_ids, const int32_t* ctx_end, const int32_t* ctx_start,
+                            const int32_t* ctx_total, int32_t max_total, float softmax_scale, float* out, int64_t rows, int32_t num_heads,
+                            int32_t num_kv_heads, int32_t head_dim, int32_t block_size, int32_t integer_softmax, const int32_t* exp_lut_1025,
+                            void* stream);
+
 /* Greedy sampling glue of one engine step: out[r] = first index of max(x[r, :D]) (argmax sampling,
  * vllm_i64/core/sampling.py:435-436); positions[i] += 1, ctx_len[i] += 1 (what scheduler.update_after_step does to a
  * decoding sequence, vllm_i64/engine/i64_scheduler.py:505-546). */

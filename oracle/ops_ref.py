@@ -166,3 +166,61 @@ def fp8_linear_scaled_mm(x: torch.Tensor, w_fp8: torch.Tensor, w_scale: torch.Te
 def fp8_linear_dequant(x: torch.Tensor, w_fp8: torch.Tensor, w_scale: torch.Tensor) -> torch.Tensor:
     """The branch the reference takes wherever its SM89 gate is closed (fp8.py:163-167): weights dequantized, fp32 GEMM."""
     return torch.nn.functional.linear(x.float(), w_fp8.float() * w_scale.unsqueeze(-1))
+
+
+# ---- integer activations, the rest of layers/integer_activations.py (38-50, 87-99, 120-133) ---------------------------------
+def _act_lut(kind: str) -> torch.Tensor:
+    x = torch.arange(-1024, 1025, dtype=torch.float32) / 128.0
+    f = {"silu": F.silu, "sigmoid": torch.sigmoid, "softplus": F.softplus}[kind]
+    return torch.round(f(x) * 128.0).to(torch.int32)
+
+
+def _act_q7(x_q7: torch.Tensor, kind: str) -> torch.Tensor:
+    r = _act_lut(kind)[(x_q7.clamp(-1024, 1024) + 1024).long()].to(x_q7.dtype)
+    hi = torch.full_like(r, 128) if kind == "sigmoid" else x_q7
+    r = torch.where(x_q7 > 1024, hi, r)
+    return torch.where(x_q7 < -1024, torch.zeros_like(r), r)
+
+
+def silu_integer(x_q7):
+    return _act_q7(x_q7, "silu")
+
+
+def sigmoid_integer(x_q7):
+    return _act_q7(x_q7, "sigmoid")
+
+
+def softplus_integer(x_q7):
+    return _act_q7(x_q7, "softplus")
+
+
+# ---- integer RMSNorm (layers/rmsnorm.py:89-110) ----------------------------------------------------------------------------
+def quantize_rmsnorm_weight(w: torch.Tensor) -> torch.Tensor:
+    return (w.float() * 4096.0).round().clamp(-32768, 32767).to(torch.int16)
+
+
+def rmsnorm_integer(x: torch.Tensor, weight_q12: torch.Tensor, eps: float) -> torch.Tensor:
+    norm = x.float().pow(2).mean(-1, keepdim=True).add(eps).rsqrt()
+    xn_q7 = (x.float() * norm * 128.0).round().to(torch.int32)
+    return (xn_q7 * weight_q12.to(torch.int32)).float() / float(128 * 4096)
+
+
+# ---- attention variants (layers/attention.py:123-245 sliding_window; 265-466 integer softmax) ------------------------------
+def _expand(t, groups):
+    return t.repeat_interleave(groups, dim=1) if groups > 1 else t
+
+
+def attention_masked(q, k, v, groups, q_pos, scale, sliding_window=None, integer=False):
+    """One sequence: q [n, heads, hd] at positions q_pos [n] against keys k / v [T, kv_heads, hd] at positions 0..T-1.
+    Float: -inf masks + softmax.  Integer: -1e4 masks + softmax_integer over all T keys (attention.py:311-334, 380-398)."""
+    kt, vt = _expand(k.float(), groups).transpose(0, 1), _expand(v.float(), groups).transpose(0, 1)
+    s = torch.bmm(q.float().transpose(0, 1), kt.transpose(1, 2)) * scale
+    T = k.shape[0]
+    qp, kp = q_pos.view(-1, 1).float(), torch.arange(T, dtype=torch.float32).view(1, -1)
+    neg = -1e4 if integer else float("-inf")
+    mask = torch.where(kp <= qp, 0.0, neg)
+    if sliding_window is not None:
+        mask = mask + torch.where(qp - kp < sliding_window, 0.0, neg)
+    s = s + mask.unsqueeze(0)
+    p = softmax_integer(s) if integer else torch.softmax(s, dim=-1)
+    return torch.bmm(p, vt).transpose(0, 1)

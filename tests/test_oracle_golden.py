@@ -201,3 +201,26 @@ def test_oracle_fp8_ops_match_reference_fixtures(golden_dir):
     y = O.fp8_linear_scaled_mm(x, wq, torch.from_numpy(z["fp8_ws"])).numpy()
     ref = z["fp8_y_dequant"]
     assert np.linalg.norm(y - ref) <= 0.05 * np.linalg.norm(ref)
+
+
+def test_variant_ops_oracle_against_reference_vectors(golden_dir):
+    """ops2.npz (integer activations, integer RMSNorm, sliding-window and integer-softmax attention): the oracle reproduces the
+    reference's captured outputs exactly."""
+    z = np.load(os.path.join(golden_dir, "ops2.npz"))
+    x = torch.from_numpy(z["act_x"])
+    assert np.array_equal(O.silu_integer(x).numpy(), z["act_silu"]) and np.array_equal(O.sigmoid_integer(x).numpy(), z["act_sigmoid"])
+    assert np.array_equal(O.softplus_integer(x).numpy(), z["act_softplus"])
+    w = torch.from_numpy(z["rmsq_w"])
+    assert np.array_equal(O.rmsnorm_integer(torch.from_numpy(z["rmsq_x"]), w, 1e-6).numpy(), z["rmsq_y"])
+    assert np.array_equal(O.rmsnorm_integer(torch.from_numpy(z["rmsq_xe"]), w, 1e-6).numpy(), z["rmsq_ye"])
+    q, k, v = (torch.from_numpy(z[n]) for n in ("at_q", "at_k", "at_v"))
+    lens = [int(t) for t in z["at_lens"]]
+    for tag, integer in (("f", False), ("i", True)):
+        for W in (None, 5):
+            off, parts = 0, []
+            for m in lens:
+                parts.append(O.attention_masked(q[off:off + m], k[off:off + m], v[off:off + m], 2, torch.arange(m), 0.25, W, integer))
+                off += m
+            assert np.array_equal(torch.cat(parts).numpy(), z[f"at_varlen_{tag}_{W}"])
+            y = O.attention_masked(q[:5], k[:19], v[:19], 2, torch.from_numpy(z["at_cached_pos"]), 0.25, W, integer)
+            assert np.array_equal(y.numpy(), z[f"at_cached_{tag}_{W}"])

@@ -47,6 +47,9 @@ SIGNATURES: Dict[str, str] = {
     "i64h_rope_q14": "ppppliip",
     "i64h_softmax_q7": "pplipp",
     "i64h_silu_mul_q7": "ppplpp",
+    "i64h_act_q7": "pplpip",
+    "i64h_rmsnorm_q7q12": "ppfplip",
+    "i64h_paged_attn_variant": "pppipippppifpliiiiipp",
     "i64h_argmax_rows": "pplip",
     "i64h_argmax_rows_advance": "pplippp",
     "i64h_advance": "pplp",
@@ -157,6 +160,10 @@ def ptr(t) -> int:
     if t is None:
         return 0
     if hasattr(t, "data_ptr"):
+        # every tensor argument of the C ABI is device memory (host arrays go in as ctypes buffers): a host tensor's address
+        # handed to a kernel is a GPU memory fault, so it is refused here
+        if not getattr(t, "is_cuda", False):
+            raise I64HError("expected a GPU tensor, got one on " + str(getattr(t, "device", "the host")))
         return t.data_ptr()
     return ctypes.addressof(t)
 

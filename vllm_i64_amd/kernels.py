@@ -38,6 +38,51 @@ def _silu_lut(device) -> torch.Tensor:
     return _LUTS[key]
 
 
+def _act_lut(kind: str, device) -> torch.Tensor:
+    """2049-entry tables round(f(i/128) * 128), f = silu / sigmoid / softplus (layers/integer_activations.py:29-35, 78-84,
+    111-117), built on the host with the reference's formulas and uploaded once per device."""
+    key = (kind, str(device))
+    if key not in _LUTS:
+        x = torch.arange(-1024, 1025, dtype=torch.float32) / 128.0
+        f = {"silu": torch.nn.functional.silu, "sigmoid": torch.sigmoid, "softplus": torch.nn.functional.softplus}[kind]
+        _LUTS[key] = torch.round(f(x) * 128.0).to(torch.int32).to(device)
+    return _LUTS[key]
+
+
+def _act_q7(x_q7: torch.Tensor, kind: str) -> torch.Tensor:
+    mode = {"silu": 0, "sigmoid": 1, "softplus": 2}[kind]
+    xi = x_q7.to(torch.int32).contiguous()
+    out = torch.empty_like(xi)
+    ops.call("i64h_act_q7", ops.ptr(xi), ops.ptr(out), xi.numel(), ops.ptr(_act_lut(kind, xi.device)), mode, ops._stream())
+    return out.to(x_q7.dtype) if x_q7.dtype in (torch.int64, torch.int16) else out
+
+
+def silu_integer(x_q7: torch.Tensor) -> torch.Tensor:
+    """Fixed-point SiLU, Q7 in / Q7 out (layers/integer_activations.py:38-50)."""
+    return _act_q7(x_q7, "silu")
+
+
+def sigmoid_integer(x_q7: torch.Tensor) -> torch.Tensor:
+    """Fixed-point sigmoid, Q7 in / Q7 out in [0, 128] (layers/integer_activations.py:87-99)."""
+    return _act_q7(x_q7, "sigmoid")
+
+
+def softplus_integer(x_q7: torch.Tensor) -> torch.Tensor:
+    """Fixed-point softplus, Q7 in / Q7 out (layers/integer_activations.py:120-133)."""
+    return _act_q7(x_q7, "softplus")
+
+
+def rmsnorm_integer(x: torch.Tensor, weight_q12: torch.Tensor, eps: float) -> torch.Tensor:
+    """RMSNorm._forward_integer (layers/rmsnorm.py:89-103): Q7 normalised values x Q12 int16 weights in int32."""
+    shape = x.shape
+    x2 = _f32(x.reshape(-1, shape[-1]))
+    out = torch.empty_like(x2)
+    wq = weight_q12.to(device=x2.device, dtype=torch.int16).contiguous()
+    assert wq.numel() == x2.shape[1], "weight_q12 must have one entry per feature"
+    ops.call("i64h_rmsnorm_q7q12", ops.ptr(x2), ops.ptr(wq), float(eps), ops.ptr(out), x2.shape[0], x2.shape[1], ops._stream())
+    return out.reshape(shape).to(x.dtype)
+
+
 def _f32(t: torch.Tensor) -> torch.Tensor:
     return t.to(torch.float32).contiguous()
 

@@ -16,7 +16,7 @@ import torch
 
 from . import ops
 from .config import ModelConfig
-from .kernels import I64Ops
+from .kernels import I64Ops, _exp_lut, rmsnorm_integer, sigmoid_integer, silu_integer, softplus_integer  # noqa: F401
 
 
 def naive_paged_decode_attention(q, k_cache, v_cache, block_table, cache_seqlens, num_kv_groups: int = 1,
@@ -30,8 +30,32 @@ def naive_paged_decode_attention(q, k_cache, v_cache, block_table, cache_seqlens
                           cache_seqlens.to(torch.int32).contiguous(), softmax_scale=softmax_scale, splits=splits).to(q.dtype)
 
 
-def _attend_packed(q, k, v, seq_of_row, ctx_of_row, lens: List[int], softmax_scale):
-    """Place contiguous per-sequence K/V into a scratch paged cache and run the paged kernel."""
+def _variant(q, k_cache, v_cache, block_table, ctx_end, ctx_start, ctx_total, slot_ids, softmax_scale, integer: bool):
+    """i64h_paged_attn_variant: sliding window and / or integer softmax over a paged cache."""
+    rows, nh, hd = q.shape
+    _, block, kvh, _ = k_cache.shape
+    if softmax_scale is None:
+        softmax_scale = 1.0 / math.sqrt(hd)
+    dev = q.device
+    i32 = lambda t: None if t is None else t.to(device=dev, dtype=torch.int32).contiguous()
+    ctx_end, ctx_start, ctx_total, slot_ids = i32(ctx_end), i32(ctx_start), i32(ctx_total), i32(slot_ids)
+    max_total = int((ctx_total if ctx_total is not None else ctx_end).max().item()) if rows else 0
+    qf = q.float().contiguous()
+    out = torch.empty_like(qf)
+    block_table = block_table.to(device=dev, dtype=torch.int32).contiguous()
+    k_cache, v_cache = k_cache.to(dev).contiguous(), v_cache.to(dev).contiguous()
+    assert k_cache.shape == v_cache.shape and k_cache.shape[3] == hd and nh % kvh == 0
+    assert max_total <= block_table.shape[1] * block, "a row's keys must lie inside its block-table row"
+    ops.call("i64h_paged_attn_variant", ops.ptr(qf), ops.ptr(k_cache), ops.ptr(v_cache), ops.KV_DTYPE_CODE[k_cache.dtype],
+             ops.ptr(block_table), block_table.shape[1], ops.ptr(slot_ids), ops.ptr(ctx_end), ops.ptr(ctx_start), ops.ptr(ctx_total), max_total,
+             float(softmax_scale), ops.ptr(out), rows, nh, kvh, hd, block, int(integer), ops.ptr(_exp_lut(dev) if integer else None),
+             ops._stream())
+    return out.to(q.dtype)
+
+
+def _attend_packed(q, k, v, seq_of_row, ctx_of_row, lens: List[int], softmax_scale, ctx_start=None, integer: bool = False):
+    """Place contiguous per-sequence K/V into a scratch paged cache and run the paged kernel (the variant kernel for a sliding
+    window or the integer softmax: ctx_start = first visible key per row; integer: every key of the row's sequence takes part)."""
     dev, block = q.device, 16
     kvh, hd = k.shape[1], k.shape[2]
     nblk = [(n + block - 1) // block for n in lens]
@@ -45,35 +69,79 @@ def _attend_packed(q, k, v, seq_of_row, ctx_of_row, lens: List[int], softmax_sca
         vc.view(-1, kvh, hd)[b0 * block: b0 * block + n] = v[off:off + n].float()
         off += n
         b0 += nblk[s]
+    if ctx_start is not None or integer:
+        total = torch.tensor(lens, dtype=torch.int32)[seq_of_row.long()] if integer else None
+        return _variant(q, kc, vc, bt.to(dev), ctx_of_row, ctx_start, total, seq_of_row, softmax_scale, integer)
     return ops.paged_attn(q.float().contiguous(), kc, vc, bt.to(dev), ctx_of_row.to(torch.int32).to(dev).contiguous(),
                           slot_ids=seq_of_row.to(torch.int32).to(dev).contiguous(), softmax_scale=softmax_scale).to(q.dtype)
 
 
+def _window_start(ctx: torch.Tensor, sliding_window: Optional[int]):
+    """First visible key of a row that sees keys up to ctx - 1: the window keeps q_pos - k_pos < window (attention.py:172-178,
+    236-239), i.e. k_pos >= ctx - window."""
+    return None if sliding_window is None else torch.clamp(ctx - int(sliding_window), min=0)
+
+
 def naive_varlen_attention(q, k, v, tokens_per_seq: List[int], num_kv_groups: int, softmax_scale: Optional[float] = None,
                            sliding_window: Optional[int] = None) -> torch.Tensor:
-    if sliding_window is not None:
-        raise NotImplementedError("sliding_window is not on the registered models' path")
     lens = [int(n) for n in tokens_per_seq]
     seq = torch.cat([torch.full((n,), s, dtype=torch.int32) for s, n in enumerate(lens)])
     ctx = torch.cat([torch.arange(1, n + 1, dtype=torch.int32) for n in lens])
-    return _attend_packed(q, k, v, seq, ctx, lens, softmax_scale)
+    return _attend_packed(q, k, v, seq, ctx, lens, softmax_scale, ctx_start=_window_start(ctx, sliding_window))
 
 
 def naive_cached_attention(q, k_full, v_full, num_kv_groups: int, positions, softmax_scale: Optional[float] = None,
                            sliding_window: Optional[int] = None) -> torch.Tensor:
-    if sliding_window is not None:
-        raise NotImplementedError("sliding_window is not on the registered models' path")
     n, T = q.shape[0], k_full.shape[0]
     ctx = torch.clamp(positions.to(torch.int32).cpu() + 1, max=T)
-    return _attend_packed(q, k_full, v_full, torch.zeros(n, dtype=torch.int32), ctx, [T], softmax_scale)
+    start = None if sliding_window is None else torch.clamp(positions.to(torch.int32).cpu() + 1 - int(sliding_window), min=0)
+    return _attend_packed(q, k_full, v_full, torch.zeros(n, dtype=torch.int32), ctx, [T], softmax_scale, ctx_start=start)
+
+
+def naive_integer_varlen_attention(q, k, v, tokens_per_seq: List[int], num_kv_groups: int, softmax_scale: Optional[float] = None,
+                                   sliding_window: Optional[int] = None) -> torch.Tensor:
+    """Float scores, softmax_integer over every key of the sequence (masked keys carry -1e4), float V product
+    (attention.py:265-339)."""
+    lens = [int(n) for n in tokens_per_seq]
+    seq = torch.cat([torch.full((n,), s, dtype=torch.int32) for s, n in enumerate(lens)])
+    ctx = torch.cat([torch.arange(1, n + 1, dtype=torch.int32) for n in lens])
+    start = _window_start(ctx, sliding_window)
+    return _attend_packed(q, k, v, seq, ctx, lens, softmax_scale, ctx_start=start if start is not None else torch.zeros_like(ctx), integer=True)
+
+
+def naive_integer_cached_attention(q, k_full, v_full, num_kv_groups: int, positions, softmax_scale: Optional[float] = None,
+                                   sliding_window: Optional[int] = None) -> torch.Tensor:
+    """attention.py:342-399."""
+    n, T = q.shape[0], k_full.shape[0]
+    pos = positions.to(torch.int32).cpu()
+    ctx = torch.clamp(pos + 1, max=T)
+    start = torch.zeros_like(ctx) if sliding_window is None else torch.clamp(pos + 1 - int(sliding_window), min=0)
+    return _attend_packed(q, k_full, v_full, torch.zeros(n, dtype=torch.int32), ctx, [T], softmax_scale, ctx_start=start, integer=True)
+
+
+def naive_integer_paged_decode_attention(q, k_cache, v_cache, block_table, cache_seqlens, num_kv_groups: int = 1,
+                                         softmax_scale: Optional[float] = None) -> torch.Tensor:
+    """attention.py:402-466: no mask, softmax_integer over the sequence's cached keys; zero-length sequences give zero rows."""
+    assert q.shape[1] == k_cache.shape[2] * num_kv_groups
+    return _variant(q, k_cache, v_cache, block_table.to(torch.int32).contiguous(), cache_seqlens, None, None, None, softmax_scale, True)
 
 
 class RMSNorm:
+    """layers/rmsnorm.py:23-103.  quantize() is quantize_rmsnorm (106-110): with weight_q12 present the forward is the integer
+    path (_forward_integer: Q7 normalised values x Q12 weights)."""
+
     def __init__(self, weight: torch.Tensor, eps: float = 1e-6):
         self.weight, self.eps = weight.float().contiguous(), eps
+        self.weight_q12: Optional[torch.Tensor] = None
+
+    def quantize(self) -> "RMSNorm":
+        self.weight_q12 = (self.weight * 4096.0).round().clamp(-32768, 32767).to(torch.int16)
+        return self
 
     def forward(self, x):
         shape = x.shape
+        if self.weight_q12 is not None:
+            return rmsnorm_integer(x, self.weight_q12, self.eps)
         return I64Ops.rmsnorm_forward(x.reshape(-1, shape[-1]), self.weight, self.eps).reshape(shape).to(x.dtype)
 
     __call__ = forward
