@@ -350,9 +350,13 @@ def moe_forward(cfg: SynthConfig, bank: LinearBank, l: int, x: torch.Tensor, tok
             inter = silu_mul(gu)
             r[m] = bank(p + "exp_down", inter, idx=e, tag=f"{p}dn.k{k}.e{e}")
         out = w[k] * r if out is None else out + w[k] * r
+    # learned scalar gates (use_shared_routed_gates, token_routed_mlp.py:84-90,174-178) replace the configured scales when the
+    # weights carry them; shared_gate * shared + routed_gate * routed is the same fp32 sum in the other order
+    rs = float(bank.w[p + "routed_gate"]) if p + "routed_gate" in bank.w else cfg.routed_scale
+    ss = float(bank.w[p + "shared_gate"]) if p + "shared_gate" in bank.w else cfg.shared_scale
     if cfg.shared_intermediate_size:
         sh = bank(p + "sh_down", silu_mul(bank(p + "sh_gate_up", x, tag=f"{p}shgu")), tag=f"{p}shdn")
-        out = cfg.routed_scale * out + cfg.shared_scale * sh
+        out = rs * out + ss * sh
     else:
         out = cfg.routed_scale * out
     return out

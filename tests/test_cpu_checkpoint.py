@@ -99,3 +99,27 @@ def test_packed_file_holds_the_observer_quantization(tmp_path, golden_dir):
             assert float(p.w_s[g]) == float(ws) and np.array_equal(p.w_q[g].numpy(), np.asarray(wq, dtype=np.int8))
     with pytest.raises(ValueError, match="not a"):
         C.load_packed(os.path.join(golden_dir, "ckpt_tiny", "model.safetensors"))
+
+
+def test_learned_output_gates_round_trip_and_oracle(golden_dir):
+    """shared_output_gate / routed_output_gate in a native state dict are kept per layer (not rejected, not dropped), survive
+    the round trip, and the oracle with them reproduces the reference module's captured output."""
+    import numpy as np
+    from oracle import model_ref as M
+    from vllm_i64_amd import checkpoint as C
+    from vllm_i64_amd.config import ModelConfig
+    ocfg = M.named_config("tiny-moe")
+    cfg = ModelConfig.from_any(ocfg)
+    w = dict(M.make_weights(ocfg, seed=0))
+    w["l1.shared_gate"], w["l1.routed_gate"] = torch.tensor(0.8), torch.tensor(1.3)
+    sd = C.weights_to_native(w, cfg)
+    assert "model.layers.1.mlp.shared_output_gate" in sd or "layers.1.mlp.shared_output_gate" in sd
+    back = C.native_to_weights(sd, cfg)
+    assert float(back["l1.shared_gate"]) == float(torch.tensor(0.8)) and float(back["l1.routed_gate"]) == float(torch.tensor(1.3))
+    assert "l0.shared_gate" not in back
+    z = np.load(os.path.join(golden_dir, "ops2.npz"))
+    y = M.moe_forward(ocfg, M.LinearBank(back, "int8"), 1, torch.from_numpy(z["gate_x"]), torch.from_numpy(z["gate_ids"]))
+    assert np.array_equal(y.numpy(), z["gate_y"])
+    broken = {k: v for k, v in sd.items() if not k.endswith("routed_output_gate")}
+    with pytest.raises(KeyError, match="go together"):
+        C.native_to_weights(broken, cfg)

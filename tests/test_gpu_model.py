@@ -345,3 +345,62 @@ def test_model_shape_sweep_against_oracle(dev):
         diffs += d
     assert max(diffs) <= 2e-2
     assert sum(v > 2e-5 for v in diffs) <= len(diffs) // 4
+
+
+def test_decode_across_a_block_boundary_without_reserve(dev):
+    """Prompts that end right at / just before a 16-token block boundary, no reserve_extra: every decode step reserves the
+    block its token lands in (a missing block would silently drop the K/V write and give logits without the new token)."""
+    from vllm_i64_amd.model import GreedyDecoder
+    ocfg, w, model = _model("tiny-moe", dev)
+    for s in range(2):
+        model.kv.free(s)
+    ids = M.make_token_ids(ocfg, 31, seed=21)
+    prompts = [ids[:16], ids[16:31]]
+    eng = M.OracleEngine(ocfg, w, mode="int8", max_seqs=2, num_blocks=64)
+    ref = [eng.prefill(prompts).numpy()]
+    dec = GreedyDecoder(model, 2, use_graph=False)
+    out = [dec.prefill(prompts, reserve_extra=0).cpu().numpy()]
+    for _ in range(3):
+        tok = torch.from_numpy(ref[-1].argmax(-1))
+        ref.append(eng.decode(tok).numpy())
+        dec.tokens.copy_(tok)
+        out.append(dec.step().cpu().numpy())
+    d = [float(np.abs(a - b).max()) for a, b in zip(out, ref)]
+    assert max(d) <= 2e-2, d
+    assert model.kv._owned[0] == 2 and model.kv._owned[1] == 2
+
+
+def test_positions_beyond_the_tables_are_refused(dev):
+    """The kernels index the rotary table by position and the block table by position / block without bounds; the host
+    refuses such a step instead of reading another sequence's table row."""
+    import dataclasses
+    from vllm_i64_amd.config import ModelConfig
+    from vllm_i64_amd.engine_adapter import EngineModel
+    from vllm_i64_amd.model import GreedyDecoder, I64MoEModel
+    ocfg = dataclasses.replace(M.named_config("tiny-moe"), max_pos=48)
+    w = M.make_weights(ocfg, seed=0)
+    model = I64MoEModel(ModelConfig.from_any(ocfg), w, device=dev, max_seqs=2, num_kv_blocks=16)
+    em = EngineModel(model)
+    cache = _EngineLikeCache(model.cfg, 16, 2, dev)
+    ids = M.make_token_ids(ocfg, 4, seed=2)
+    with pytest.raises(ValueError, match="max_pos"):
+        em(ids[:1], torch.tensor([48]), cache, [0], [1])
+    small = _EngineLikeCache(model.cfg, 16, 2, dev)
+    small.block_table = small.block_table[:, :2].contiguous()     # two blocks per sequence: positions up to 31
+    with pytest.raises(ValueError, match="block"):
+        em(ids[:1], torch.tensor([40]), small, [0], [1])
+    em(ids[:1], torch.tensor([31]), small, [0], [1])              # the last position the table reaches is fine
+    dec = GreedyDecoder(model, 2, use_graph=False)
+    dec.set_state(ids[:2].to(dev), [46, 47])
+    dec.step()                                                    # positions 46 and 47: the last ones
+    with pytest.raises(RuntimeError, match="max_pos"):
+        dec.step()
+
+
+def test_engine_model_refuses_a_prefix_caching_cache(dev):
+    from vllm_i64_amd.engine_adapter import EngineModel
+    ocfg, w, model = _model("tiny-moe", dev)
+    cache = _EngineLikeCache(model.cfg, 16, 2, dev)
+    cache.prefix_cache_enabled = lambda: True
+    with pytest.raises(RuntimeError, match="copy-on-write"):
+        EngineModel(model)(M.make_token_ids(ocfg, 3, seed=1), torch.arange(3), cache, [0], [3])

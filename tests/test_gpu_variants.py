@@ -76,3 +76,28 @@ def test_integer_paged_decode_attention(dev, z):
     out = L.naive_integer_paged_decode_attention(d("pdi_q"), d("pdi_k"), d("pdi_v"), d("pdi_bt"), d("pdi_sl"), num_kv_groups=2).cpu().numpy()
     assert not out[2].any()
     assert np.abs(out - z["pdi_out"]).max() <= 2e-3 and np.abs(out - z["pdi_out"]).mean() <= 2e-5
+
+
+def test_moe_layer_with_learned_output_gates(dev, z):
+    """use_shared_routed_gates (token_routed_mlp.py:84-90,174-178): shared_gate * shared + routed_gate * routed, against the
+    reference module's captured int8 output; through the layer object and through the model runner's layer call."""
+    from oracle import model_ref as M
+    from vllm_i64_amd.config import ModelConfig
+    from vllm_i64_amd.layers import TokenRoutedMLPInt8
+    from vllm_i64_amd.model import I64MoEModel
+    ocfg = M.named_config("tiny-moe")
+    w = dict(M.make_weights(ocfg, seed=0))
+    x, ids = torch.from_numpy(z["gate_x"]).to(dev), torch.from_numpy(z["gate_ids"]).to(dev)
+    layer = TokenRoutedMLPInt8(ModelConfig.from_any(ocfg), {"exp_gate_up": w["l1.exp_gate_up"], "exp_down": w["l1.exp_down"],
+                                                           "sh_gate_up": w["l1.sh_gate_up"], "sh_down": w["l1.sh_down"],
+                                                           "table": w["l1.table"], "shared_gate": torch.tensor(0.8),
+                                                           "routed_gate": torch.tensor(1.3)}, device=dev)
+    y = layer(x, ids).cpu().numpy()
+    assert np.abs(y - z["gate_y"]).max() <= 1e-2 and np.abs(y - z["gate_y"]).mean() <= 1e-5
+    w["l1.shared_gate"], w["l1.routed_gate"] = torch.tensor(0.8), torch.tensor(1.3)
+    model = I64MoEModel(ModelConfig.from_any(ocfg), w, device=dev, max_seqs=2, num_kv_blocks=8)
+    y2 = model.moe_layer(1, x, ids).cpu().numpy()
+    assert np.abs(y2 - z["gate_y"]).max() <= 1e-2 and np.abs(y2 - z["gate_y"]).mean() <= 1e-5
+    # without the gates the configured scales (1.5 / 0.75) apply: a different result
+    y3 = model.moe_layer(0, x, ids).cpu().numpy()
+    assert np.abs(y3 - z["gate_y"]).max() > 1e-2

@@ -163,6 +163,12 @@ def native_to_weights(state: Dict[str, torch.Tensor], cfg: ModelConfig) -> Dict[
             if cfg.shared_intermediate_size:
                 w[q + "sh_gate_up"] = f32(torch.cat([take(m + "shared_gate.weight"), take(m + "shared_up.weight")], dim=0))
                 w[q + "sh_down"] = f32(take(m + "shared_down.weight"))
+                # learned scalar output gates (use_shared_routed_gates, layers/token_routed_mlp.py:84-90,174-178)
+                sg, rg = take(m + "shared_output_gate", optional=True), take(m + "routed_output_gate", optional=True)
+                if (sg is None) != (rg is None):
+                    raise KeyError(f"layer {l}: shared_output_gate and routed_output_gate go together")
+                if sg is not None:
+                    w[q + "shared_gate"], w[q + "routed_gate"] = f32(sg).reshape(()), f32(rg).reshape(())
             table = take(m + "topk_token_to_expert", optional=True)
             primary = take(m + "token_to_expert", optional=True)
             if table is not None:
@@ -211,6 +217,8 @@ def weights_to_native(w: Dict[str, torch.Tensor], cfg: ModelConfig) -> Dict[str,
             if cfg.shared_intermediate_size:
                 S = cfg.shared_intermediate_size
                 sd[m + "shared_gate.weight"], sd[m + "shared_up.weight"] = c(w[q + "sh_gate_up"][:S]), c(w[q + "sh_gate_up"][S:])
+                if q + "shared_gate" in w:
+                    sd[m + "shared_output_gate"], sd[m + "routed_output_gate"] = c(w[q + "shared_gate"]), c(w[q + "routed_gate"])
                 sd[m + "shared_down.weight"] = c(w[q + "sh_down"])
             sd[m + "topk_token_to_expert"] = c(w[q + "table"].long())
             sd[m + "token_to_expert"] = w[q + "table"][0].long().clone()

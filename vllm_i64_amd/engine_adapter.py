@@ -33,14 +33,29 @@ class EngineModel:
         self.config = runner.cfg
 
     def _ensure_blocks(self, kv_cache, seq_ids: Sequence[int], last_pos: Sequence[int]):
+        """Blocks for positions [0, last_pos] of every sequence, through the cache's own allocate_blocks.  What a sequence
+        already owns is read from the cache's bookkeeping (_seq_blocks, kv_cache.py:119,281-285) when it is there: counting
+        the table's non-negative entries would disagree with it as soon as the table has holes (swapped-out blocks)."""
         bt = kv_cache.block_table
         bs = int(kv_cache.block_size)
-        rows = bt[torch.tensor(list(seq_ids), dtype=torch.long, device=bt.device)].cpu()      # one small transfer per step
+        owned = getattr(kv_cache, "_seq_blocks", None)
+        rows = None if owned is not None else bt[torch.tensor(list(seq_ids), dtype=torch.long, device=bt.device)].cpu()
         for i, (sid, lp) in enumerate(zip(seq_ids, last_pos)):
             need = lp // bs + 1
-            have = int((rows[i] >= 0).sum())
+            have = len(owned.get(int(sid), [])) if owned is not None else int((rows[i] >= 0).sum())
             if need > have:
                 kv_cache.allocate_blocks(int(sid), need - have)
+
+    @staticmethod
+    def _check_cache(kv_cache):
+        """The kernels write K/V straight into the blocks the table names.  The reference's write_kv first makes a private copy
+        of a block that the prefix cache shares (_cow_if_shared, kv_cache.py:663-695) and updates the LRU order (_touch,
+        196-199); this adapter does neither, so a cache with prefix caching switched on is refused rather than corrupted."""
+        enabled = getattr(kv_cache, "prefix_cache_enabled", None)
+        if callable(enabled):
+            enabled = enabled()
+        if enabled:
+            raise RuntimeError("EngineModel writes K/V without copy-on-write: run it on a PagedKVCache without prefix caching")
 
     @torch.no_grad()
     def forward(self, token_ids: torch.Tensor, positions: Optional[torch.Tensor] = None, kv_cache=None,
@@ -73,6 +88,15 @@ class EngineModel:
         ends = torch.cumsum(torch.tensor(tps), 0)
         last_pos = [int(pos_h[int(e) - 1 if t > 0 else 0]) if t > 0 else -1 for e, t in zip(ends, tps)]
         max_pos = [int(pos_h[int(e) - t:int(e)].max()) if t > 0 else -1 for e, t in zip(ends, tps)]
+        self._check_cache(kv_cache)
+        # the kernels index the rotary table by position and the block table by position / block without bounds: a position
+        # beyond either would read another sequence's table row and write K/V into its blocks
+        top = max(max_pos) if max_pos else -1
+        if n > 0 and (int(pos_h.min()) < 0 or top >= r.cfg.max_pos):
+            raise ValueError(f"position {top if top >= r.cfg.max_pos else int(pos_h.min())} outside [0, max_pos={r.cfg.max_pos})")
+        if top // int(kv_cache.block_size) >= kv_cache.block_table.shape[1]:
+            raise ValueError(f"position {top} needs block {top // int(kv_cache.block_size)}, the cache's table has "
+                             f"{kv_cache.block_table.shape[1]} per sequence")
         self._ensure_blocks(kv_cache, seq_ids, [max(m, 0) for m in max_pos])
         logits = r.forward(ids, pos, slots, (pos + 1).contiguous(), max_ctx_hint=max(max_pos) + 1 if max_pos else 0,
                            kv=_CacheView(kv_cache))

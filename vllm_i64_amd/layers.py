@@ -193,7 +193,9 @@ class TokenRoutedMLPInt8:
             L.shared_gate_up, L.shared_gate_up_scale = ops.ptr(self.sh_gu.w_q), ops.ptr(self.sh_gu.w_s)
             L.shared_down, L.shared_down_scale = ops.ptr(self.sh_dn.w_q), ops.ptr(self.sh_dn.w_s)
         L.route_weights = ctypes.addressof(self._rw)
-        L.routed_scale, L.shared_scale = cfg.routed_scale, cfg.shared_scale
+        # learned scalar gates of the layer (use_shared_routed_gates) replace the configured output scales
+        L.routed_scale = float(weights["routed_gate"]) if "routed_gate" in weights else cfg.routed_scale
+        L.shared_scale = float(weights["shared_gate"]) if "shared_gate" in weights else cfg.shared_scale
         self._layer = L
         self._ws: Optional[torch.Tensor] = None
 

@@ -187,6 +187,10 @@ class I64MoEModel:
             else:
                 d["gu"] = pack_per_tensor(weights[p + "gate_up"], dev)
                 d["dn"] = pack_per_tensor(weights[p + "down"], dev)
+            # output scales of the MoE combine: the configured ones, or this layer's learned scalar gates
+            # (layers/token_routed_mlp.py:174-183)
+            d["routed_scale"] = float(weights[p + "routed_gate"]) if p + "routed_gate" in weights else cfg.routed_scale
+            d["shared_scale"] = float(weights[p + "shared_gate"]) if p + "shared_gate" in weights else cfg.shared_scale
             self.layers.append(d)
         self.tables = torch.stack(tables).to(dev).contiguous() if tables else None  # [L, top_k, V] int64
         self.rope = rope_table(cfg.max_pos, cfg.head_dim, cfg.rope_theta).to(dev)
@@ -252,7 +256,7 @@ class I64MoEModel:
             if cfg.is_moe:
                 S = cfg.shared_intermediate_size or 0
                 d.num_experts, d.expert_inter, d.mlp_inter = cfg.num_experts, cfg.expert_inter, S
-                d.routed_scale, d.shared_scale = cfg.routed_scale, cfg.shared_scale
+                d.routed_scale, d.shared_scale = W["routed_scale"], W["shared_scale"]
                 for k, wk in enumerate(cfg.route_weights):
                     d.route_weights[k] = float(wk)
                 d.e_inter, d.e_out = ops.ptr(B.e_inter), ops.ptr(B.e_out)
@@ -308,6 +312,11 @@ class I64MoEModel:
         cfg, st = self.cfg, self.stats
         kvc = kv if kv is not None else self.kv
         n = token_ids.numel()
+        if positions.device.type != "cuda" and n:  # host positions: check them (device positions are the caller's contract:
+            # GreedyDecoder and EngineModel bound them on the host)
+            if int(positions.max()) >= cfg.max_pos or int(positions.max()) // kvc.k[0].shape[1] >= kvc.block_table.shape[1]:
+                raise ValueError(f"position {int(positions.max())} outside the rotary table ({cfg.max_pos}) or the block table")
+            positions = positions.to(device=self.device, dtype=torch.int32)
         B = self.buffers(n, logit_rows.numel() if logit_rows is not None else n)
         H, nbk, spl = cfg.hidden_size, self.nb, self.spl
         eps = cfg.rms_eps
@@ -351,7 +360,8 @@ class I64MoEModel:
                 ops.fused_residual_norm(B.h, W["ln1"], eps, h_out=B.h, normed=B.normed, slot_base=base, stats=st)
             if record is not None:
                 record[f"l{l}.in"] = B.h.clone()
-            if fuse_rows and self.fuse_qkr and cfg.head_dim == 64 and H >= 256:
+            # the library's own conditions for the fused form (i64h_gemm_i8_qkv_rope_kv): other shapes take the two-kernel path
+            if fuse_rows and self.fuse_qkr and cfg.head_dim == 64 and 256 <= H <= 2048 and H % 64 == 0:
                 # decode-sized step: projection, QK norm, RoPE and cache write in one launch (a 64-column tile is one head)
                 ops.gemm_i8_qkv_rope_kv(ops.gemm_desc(B.normed, W["qkv"].w_q, W["qkv"].w_s, B.qkv, a_slot_base=base + 0, stats=st),
                                         W["q_norm"], W["k_norm"], 1e-6, self.rope, positions, slot_ids, kvc.block_table, kvc.k[l], kvc.v[l],
@@ -394,7 +404,7 @@ class I64MoEModel:
                 last = l + 1 == cfg.num_layers
                 ops.fused_residual_norm(B.h, nxt, eps, moe_rows=B.e_out, moe_inv=moe_inv,
                                         moe_shared=B.sh_out if cfg.shared_intermediate_size else None, route_weights=rw,
-                                        routed_scale=cfg.routed_scale, shared_scale=cfg.shared_scale, h_out=B.h, normed=B.normed,
+                                        routed_scale=W["routed_scale"], shared_scale=W["shared_scale"], h_out=B.h, normed=B.normed,
                                         slot_base=base + spl, stats=None if last else st)
                 if record is not None:
                     record[f"l{l}.out"] = B.h.clone()
@@ -469,8 +479,8 @@ class I64MoEModel:
         zero = torch.zeros_like(x)
         out, _ = ops.fused_residual_norm(zero, None, cfg.rms_eps, moe_rows=B.e_out, moe_inv=moe_inv,
                                          moe_shared=B.sh_out if cfg.shared_intermediate_size else None,
-                                         route_weights=cfg.route_weights, routed_scale=cfg.routed_scale,
-                                         shared_scale=cfg.shared_scale, want_normed=False)
+                                         route_weights=cfg.route_weights, routed_scale=self.layers[l]["routed_scale"],
+                                         shared_scale=self.layers[l]["shared_scale"], want_normed=False)
         return out
 
 
@@ -489,6 +499,7 @@ class GreedyDecoder:
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.logits: Optional[torch.Tensor] = None
         self.max_ctx_hint = 0
+        self.host_lens: List[int] = [0] * batch   # tokens each sequence holds (host mirror of `positions`)
 
     def prefill(self, prompts: Sequence[torch.Tensor], reserve_extra: int = 0) -> torch.Tensor:
         m, dev = self.m, self.m.device
@@ -503,6 +514,7 @@ class GreedyDecoder:
         self.positions.copy_(torch.tensor(lens, dtype=torch.int32))
         self.ctx_len.copy_(torch.tensor(lens, dtype=torch.int32) + 1)
         self.max_ctx_hint = max(lens) + reserve_extra
+        self.host_lens = list(lens)
         ops.argmax_rows(logits, out=self.tokens)
         return logits
 
@@ -514,6 +526,22 @@ class GreedyDecoder:
         self.positions.copy_(torch.tensor(list(lens), dtype=torch.int32))
         self.ctx_len.copy_(torch.tensor(list(lens), dtype=torch.int32) + 1)
         self.max_ctx_hint = max(lens) + reserve_extra
+        self.host_lens = [int(n) for n in lens]
+
+    def _reserve_next(self):
+        """Host-side bound of the device-side position advance: the token of this step lands at position host_lens[s]; make
+        sure its block exists (the block table keeps its address, so a captured graph stays valid) and refuse to run past
+        the position range - the kernels index the rotary and block tables without bounds."""
+        top = max(self.host_lens) if self.host_lens else 0
+        if top >= self.m.cfg.max_pos:
+            raise RuntimeError(f"sequence length {top + 1} exceeds max_pos {self.m.cfg.max_pos}")
+        for s, n in enumerate(self.host_lens):
+            self.m.kv.reserve(s, n + 1)
+        if top + 1 > self.max_ctx_hint and self.graph is not None:
+            # the attention split count was chosen for the hint at capture time: it only has to be a bound for the split
+            # heuristic, the kernels take the real lengths from ctx_len
+            self.max_ctx_hint = top + 1
+        self.host_lens = [n + 1 for n in self.host_lens]
 
     def _step_body(self):
         self.logits = self.m.forward(self.tokens, self.positions, self.slot_ids, self.ctx_len, max_ctx_hint=self.max_ctx_hint,
@@ -522,6 +550,7 @@ class GreedyDecoder:
 
     def step(self) -> torch.Tensor:
         """One decode step for the whole batch; returns the logits of the step (valid until the next step)."""
+        self._reserve_next()
         if not self.use_graph:
             self._step_body()
             return self.logits
