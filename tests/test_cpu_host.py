@@ -95,3 +95,29 @@ def test_multi_rank_timing_reduction_gloo(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0].split()
     assert int(line[1]) == 2 and float(line[2]) == 0.2 and float(line[3]) == 6400.0
+
+
+def test_baseline_config_1_dense_batch1_greedy_on_the_cpu_engine():
+    """BASELINE configuration 1 (dense-306, --quantization int8, CPU engine, greedy decode, batch 1): the plumbing case that runs
+    without a GPU.  The oracle's engine with torch's own dynamic int8 Linears (the reference's quantized kernels) at the config's
+    real width, four layers deep to keep the CPU suite short: deterministic, finite logits, and the numpy restatement of the
+    quantized Linear gives the same greedy tokens."""
+    import dataclasses
+    from oracle import model_ref as M
+    cfg = dataclasses.replace(M.named_config("dense306-synth"), num_layers=4, vocab_size=2048, name="dense306-4layer")
+    w = M.make_weights(cfg, seed=0)
+    prompt = M.make_token_ids(cfg, 24, seed=7)
+    runs = []
+    for mode in ("int8_torch", "int8_torch", "int8"):
+        eng = M.OracleEngine(cfg, w, mode=mode, max_seqs=1, num_blocks=8)
+        lg = eng.prefill([prompt])
+        toks, logits = [], [lg]
+        for _ in range(6):
+            t = lg.argmax(-1)
+            toks.append(int(t))
+            lg = eng.decode(t)
+            logits.append(lg)
+        runs.append((toks, torch.cat(logits)))
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])          # deterministic
+    assert torch.isfinite(runs[0][1]).all()
+    assert runs[2][0] == runs[0][0] and torch.equal(runs[2][1], runs[0][1])          # restatement == torch's kernels, bit for bit

@@ -122,3 +122,56 @@ def test_decode_attention_at_2048_tokens_against_oracle_rows(dev):
         vf = vc[bt[i, :(c + 15) // 16].long()].reshape(-1, kvh, hd)[:c].float()
         ref = M.cached_attention(q[i:i + 1], kf, vf, nh // kvh, torch.tensor([c - 1]), 1.0 / hd ** 0.5)[0]
         torch.testing.assert_close(out[i], ref, rtol=1e-5, atol=3e-6)
+
+
+@pytest.mark.parametrize("name,lens", [("trmoe306-synth", [1] * 16), ("trmoe306-synth", [200, 57]), ("dense306-synth", [1]),
+                                       ("dense306-synth", [23, 10]), ("dense306-synth", [180, 120])])
+def test_other_baseline_configs_teacher_forced(dev, name, lens):
+    """BASELINE configurations 1 and 2 at their real dimensions (two-layer cuts): `trmoe306-synth` (4 experts of 512, shared
+    2048 - the shared down projection's K = 2048 sits on the decode-sized kernel's limit; cyclic top-2 routing, 0.95 / 0.05
+    weights) with 16 decode rows and with a prefill; `dense306-synth` (dense MLP of 4096: the down projection's K = 4096 is
+    beyond the decode-sized kernel and runs the tiled kernel with the quantizer in its staging loop) at batch 1, a small
+    prefill and a 300-row prefill.  Every layer is fed the oracle's layer input; decode rows attend to a 40-token history."""
+    from vllm_i64_amd.config import ModelConfig
+    from vllm_i64_amd.model import I64MoEModel
+    ocfg = dataclasses.replace(M.named_config(name), num_layers=2, name=name + "-2layer")
+    w = M.make_weights(ocfg, seed=0)
+    nseq = len(lens)
+    model = I64MoEModel(ModelConfig.from_any(ocfg), w, device=dev, kv_dtype=torch.float32, max_seqs=nseq, num_kv_blocks=nseq * 16 + 32)
+    eng = M.OracleEngine(ocfg, w, mode="int8_torch", max_seqs=nseq, num_blocks=nseq * 16 + 32)
+    decode = all(k == 1 for k in lens)
+    hist = 40 if decode else 0
+    if decode:  # a 40-token history computed by the oracle; the GPU cache starts from the oracle's cache contents and block table
+        eng.prefill([M.make_token_ids(ocfg, hist, seed=50 + s) for s in range(nseq)])
+        for l in range(ocfg.num_layers):
+            model.kv.k[l].copy_(eng.kv.k[l])
+            model.kv.v[l].copy_(eng.kv.v[l])
+        model.kv.block_table.copy_(eng.kv.block_table)
+    n = sum(lens)
+    ids = M.make_token_ids(ocfg, n, seed=3)
+    rec = {}
+    if decode:
+        eng.decode(ids, record=rec)
+    else:
+        eng.prefill(list(ids.split(lens)), record=rec)
+        for s, k in enumerate(lens):
+            model.kv.reserve(s, k)
+    pos = torch.cat([torch.arange(hist, hist + k, dtype=torch.int32) for k in lens]).to(dev)
+    slots = torch.cat([torch.full((k,), s, dtype=torch.int32) for s, k in enumerate(lens)]).to(dev)
+    grec = {}
+    model.forward(ids.to(dev), pos, slots, (pos + 1).contiguous(), record=grec,
+                  inject={l: rec[f"l{l}.in"].to(dev) for l in range(ocfg.num_layers)}, max_ctx_hint=hist + 1 if decode else 0)
+    for l in range(ocfg.num_layers):
+        da = (grec[f"l{l}.attn_out"].cpu() - rec[f"l{l}.attn_out"]).abs()
+        do = (grec[f"l{l}.out"].cpu() - rec[f"l{l}.out"]).abs()
+        print(f"{name} rows {n} layer {l}: attention-out diff max {da.max():.3e}; layer-out diff max {do.max():.3e} mean {do.mean():.3e}")
+        if da.max() > 1e-5:
+            # one 7-bit step of the qkv call's activation quantizer flipped on a rounding tie (the layer input is the oracle's, the
+            # RMSNorm in front of the quantizer is ours): a key / value row moves by one quantization step and every later query of
+            # that sequence sees it.  Bounded by that step; the layer output is then only held to the single-Linear bound.
+            assert da.max() <= 5e-3 and do.max() <= 1e-1 and do.mean() <= 5e-3, (da.max(), do.max(), do.mean())
+            continue
+        row_err = do.max(dim=1).values
+        flipped = row_err > 1e-5   # a row whose fp32 input sits on a rounding tie of the 7-bit quantizer (see the test above)
+        assert int(flipped.sum()) <= max(2, n // 64), (int(flipped.sum()), row_err[flipped])
+        assert row_err.max() <= 1e-1 and do.mean() <= 2e-4
