@@ -7,7 +7,9 @@ Workload (BASELINE.json configs[2]): `trhash500m-synth` (492.1 M parameters, E=8
 expert) with every Linear in the reference CPU engine's dynamic int8 scheme; 64 sequences per GPU, 2048-token prompts
 (real prefill, untimed, its rate reported separately), then K greedy decode steps of batch 64 (timed).  A "step" is
 one decode step of the whole batch: routing plan, 24 layers, lm_head, argmax, position advance - one HIP graph replay.
-With N GPUs every rank serves its own 64 sequences (weak scaling, no collective on the data path).
+With N > 1 GPUs every rank serves its own 64 sequences (weak scaling) and the routed experts are sharded over the ranks:
+per MoE layer one all-gather of the MoE input rows and one equal-split all-to-all of the expert rows (RCCL); a second,
+labelled measurement of the same ranks as independent replicas is reported beside it ("replica").
 
 Prints ONE JSON line on rank 0: metric / value / unit / n_gpus / steps / warmup / ms_per_step / scaling / dtype / data / config, plus the
 roofline objects of the dominant decode kernel and of the grouped expert GEMM, and the CPU baseline.
@@ -27,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec
 MFMA_I8_PEAK_TOPS = 5000.0  # dense int8 MFMA peak (the datasheet's headline figure halved: it counts 2:1 sparsity)
-MFMA_I8_PEAK_TOPS = 5000.0  # dense int8 MFMA (2x the ~2.5 PF bf16 dense peak)
+PMC_PROFILE = "r02_pmc_traffic.json"  # HBM counter passes of the default command (tools/pmc_traffic.sh), under profiles/
 
 
 def parse():
@@ -48,10 +50,23 @@ def parse():
     ap.add_argument("--cpu-ctx", type=int, default=128)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--zipf", type=float, default=0.0, help="prompt ids from a Zipf(s) distribution instead of uniform (bucket skew)")
-    ap.add_argument("--parallelism", default="dp", choices=["dp", "ep"],
-                    help="dp: every rank is an independent replica (default; no data-path collective).  ep: the routed experts are "
-                         "sharded over the ranks, one all-to-all each way per MoE layer (RCCL); runs without the HIP graph")
+    ap.add_argument("--parallelism", default="auto", choices=["auto", "dp", "ep"],
+                    help="ep: the routed experts are sharded over the ranks (one all-gather of the MoE input rows and one all-to-all "
+                         "of the expert rows per layer, RCCL) - the default with more than one GPU.  dp: every rank is an "
+                         "independent replica (no data-path collective) - the default on one GPU")
+    ap.add_argument("--no-replica-leg", action="store_true",
+                    help="N > 1: skip the second, labelled measurement of independent replicas (reported beside the expert-parallel value)")
     return ap.parse_args()
+
+
+def self_launch(args) -> int:
+    """`--gpus N` (N > 1) started as a plain process: start the N ranks as children (one per GPU) and return their exit code.
+    Nothing has touched the GPU yet in this process."""
+    import subprocess
+    port = os.environ.get("MASTER_PORT", "29531")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
 
 
 def get_config(name):
@@ -95,8 +110,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: this machine shows {ndev} GPU(s)")
+        raise SystemExit(self_launch(args))
+    if world != args.gpus:
+        if world > 1:
+            args.gpus = world
+        else:
+            raise SystemExit(f"bench.py --gpus {args.gpus} inside a job of WORLD_SIZE {world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     dist = None
@@ -125,22 +148,45 @@ def main():
         cfg = dataclasses.replace(cfg, max_pos=(need + 255) // 256 * 256)
     t0 = time.time()
     weights = synth.make_weights(cfg, seed=0)
-    ep_mode = args.parallelism == "ep"
-    model = I64MoEModel(cfg, weights, device=dev, kv_dtype=kv_dtype, max_seqs=B, expert_parallel=ep_mode)
-    t_setup = time.time() - t0
-    dec = GreedyDecoder(model, B, use_graph=not (args.no_graph or ep_mode))
+    ep_mode = cfg.is_moe and (args.parallelism == "ep" or (args.parallelism == "auto" and world > 1))
     total_len = P + args.steps + args.warmup + 2
-
-    # ---- prefill (untimed for the headline; its own rate is reported) ----
-    prefill_tps = None
     ids = synth.make_token_ids(cfg, B * P, seed=7 + rank, zipf=args.zipf).view(B, P)
-    if args.synthetic_kv:
-        g = torch.Generator(device=dev).manual_seed(5)
-        for l in range(cfg.num_layers):
-            model.kv.k[l].copy_(torch.randn(model.kv.k[l].shape, device=dev, generator=g).to(kv_dtype))
-            model.kv.v[l].copy_((0.6 * torch.randn(model.kv.v[l].shape, device=dev, generator=g)).to(kv_dtype))
-        dec.set_state(ids[:, -1].to(dev), [P] * B, reserve_extra=total_len - P)
-    else:
+
+    def run_leg(expert_parallel: bool):
+        """Build the runner, prefill (untimed; its own rate is reported), W warm-up steps, then exactly K timed steps bracketed
+        by barrier + synchronize; the time is the maximum over the ranks."""
+        model = I64MoEModel(cfg, weights, device=dev, kv_dtype=kv_dtype, max_seqs=B, expert_parallel=expert_parallel)
+        dec = GreedyDecoder(model, B, use_graph=not args.no_graph)
+        prefill_tps = fill_cache(model, dec)
+        dec.prepare()  # buffer allocation and graph capture are set-up, not steps (no state advances)
+        for _ in range(args.warmup):
+            dec.step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            dec.step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t1
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return model, dec, prefill_tps, elapsed
+
+    def fill_cache(model, dec):
+        if args.synthetic_kv:
+            g = torch.Generator(device=dev).manual_seed(5)
+            for l in range(cfg.num_layers):
+                model.kv.k[l].copy_(torch.randn(model.kv.k[l].shape, device=dev, generator=g).to(kv_dtype))
+                model.kv.v[l].copy_((0.6 * torch.randn(model.kv.v[l].shape, device=dev, generator=g)).to(kv_dtype))
+            dec.set_state(ids[:, -1].to(dev), [P] * B, reserve_extra=total_len - P)
+            return None
         for s in range(B):
             model.kv.reserve(s, total_len)
         first = torch.empty(B, dtype=torch.int64, device=dev)
@@ -159,31 +205,26 @@ def main():
                 torch.cuda.synchronize()
                 tp, timed_seqs = time.time(), B - len(seqs)
         torch.cuda.synchronize()
-        prefill_tps = timed_seqs * P / (time.time() - tp)
+        rate = timed_seqs * P / (time.time() - tp)
         dec.set_state(first, [P] * B, reserve_extra=total_len - P)
+        return rate
 
-    # ---- decode: W warm-up steps, then exactly K timed steps ----
-    dec.prepare()  # buffer allocation and graph capture are set-up, not steps (no state advances)
-    for _ in range(args.warmup):
-        dec.step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        dec.step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t1
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    model, dec, prefill_tps, elapsed = run_leg(ep_mode)
+    t_setup = time.time() - t0
     ms_per_step = elapsed / args.steps * 1e3
     value = B * world * args.steps / elapsed
+    used_graph = dec.graph is not None
+    replica, r_model = None, None
+    if ep_mode and world > 1 and not args.no_replica_leg:
+        # the same ranks as independent replicas (every rank holds all experts, no data-path collective), for the reader who
+        # wants the cost of the exchange: a labelled extra, never the headline value
+        ep_model, ep_dec = model, dec
+        del model, dec
+        r_model, r_dec, r_prefill, r_elapsed = run_leg(False)
+        replica = {"parallelism": f"dp{world} (independent replicas, no collective)", "value": round(B * world * args.steps / r_elapsed, 1),
+                   "unit": "tokens/s", "ms_per_step": round(r_elapsed / args.steps * 1e3, 4), "hip_graph": r_dec.graph is not None}
+        del r_dec
+        model, dec = ep_model, ep_dec
 
     # ---- roofline of the dominant kernel: paged-KV attention of one layer, timed with HIP events on the launch stream ----
     ctx_now = P + args.warmup + args.steps
@@ -205,12 +246,17 @@ def main():
     attn_bytes = B * ctx_now * cfg.num_kv_heads * cfg.head_dim * 2 * kvb  # K and V rows of every cached token, once
     achieved = attn_bytes / (attn_ms * 1e-3) / 1e9
     # HBM-side bytes of the same kernel from the counter passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
-    # --pmc WRITE_SIZE in runs of their own; FETCH_SIZE doubled, the gfx950 correction): a profiler cannot run inside this process
+    # --pmc WRITE_SIZE in runs of their own; FETCH_SIZE doubled, the gfx950 correction): a profiler cannot run inside this
+    # process, so the figure is reported only when this run's workload is the one the passes were taken on
     traffic = None
+    this_workload = {"config": cfg.name, "batch": B, "prompt_len": P, "kv_dtype": args.kv_dtype, "steps": args.steps, "warmup": args.warmup,
+                     "splits": splits}
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")) as f:
-            for kname, kd in json.load(f)["kernels"].items():
-                if "paged_attn_allheads_kernel" in kname and ("bfloat16" in kname) == (args.kv_dtype == "bf16"):
+        with open(os.path.join(ROOT, "profiles", PMC_PROFILE)) as f:
+            prof = json.load(f)
+        if prof.get("workload") == this_workload:
+            for kname, kd in prof["kernels"].items():
+                if "paged_attn_allheads_kernel" in kname:
                     traffic = int(kd["hbm_read_bytes_corrected"] + kd["hbm_write_bytes"])
     except Exception:
         traffic = None
@@ -219,17 +265,29 @@ def main():
                 "avg_launch_ms": round(attn_ms, 4), "algorithmic_bytes_per_launch": attn_bytes, "splits": splits,
                 "share_of_step": round(attn_ms * cfg.num_layers / ms_per_step, 3)}
 
+    # ---- the whole decode step against HBM: bytes a step cannot avoid (every weight once, the cached K/V rows once, the
+    # lm_head matrix once) over the measured step time
+    wbytes = sum(t.numel() * t.element_size() for W in model.layers for v in W.values() if hasattr(v, "w_q") for t in (v.w_q,))
+    step_bytes = wbytes + cfg.num_layers * attn_bytes + model.embed.numel() * 4
+    step_roof = {"bound": "hbm", "algorithmic_bytes_per_step": int(step_bytes), "weights_bytes": int(wbytes),
+                 "kv_bytes": int(cfg.num_layers * attn_bytes), "achieved": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                 "unit": "GB/s", "frac": round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                 "floor_ms_per_step": round(step_bytes / (HBM_PEAK_GBS * 1e9) * 1e3, 4)}
+
     # ---- second half of the metric: the grouped-expert gate_up GEMM of one prefill chunk against the dense int8 MFMA peak.
     # Rows and group sizes are those of a real chunk (prefill_chunk_seqs x P tokens, top_k routes each, layer 0 routing),
     # operands already quantized; ops = 2*M*N*K over real rows only.
     mfma = None
+    gm = model if not (ep_mode and world > 1) else r_model   # a runner that holds every expert
     try:
+        if gm is None:
+            raise RuntimeError("skipped: no runner with all experts in this run (--no-replica-leg)")
         nchunk = min(B, args.prefill_chunk_seqs) * P
         ids_chunk = ids[:min(B, args.prefill_chunk_seqs)].reshape(-1).to(dev)
-        Bp = model.buffers(nchunk, nchunk)
-        Bp.plan.run(ids_chunk, model.tables)
+        Bp = gm.buffers(nchunk, nchunk)
+        Bp.plan.run(ids_chunk, gm.tables)
         R = Bp.plan.rows
-        Wg = model.layers[0]["exp_gu"]
+        Wg = gm.layers[0]["exp_gu"]
         a8 = torch.randint(-127, 128, (R, cfg.hidden_size), dtype=torch.int8, device=dev)
         rs = torch.rand(R, device=dev) * 1e-3
         o8 = torch.empty(R, cfg.expert_inter, device=dev)
@@ -260,13 +318,18 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{cfg.name} int8 dynamic-Linear forward, batch {B} per GPU, {P}-token prompts"
                                f"{' (synthetic KV)' if args.synthetic_kv else ' (real prefill)'} + greedy decode, KV cache {args.kv_dtype}",
-                   "global_batch": B * world, "seq_len": P, "parallelism": (f"ep{world} (experts sharded, all-to-all each way per MoE layer)" if ep_mode else
+                   "global_batch": B * world, "seq_len": P,
+                   "parallelism": (f"ep{world} (experts sharded over the ranks; per MoE layer one all-gather of the input rows and one "
+                                   f"equal-split all-to-all of the expert rows, RCCL)" if ep_mode else
                                    f"dp{world} (independent replicas, no collective)" if world > 1 else "single GPU"),
-                   "kv_dtype": args.kv_dtype, "hip_graph": not (args.no_graph or ep_mode),
+                   "kv_dtype": args.kv_dtype, "hip_graph": used_graph,
                    "prompt_ids": f"zipf({args.zipf})" if args.zipf > 0 else "uniform"},
         "roofline": roofline,
+        "roofline_step": step_roof,
         "roofline_mfma": mfma,
     }
+    if replica is not None:
+        out["replica"] = replica
     if prefill_tps is not None:
         out["prefill_tokens_per_s"] = round(prefill_tps, 1)
     out["setup_s"] = round(t_setup, 1)

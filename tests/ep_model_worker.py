@@ -1,0 +1,82 @@
+"""Worker of the whole-model expert-parallel tests, launched through torch.distributed.run with the gloo backend.
+  mode "cpu": the exchange code of vllm_i64_amd.ep driven with oracle arithmetic (tests/ep_oracle.rank_step), which must equal
+              the single-process statement exactly;
+  mode "gpu": the HIP runner (I64MoEModel(expert_parallel=True)), every rank on cuda:0 (gloo stages through the host), against
+              the same single-process statement within the quantization-noise bound of the model tests.
+One prefill step and two decode steps."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import ep_oracle  # noqa: E402
+from oracle import model_ref as M  # noqa: E402
+from vllm_i64_amd import ep  # noqa: E402
+
+
+def main():
+    mode = sys.argv[1]
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    comm = ep.EPComm()
+    ocfg = M.named_config("tiny-moe")
+    w = M.make_weights(ocfg, seed=0)
+    bank = M.LinearBank(w, "int8")
+    lens, prompts = ep_oracle.make_case(ocfg, world)
+    nseq = len(lens[0])
+    # the single-process statement, for all ranks (every rank computes it: tiny)
+    kvs = [M.PagedKV(ocfg, 32, nseq) for _ in range(world)]
+    steps = []   # per step: (ids per rank, positions per rank, tokens per seq)
+    ids = [torch.cat(p) for p in prompts]
+    pos = [torch.cat([torch.arange(n) for n in ls]) for ls in lens]
+    cur = [list(ls) for ls in lens]
+    ref = []
+    tps = [list(ls) for ls in lens]
+    for step in range(3):
+        lg = ep_oracle.reference_step(ocfg, bank, ids, pos, kvs, [list(range(nseq))] * world, tps)
+        steps.append((ids, pos, tps))
+        if step == 0:
+            lg = [x[torch.cumsum(torch.tensor(ls), 0) - 1] for x, ls in zip(lg, lens)]
+        ref.append(lg)
+        ids = [x.argmax(-1) for x in lg]                       # greedy: the next step's tokens
+        pos = [torch.tensor(c) for c in cur]
+        cur = [[c + 1 for c in cs] for cs in cur]
+        tps = [[1] * nseq for _ in range(world)]
+    worst, agree = 0.0, 1.0
+    if mode == "cpu":
+        kv = M.PagedKV(ocfg, 32, nseq)
+        for step, (sids, spos, stps) in enumerate(steps):
+            lg = ep_oracle.rank_step(ocfg, bank, comm, sids[rank], spos[rank], kv, list(range(nseq)), stps[rank])
+            if step == 0:
+                lg = lg[torch.cumsum(torch.tensor(lens[rank]), 0) - 1]
+            worst = max(worst, float((lg - ref[step][rank]).abs().max()))
+    else:
+        from vllm_i64_amd.config import ModelConfig
+        from vllm_i64_amd.model import I64MoEModel
+        dev = torch.device("cuda:0")
+        model = I64MoEModel(ModelConfig.from_any(ocfg), w, device=dev, max_seqs=nseq, num_kv_blocks=32, expert_parallel=True)
+        assert model.ep.world == world and not model.ep.direct
+        for s in range(nseq):
+            model.kv.reserve(s, lens[rank][s] + 4)
+        for step, (sids, spos, stps) in enumerate(steps):
+            slot = torch.cat([torch.full((c,), s, dtype=torch.int32) for s, c in enumerate(stps[rank])]).to(dev)
+            p32 = spos[rank].to(torch.int32).to(dev)
+            rows = None
+            if step == 0:
+                rows = (torch.cumsum(torch.tensor(lens[rank]), 0) - 1).to(torch.int32).to(dev)
+            lg = model.forward(sids[rank].to(dev), p32, slot, (p32 + 1).contiguous(), logit_rows=rows).cpu()
+            worst = max(worst, float((lg - ref[step][rank]).abs().max()))
+            agree = min(agree, float((lg.argmax(-1) == ref[step][rank].argmax(-1)).float().mean()))
+    t = torch.tensor([worst, -agree], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print("EP_MODEL_RESULT", mode, world, float(t[0]), -float(t[1]))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -23,6 +23,43 @@ def test_expert_parallel_layer_equals_single_process_oracle(world, port):
     assert int(line[4]) == int(line[5])          # every (route, token) row arrived at exactly one owner
 
 
+@pytest.mark.parametrize("world,port", [(2, 29543), (4, 29544)])
+def test_expert_parallel_whole_model_fixed_shape_exchange(world, port):
+    """Whole model (prefill + two greedy decode steps) over `world` gloo ranks: the fixed-shape exchange of the HIP runner
+    (ids gathered once per step, MoE input rows gathered and one equal-split all-to-all per layer, row maps from the global
+    plan) with oracle arithmetic, against the single-process statement of the same step.  Must be exact."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "ep_model_worker.py"), "cpu"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("EP_MODEL_RESULT")][0].split()
+    assert int(line[2]) == world
+    assert float(line[3]) == 0.0, f"expert-parallel logits differ from the single-process statement by {line[3]}"
+
+
+def test_exchange_row_maps_route_every_row_to_its_owner_and_back():
+    from vllm_i64_amd import ep
+    world, n, top_k, E = 4, 5, 2, 8
+    le, n_all = E // world, world * n
+    g = torch.Generator().manual_seed(3)
+    expert = torch.randint(0, E, (3, top_k, n_all), generator=g)                       # three layers
+    keys = (expert * top_k + torch.arange(top_k)[None, :, None]).reshape(3, -1).to(torch.int32)
+    perm = torch.stack([torch.sort(k.to(torch.int64), stable=True).indices for k in keys]).to(torch.int32)
+    rm = ep.exchange_row_map(perm, n, world, top_k)
+    for l in range(3):
+        send = torch.full((world, world, top_k * n), -1.0)                              # [owner, destination, row]
+        for j, s in enumerate(perm[l].tolist()):
+            k, t = divmod(s, n_all)
+            send[int(expert[l, k, t]) // le].view(-1)[rm[l, j]] = 1000 * k + t
+        for r in range(world):
+            m = ep.owner_row_map(keys, n, r, world, top_k, le)
+            assert m.shape == (3, top_k * n) and m.dtype == torch.int32
+            got = send[:, r].reshape(-1)[m[l].long()].view(top_k, n)
+            want = torch.tensor([[1000.0 * k + r * n + t for t in range(n)] for k in range(top_k)])
+            assert torch.equal(got, want)
+
+
 def test_exchange_plan_arithmetic():
     from vllm_i64_amd import ep
     top_k, V, E = 2, 50, 4

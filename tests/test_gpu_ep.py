@@ -1,0 +1,31 @@
+"""Whole-model expert parallelism on the HIP runner: ranks as separate processes that share the one card of the test box
+(gloo rendezvous, exchanged tensors staged through the host), against the single-process oracle statement of the same steps
+(tests/ep_oracle.reference_step).  On a multi-GPU node the same code runs one rank per GPU over RCCL (bench.py --gpus N)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("world,port,force", [(2, 29551, "0"), (4, 29552, "0"), (1, 29553, "1")])
+def test_expert_parallel_runner_against_single_process_oracle(world, port, force):
+    """Prefill (ragged prompts, equal token count per rank) and two greedy decode steps.  Bound: the quantization-noise scale
+    of the model tests (a flipped 7-bit activation LSB moves a logit by ~1e-2); greedy tokens identical.  world 1 with forced
+    collectives walks the exchange path (gather, row maps, all-to-all, owner-indexed combine) at one rank."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", I64H_EP_FORCE_COLLECTIVES=force)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "ep_model_worker.py"), "gpu"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith("EP_MODEL_RESULT")][0].split()
+    print(line)
+    assert int(line[2]) == world
+    assert float(line[3]) <= 2.5e-2, f"expert-parallel logits differ from the oracle statement by {line[3]}"
+    assert float(line[4]) == 1.0

@@ -26,6 +26,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -296,3 +298,94 @@ class ExpertParallelMoE:
         return be.combine(back, plan.inv, shared_out, n)
 
     __call__ = forward
+
+
+# ---------------------------------------------------------------------------------------------------------
+# fixed-shape exchange for whole-model expert parallelism (graph-capturable: no host-side split sizes)
+# ---------------------------------------------------------------------------------------------------------
+class EPComm:
+    """The two collectives of the whole-model expert-parallel runner (vllm_i64_amd.model.I64MoEModel(expert_parallel=True)),
+    both of FIXED shape, so that a decode step with them can be captured into one HIP graph and needs no device-to-host
+    transfer at all:
+
+      all_gather(rows [n, ...])            -> [world * n, ...]   every rank sees every rank's tokens (ids once per step, the
+                                                                  MoE input rows once per layer): because the routing is a pure
+                                                                  function of the token id, every rank then derives the SAME
+                                                                  global bucket plan on the device and picks its experts' rows
+                                                                  out of the gathered block - no count exchange, no split sizes;
+      exchange(send [world, m, H])         -> [world, m, H]       block d of `send` holds this rank's contribution to rank d's
+                                                                  (route, token) rows (rows of other ranks' experts are never
+                                                                  written); one all_to_all of equal splits.  The receiver reads
+                                                                  row (k, t) out of the block of the rank that owns its expert
+                                                                  (owner_row_map, from the same global plan): no zero fill, no
+                                                                  sum, every value arrives untouched.
+
+    Replaces the variable-split dispatch / combine of the reference's expert-parallel layer
+    (vllm_i64/layers/token_routed_i64/layer.py:227-292) for the decode-sized steps where latency, not volume, is the cost;
+    the variable-split form stays available as ExpertParallelMoE.  Tensors on the GPU go through the group's backend directly
+    when it is RCCL ("nccl"); with any other backend (gloo rehearsals, two ranks sharing one card) they are staged through the
+    host."""
+
+    def __init__(self, group=None, force: Optional[bool] = None):
+        """force: run the collectives even at world size 1 (default: the environment variable I64H_EP_FORCE_COLLECTIVES=1) -
+        rehearses the whole exchange path, graph capture of the collectives included, on one GPU."""
+        self.group = group
+        self.on = dist.is_available() and dist.is_initialized()
+        self.rank = dist.get_rank(group) if self.on else 0
+        self.world = dist.get_world_size(group) if self.on else 1
+        self.direct = self.on and dist.get_backend(group) == "nccl"
+        if force is None:
+            force = os.environ.get("I64H_EP_FORCE_COLLECTIVES", "0") == "1"
+        self.active = self.world > 1 or (bool(force) and self.on)   # False: one rank, nothing to exchange
+
+    def all_gather(self, t: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if not self.active:
+            return t
+        t = t.contiguous()
+        if out is None:
+            out = t.new_empty((self.world * t.shape[0],) + tuple(t.shape[1:]))
+        if self.direct or not t.is_cuda:
+            dist.all_gather_into_tensor(out, t, group=self.group)
+        else:
+            host = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(host, t.cpu(), group=self.group)
+            out.copy_(host)
+        return out
+
+    def exchange(self, send: torch.Tensor, recv: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """send [world, m, H] (block d = this rank's rows for rank d) -> recv [world, m, H] (block s = what rank s computed for
+        this rank)."""
+        if not self.active:
+            return send
+        assert send.is_contiguous() and send.shape[0] == self.world
+        if recv is None:
+            recv = torch.empty_like(send)
+        if self.direct or not send.is_cuda:
+            dist.all_to_all_single(recv, send, group=self.group)
+        else:
+            host = torch.empty(send.shape, dtype=send.dtype)
+            dist.all_to_all_single(host, send.cpu(), group=self.group)
+            recv.copy_(host)
+        return recv
+
+
+def exchange_row_map(perm: torch.Tensor, n: int, world: int, top_k: int) -> torch.Tensor:
+    """perm[..., j] = k * (world * n) + t, the global (route, token) source row of bucket-ordered row j (i64h_moe_plan over the
+    gathered ids) -> the row of the exchange buffer [world, top_k * n, H] it belongs to: rank d = t // n owns token t, and
+    inside rank d's block the rows lie in that rank's local (route, token) order k * n + (t % n).  int32, same shape."""
+    n_all = world * n
+    p = perm.to(torch.int64)
+    k, t = p // n_all, p % n_all
+    return ((t // n) * (top_k * n) + k * n + (t % n)).to(torch.int32)
+
+
+def owner_row_map(keys: torch.Tensor, n: int, rank: int, world: int, top_k: int, local_experts: int) -> torch.Tensor:
+    """keys[..., k * (world * n) + t] = expert * top_k + k, the bucket of global (route, token) row (i64h_moe_plan over the
+    gathered ids) -> for THIS rank's rows (k, t_local): the row of the received exchange buffer [world, top_k * n, H] that
+    holds the result, block = the rank that owns the expert.  int32 [..., top_k * n]."""
+    n_all = world * n
+    lead = keys.shape[:-1]
+    mine = keys.reshape(*lead, top_k, n_all)[..., rank * n:(rank + 1) * n].to(torch.int64)      # [..., top_k, n]
+    owner = mine // (top_k * local_experts)
+    local = torch.arange(top_k * n, device=keys.device, dtype=torch.int64).reshape(top_k, n)
+    return (owner * (top_k * n) + local).reshape(*lead, top_k * n).to(torch.int32)

@@ -102,8 +102,12 @@ class PagedKVCache:
 class _Buffers:
     """Per-step device buffers for N tokens (allocated once per N, reused: graph-safe)."""
 
-    def __init__(self, cfg: ModelConfig, n: int, n_logit_rows: int, device):
-        H, R = cfg.hidden_size, n * cfg.top_k
+    def __init__(self, cfg: ModelConfig, n: int, n_logit_rows: int, device, ep_world: int = 0, ep_exchange: bool = False):
+        """ep_world > 0: expert-parallel runner - the routing plan and the expert-side buffers span the tokens of ALL ranks
+        (n_all = ep_world * n rows); ep_exchange: plus the fixed-shape exchange buffers."""
+        H = cfg.hidden_size
+        n_all = n * max(ep_world, 1)
+        R = n_all * cfg.top_k
         f32 = dict(dtype=torch.float32, device=device)
         i8 = dict(dtype=torch.int8, device=device)
         kvw = cfg.num_kv_heads * cfg.head_dim
@@ -128,7 +132,13 @@ class _Buffers:
                 self.sha = torch.empty(n, S, **i8)
                 self.shs = torch.empty(n, **f32)
                 self.sh_out = torch.empty(n, H, **f32)
-            self.plan = ops.MoePlan(n, cfg.top_k, cfg.num_experts, cfg.num_layers, device)
+            self.plan = ops.MoePlan(n_all, cfg.top_k, cfg.num_experts, cfg.num_layers, device)
+            if ep_exchange:
+                self.normed_all = torch.empty(n_all, H, **f32)
+                self.xsend = torch.empty(ep_world, cfg.top_k * n, H, **f32)   # block d: this rank's contribution to rank d's rows
+                self.xrecv = torch.empty(ep_world, cfg.top_k * n, H, **f32)
+                self.row_map: Optional[torch.Tensor] = None    # [L, R] send-buffer row of bucket-ordered row j
+                self.recv_map: Optional[torch.Tensor] = None   # [L, top_k * n] received-buffer row of this rank's (route, token) row
         else:
             I = cfg.intermediate_size
             self.d_inter = torch.empty(n, I, **f32)
@@ -149,16 +159,15 @@ class I64MoEModel:
         layer exchanges the routed rows with one all-to-all each way (vllm_i64_amd/ep.py)."""
         self.cfg, self.device = cfg, torch.device(device)
         dev = self.device
-        self.ep_layers = None
+        self.ep = None            # expert-parallel communication (ep.EPComm) or None
+        self.ep_e0 = self.ep_le = 0
         if expert_parallel and cfg.is_moe:
-            import torch.distributed as dist
             from . import ep as _ep
             self._ep = _ep
-            ep_rank = dist.get_rank(ep_group) if dist.is_initialized() else 0
-            ep_world = dist.get_world_size(ep_group) if dist.is_initialized() else 1
-            assert cfg.num_experts % ep_world == 0, "experts must divide over the ranks"
-            le = cfg.num_experts // ep_world
-            self.ep_layers = []
+            self.ep = _ep.EPComm(ep_group)
+            assert cfg.num_experts % self.ep.world == 0, "experts must divide over the ranks"
+            self.ep_le = cfg.num_experts // self.ep.world
+            self.ep_e0 = self.ep.rank * self.ep_le
         f = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
         self.embed = f(weights["embed"])
         self.final_norm = f(weights["final_norm"])
@@ -168,18 +177,12 @@ class I64MoEModel:
             p = f"l{l}."
             d = dict(ln1=f(weights[p + "ln1"]), ln2=f(weights[p + "ln2"]), q_norm=f(weights[p + "q_norm"]),
                      k_norm=f(weights[p + "k_norm"]), qkv=pack_per_tensor(weights[p + "qkv"], dev), o=pack_per_tensor(weights[p + "o"], dev))
-            if cfg.is_moe and self.ep_layers is not None:
-                local = {"exp_gate_up": weights[p + "exp_gate_up"][ep_rank * le:(ep_rank + 1) * le],
-                         "exp_down": weights[p + "exp_down"][ep_rank * le:(ep_rank + 1) * le]}
-                if cfg.shared_intermediate_size:
-                    local["sh_gate_up"], local["sh_down"] = weights[p + "sh_gate_up"], weights[p + "sh_down"]
-                table_l = weights[p + "table"].to(torch.int64).to(dev)
-                self.ep_layers.append(_ep.ExpertParallelMoE(cfg, table_l, _ep.HipBackend(cfg, local, dev), ep_group,
-                                                            shared_global_stats=False))
-                tables.append(weights[p + "table"].to(torch.int64))
-            elif cfg.is_moe:
-                d["exp_gu"] = pack_per_tensor(weights[p + "exp_gate_up"], dev)
-                d["exp_dn"] = pack_per_tensor(weights[p + "exp_down"], dev)
+            if cfg.is_moe:
+                # expert parallel: this rank's experts only (one quantization scale per expert matrix, so slicing commutes with
+                # packing); the shared expert, the attention projections and the routing tables are replicated
+                mine = slice(self.ep_e0, self.ep_e0 + self.ep_le) if self.ep is not None else slice(None)
+                d["exp_gu"] = pack_per_tensor(weights[p + "exp_gate_up"][mine], dev)
+                d["exp_dn"] = pack_per_tensor(weights[p + "exp_down"][mine], dev)
                 if cfg.shared_intermediate_size:
                     d["sh_gu"] = pack_per_tensor(weights[p + "sh_gate_up"], dev)
                     d["sh_dn"] = pack_per_tensor(weights[p + "sh_down"], dev)
@@ -197,7 +200,9 @@ class I64MoEModel:
         nb = num_kv_blocks or max_seqs * ((cfg.max_pos + cfg.kv_block - 1) // cfg.kv_block)
         self.kv = PagedKVCache(cfg, nb, max_seqs, dev, kv_dtype)
         self.nb = cfg.num_experts * cfg.top_k if cfg.is_moe else 0
-        self.spl = 4 + 2 * self.nb if cfg.is_moe else 4       # stat slots per layer
+        # stat slots per layer; the expert-parallel runner keeps one more: the shared expert's gate_up call is quantized over THIS
+        # rank's tokens (every rank an engine of its own for the dense calls), while slot 2 collects all ranks' rows
+        self.spl = (4 + 2 * self.nb + (1 if self.ep is not None else 0)) if cfg.is_moe else 4
         self.stats = ops.stats_alloc(self.spl * cfg.num_layers + 1, dev)
         self._bufs: Dict[tuple, _Buffers] = {}
         self.dec_sync = ops.decode_sync_alloc(dev)
@@ -206,7 +211,8 @@ class I64MoEModel:
     def buffers(self, n: int, n_logit_rows: int) -> _Buffers:
         key = (n, n_logit_rows)
         if key not in self._bufs:
-            self._bufs[key] = _Buffers(self.cfg, n, n_logit_rows, self.device)
+            self._bufs[key] = _Buffers(self.cfg, n, n_logit_rows, self.device, ep_world=self.ep.world if self.ep is not None else 0,
+                                       ep_exchange=self.ep is not None and self.ep.active)
         return self._bufs[key]
 
     FUSE_MAX_ROWS = 256  # up to this many operand rows the quantizer runs inside the GEMM (one launch per Linear call)
@@ -223,7 +229,7 @@ class I64MoEModel:
     def _tail_supported(self, n: int) -> bool:
         cfg = self.cfg
         H = cfg.hidden_size
-        if not (self.use_tail and self.ep_layers is None and 1 <= n <= self.TAIL_MAX_ROWS and cfg.head_dim == 64):
+        if not (self.use_tail and self.ep is None and 1 <= n <= self.TAIL_MAX_ROWS and cfg.head_dim == 64):
             return False
         if H % 64 or not 256 <= H <= 2048:
             return False
@@ -322,10 +328,13 @@ class I64MoEModel:
         eps = cfg.rms_eps
         fuse_rows = n <= self.FUSE_MAX_ROWS
         rw = cfg.route_weights
-        ep_plans = None
-        if self.ep_layers is not None:
-            ids_all, sizes = self.ep_layers[0].gather_ids(token_ids)
-            ep_plans = self._ep.build_plans(ids_all, self.tables, sizes, self.ep_layers[0].rank, cfg.num_experts)
+        if self.ep is not None:
+            # the routing is a pure function of the token id: every rank gathers every rank's ids once per step and derives the
+            # same global plan on the device (no count exchange, nothing returns to the host)
+            B.plan.run(self.ep.all_gather(token_ids), self.tables)
+            if self.ep.active:
+                B.row_map = self._ep.exchange_row_map(B.plan.perm, n, self.ep.world, cfg.top_k)
+                B.recv_map = self._ep.owner_row_map(B.plan.keys, n, self.ep.rank, self.ep.world, cfg.top_k, self.ep_le)
         elif cfg.is_moe:
             B.plan.run(token_ids, self.tables)
         ops.embedding(token_ids, self.embed, out=B.h, reset_stats=st)  # + the reset of the step's stat slots
@@ -379,8 +388,9 @@ class I64MoEModel:
             if splits == 1:
                 ops.rows_minmax(attn2d, st, slot_base=base + 1)
             # h += o_proj(attn) ; normed = ln2(h) ; statistics of the Linear call(s) that read normed
-            if ep_plans is not None:
-                ln2_slots, ln2_stats = None, None          # the expert-parallel layer gathers its own statistics
+            ln2_base = base + 2
+            if self.ep is not None:
+                ln2_slots, ln2_stats, ln2_base = None, st, base + spl - 1   # this rank's rows: the shared expert's call
             elif cfg.is_moe:
                 ln2_slots, ln2_stats = B.plan.tok_slots[l], st   # the shared call and every (route, expert) bucket call
             else:
@@ -388,21 +398,19 @@ class I64MoEModel:
             # (folding this residual + norm into the o projection through a last-arriving workgroup per row block was built and
             # measured: the tail's device-coherent round trip costs more than the kernel boundary it removes)
             self._linear(attn2d, W["o"], base + 1, B.xa, B.xs, B.o)
-            ops.fused_residual_norm(B.h, W["ln2"], eps, add=B.o, h_out=B.h, normed=B.normed, slots=ln2_slots, slot_base=base + 2,
+            ops.fused_residual_norm(B.h, W["ln2"], eps, add=B.o, h_out=B.h, normed=B.normed, slots=ln2_slots, slot_base=ln2_base,
                                     stats=ln2_stats)
-            if ep_plans is not None:
-                moe_out = self.ep_layers[l].forward(B.normed, None, plan=ep_plans[l])
-                nxt = self.layers[l + 1]["ln1"] if l + 1 < cfg.num_layers else self.final_norm
-                last = l + 1 == cfg.num_layers
-                ops.fused_residual_norm(B.h, nxt, eps, add=moe_out, h_out=B.h, normed=B.normed, slot_base=base + spl,
-                                        stats=None if last else st)
-            elif cfg.is_moe:
+            if cfg.is_moe:
                 if record is not None:
                     record[f"l{l}.mlp_in"] = B.normed.clone()
-                moe_inv = self._moe(B, W, l, base)
+                moe_rows, moe_inv = B.e_out, None
+                if self.ep is not None:
+                    moe_rows, moe_inv = self._moe_ep(B, W, l, base)
+                else:
+                    moe_inv = self._moe(B, W, l, base)
                 nxt = self.layers[l + 1]["ln1"] if l + 1 < cfg.num_layers else self.final_norm
                 last = l + 1 == cfg.num_layers
-                ops.fused_residual_norm(B.h, nxt, eps, moe_rows=B.e_out, moe_inv=moe_inv,
+                ops.fused_residual_norm(B.h, nxt, eps, moe_rows=moe_rows, moe_inv=moe_inv,
                                         moe_shared=B.sh_out if cfg.shared_intermediate_size else None, route_weights=rw,
                                         routed_scale=W["routed_scale"], shared_scale=W["shared_scale"], h_out=B.h, normed=B.normed,
                                         slot_base=base + spl, stats=None if last else st)
@@ -463,6 +471,49 @@ class I64MoEModel:
                  ops.ptr(st), ops.ptr(B.eia), ops.ptr(B.eis), 0, ops._stream())
         ops.gemm_i8(B.eia, B.eis, W["exp_dn"].w_q, W["exp_dn"].w_s, group_offsets=plan.expert_offsets[l], out=B.e_out)
         return plan.inv[l]
+
+    def _moe_ep(self, B: _Buffers, W: dict, l: int, base: int) -> torch.Tensor:
+        """Expert-parallel MoE layer (experts sharded over the ranks, reference: vllm_i64/layers/token_routed_i64/layer.py:227-292).
+        Every rank holds all ranks' MoE input rows after ONE all-gather and, from the global plan, runs ITS experts' buckets over
+        them - each (route, expert) bucket call sees all of its rows, so its per-call activation range is exact without any
+        statistics exchange.  The results go back through one fixed-shape all-to-all.  The shared expert runs on this rank's
+        tokens (a call of this rank's engine).  Returns (rows, map): the combine reads (route, token) row s at rows[map[s]]
+        (map None: rows already lie in that order)."""
+        cfg, st, nbk, ep = self.cfg, self.stats, self.nb, self.ep
+        plan, world = B.plan, self.ep.world
+        n, n_all, R = B.h.shape[0], plan.n, plan.rows
+        H, spl = cfg.hidden_size, self.spl
+        x_all = ep.all_gather(B.normed, out=B.normed_all) if ep.active else B.normed
+        # statistics of every bucket call over the rows of ALL ranks (relative slot 0 = slot base + 2 is not read in this mode)
+        ops.rows_minmax(x_all, st, slots=plan.tok_slots[l], slot_base=base + 2)
+        if cfg.shared_intermediate_size:
+            self._linear(B.normed, W["sh_gu"], base + spl - 1, B.xa, B.xs, B.sh_inter, epilogue=ops.EPI_SWIGLU, stats_slot=base + 3 + nbk)
+            self._linear(B.sh_inter, W["sh_dn"], base + 3 + nbk, B.sha, B.shs, B.sh_out)
+        eo = plan.expert_offsets[l][self.ep_e0: self.ep_e0 + self.ep_le + 1]   # row ranges of this rank's experts (device)
+        if not ep.active:
+            out_buf, c_map = B.e_out, plan.perm[l]
+        else:
+            out_buf, c_map = B.xsend.view(-1, H), B.row_map[l]                 # rows of other ranks' experts: never read
+        if R <= self.FUSE_MAX_ROWS:
+            e_gu = ops.gemm_desc(x_all, W["exp_gu"].w_q, W["exp_gu"].w_s, B.e_inter, a_src_row=plan.perm[l], a_src_mod=n_all,
+                                 a_row_slot=plan.sorted_bucket[l], a_slot_base=base + 3, group_offsets=eo, epilogue=ops.EPI_SWIGLU,
+                                 out_row_slot=plan.sorted_bucket[l], out_slot_base=base + 4 + nbk, stats=st, want_stats=True, m_total=R)
+            ops.gemm_i8_pair(e_gu)
+            e_dn = ops.gemm_desc(B.e_inter, W["exp_dn"].w_q, W["exp_dn"].w_s, out_buf, a_row_slot=plan.sorted_bucket[l],
+                                 a_slot_base=base + 4 + nbk, group_offsets=eo, stats=st, m_total=R, c_row_map=c_map)
+            ops.gemm_i8_pair(e_dn)
+        elif R > 0:
+            ops.call("i64h_quantize_dynamic", ops.ptr(x_all), R, H, ops.ptr(plan.perm[l]), n_all, ops.ptr(plan.sorted_bucket[l]),
+                     base + 3, ops.ptr(st), ops.ptr(B.ea), ops.ptr(B.es), 0, ops._stream())
+            ops.gemm_i8(B.ea, B.es, W["exp_gu"].w_q, W["exp_gu"].w_s, group_offsets=eo, epilogue=ops.EPI_SWIGLU,
+                        row_slot=plan.sorted_bucket[l], slot_base=base + 4 + nbk, stats=st, out=B.e_inter)
+            ops.call("i64h_quantize_dynamic", ops.ptr(B.e_inter), R, cfg.expert_inter, 0, 0, ops.ptr(plan.sorted_bucket[l]), base + 4 + nbk,
+                     ops.ptr(st), ops.ptr(B.eia), ops.ptr(B.eis), 0, ops._stream())
+            ops.gemm_i8_pair(ops.gemm_desc(B.eia, W["exp_dn"].w_q, W["exp_dn"].w_s, out_buf, row_scale=B.eis, group_offsets=eo, m_total=R,
+                                           c_row_map=c_map))
+        if not ep.active:
+            return B.e_out, None
+        return ep.exchange(B.xsend, recv=B.xrecv).view(-1, H), B.recv_map[l]
 
     # ---- stand-alone MoE layer (operator form of TokenRoutedMLP.forward) ----
     def moe_layer(self, l: int, x: torch.Tensor, token_ids: torch.Tensor) -> torch.Tensor:
