@@ -120,6 +120,10 @@ def main():
             args.gpus = world
         else:
             raise SystemExit(f"bench.py --gpus {args.gpus} inside a job of WORLD_SIZE {world}")
+    # stdout carries ONE line, the result: whatever libraries print there (collective library banners ...) goes to stderr
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     dist = None
@@ -340,9 +344,22 @@ def main():
         except Exception as e:  # the baseline is a reported extra; never lose the GPU line to it
             out["cpu_baseline"] = {"error": repr(e)}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    os.close(result_fd)
     if dist is not None:
+        # tear-down must never cost the result: captured graphs hold kernels of the collective library, so release them first,
+        # and leave without the orderly shutdown if that does not come back
+        import gc
+        import threading
+        threading.Timer(30.0, lambda: os._exit(0)).start()
+        for d in (dec,):
+            d.graph = None
+        model = dec = r_model = gm = None  # noqa: F841
+        gc.collect()
+        torch.cuda.synchronize()
+        dist.barrier()
         dist.destroy_process_group()
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -303,6 +303,11 @@ class ExpertParallelMoE:
 # ---------------------------------------------------------------------------------------------------------
 # fixed-shape exchange for whole-model expert parallelism (graph-capturable: no host-side split sizes)
 # ---------------------------------------------------------------------------------------------------------
+class _Done:
+    def wait(self):
+        return True
+
+
 class EPComm:
     """The two collectives of the whole-model expert-parallel runner (vllm_i64_amd.model.I64MoEModel(expert_parallel=True)),
     both of FIXED shape, so that a decode step with them can be captured into one HIP graph and needs no device-to-host
@@ -351,6 +356,15 @@ class EPComm:
             dist.all_gather_into_tensor(host, t.cpu(), group=self.group)
             out.copy_(host)
         return out
+
+    def all_gather_start(self, t: torch.Tensor, out: torch.Tensor):
+        """all_gather into `out`, not waited for: returns a handle whose wait() orders the CURRENT stream after the gather.
+        Kernels launched between the two run beside the collective (RCCL works on a stream of its own).  Staged / host paths
+        complete here and return a handle whose wait() does nothing."""
+        if self.active and self.direct and t.is_cuda:
+            return dist.all_gather_into_tensor(out, t.contiguous(), group=self.group, async_op=True)
+        self.all_gather(t, out=out)
+        return _Done()
 
     def exchange(self, send: torch.Tensor, recv: Optional[torch.Tensor] = None) -> torch.Tensor:
         """send [world, m, H] (block d = this rank's rows for rank d) -> recv [world, m, H] (block s = what rank s computed for

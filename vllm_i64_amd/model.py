@@ -102,9 +102,9 @@ class PagedKVCache:
 class _Buffers:
     """Per-step device buffers for N tokens (allocated once per N, reused: graph-safe)."""
 
-    def __init__(self, cfg: ModelConfig, n: int, n_logit_rows: int, device, ep_world: int = 0, ep_exchange: bool = False):
+    def __init__(self, cfg: ModelConfig, n: int, n_logit_rows: int, device, ep_world: int = 0):
         """ep_world > 0: expert-parallel runner - the routing plan and the expert-side buffers span the tokens of ALL ranks
-        (n_all = ep_world * n rows); ep_exchange: plus the fixed-shape exchange buffers."""
+        (n_all = ep_world * n rows), plus the fixed-shape exchange buffers."""
         H = cfg.hidden_size
         n_all = n * max(ep_world, 1)
         R = n_all * cfg.top_k
@@ -126,14 +126,15 @@ class _Buffers:
             self.e_inter = torch.empty(max(R, 1), ei, **f32)
             self.eia = torch.empty(max(R, 1), ei, **i8)
             self.eis = torch.empty(max(R, 1), **f32)
-            self.e_out = torch.empty(max(R, 1), H, **f32)
+            if not ep_world:
+                self.e_out = torch.empty(max(R, 1), H, **f32)
             if S:
                 self.sh_inter = torch.empty(n, S, **f32)
                 self.sha = torch.empty(n, S, **i8)
                 self.shs = torch.empty(n, **f32)
                 self.sh_out = torch.empty(n, H, **f32)
             self.plan = ops.MoePlan(n_all, cfg.top_k, cfg.num_experts, cfg.num_layers, device)
-            if ep_exchange:
+            if ep_world:
                 self.normed_all = torch.empty(n_all, H, **f32)
                 self.xsend = torch.empty(ep_world, cfg.top_k * n, H, **f32)   # block d: this rank's contribution to rank d's rows
                 self.xrecv = torch.empty(ep_world, cfg.top_k * n, H, **f32)
@@ -168,6 +169,8 @@ class I64MoEModel:
             assert cfg.num_experts % self.ep.world == 0, "experts must divide over the ranks"
             self.ep_le = cfg.num_experts // self.ep.world
             self.ep_e0 = self.ep.rank * self.ep_le
+            if not self.ep.active:   # one rank, nothing to exchange: the plain runner IS the expert-parallel runner
+                self.ep = None
         f = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
         self.embed = f(weights["embed"])
         self.final_norm = f(weights["final_norm"])
@@ -211,8 +214,7 @@ class I64MoEModel:
     def buffers(self, n: int, n_logit_rows: int) -> _Buffers:
         key = (n, n_logit_rows)
         if key not in self._bufs:
-            self._bufs[key] = _Buffers(self.cfg, n, n_logit_rows, self.device, ep_world=self.ep.world if self.ep is not None else 0,
-                                       ep_exchange=self.ep is not None and self.ep.active)
+            self._bufs[key] = _Buffers(self.cfg, n, n_logit_rows, self.device, ep_world=self.ep.world if self.ep is not None else 0)
         return self._bufs[key]
 
     FUSE_MAX_ROWS = 256  # up to this many operand rows the quantizer runs inside the GEMM (one launch per Linear call)
@@ -332,9 +334,8 @@ class I64MoEModel:
             # the routing is a pure function of the token id: every rank gathers every rank's ids once per step and derives the
             # same global plan on the device (no count exchange, nothing returns to the host)
             B.plan.run(self.ep.all_gather(token_ids), self.tables)
-            if self.ep.active:
-                B.row_map = self._ep.exchange_row_map(B.plan.perm, n, self.ep.world, cfg.top_k)
-                B.recv_map = self._ep.owner_row_map(B.plan.keys, n, self.ep.rank, self.ep.world, cfg.top_k, self.ep_le)
+            B.row_map = self._ep.exchange_row_map(B.plan.perm, n, self.ep.world, cfg.top_k)
+            B.recv_map = self._ep.owner_row_map(B.plan.keys, n, self.ep.rank, self.ep.world, cfg.top_k, self.ep_le)
         elif cfg.is_moe:
             B.plan.run(token_ids, self.tables)
         ops.embedding(token_ids, self.embed, out=B.h, reset_stats=st)  # + the reset of the step's stat slots
@@ -403,11 +404,10 @@ class I64MoEModel:
             if cfg.is_moe:
                 if record is not None:
                     record[f"l{l}.mlp_in"] = B.normed.clone()
-                moe_rows, moe_inv = B.e_out, None
                 if self.ep is not None:
                     moe_rows, moe_inv = self._moe_ep(B, W, l, base)
                 else:
-                    moe_inv = self._moe(B, W, l, base)
+                    moe_rows, moe_inv = B.e_out, self._moe(B, W, l, base)
                 nxt = self.layers[l + 1]["ln1"] if l + 1 < cfg.num_layers else self.final_norm
                 last = l + 1 == cfg.num_layers
                 ops.fused_residual_norm(B.h, nxt, eps, moe_rows=moe_rows, moe_inv=moe_inv,
@@ -477,23 +477,22 @@ class I64MoEModel:
         Every rank holds all ranks' MoE input rows after ONE all-gather and, from the global plan, runs ITS experts' buckets over
         them - each (route, expert) bucket call sees all of its rows, so its per-call activation range is exact without any
         statistics exchange.  The results go back through one fixed-shape all-to-all.  The shared expert runs on this rank's
-        tokens (a call of this rank's engine).  Returns (rows, map): the combine reads (route, token) row s at rows[map[s]]
-        (map None: rows already lie in that order)."""
+        tokens (a call of this rank's engine).  Returns (rows, map): the combine reads (route, token) row s at rows[map[s]]."""
         cfg, st, nbk, ep = self.cfg, self.stats, self.nb, self.ep
-        plan, world = B.plan, self.ep.world
+        plan = B.plan
         n, n_all, R = B.h.shape[0], plan.n, plan.rows
         H, spl = cfg.hidden_size, self.spl
-        x_all = ep.all_gather(B.normed, out=B.normed_all) if ep.active else B.normed
-        # statistics of every bucket call over the rows of ALL ranks (relative slot 0 = slot base + 2 is not read in this mode)
-        ops.rows_minmax(x_all, st, slots=plan.tok_slots[l], slot_base=base + 2)
+        # the gather of the MoE input rows runs beside the shared expert (this rank's rows only: independent of it)
+        pending = ep.all_gather_start(B.normed, B.normed_all)
         if cfg.shared_intermediate_size:
             self._linear(B.normed, W["sh_gu"], base + spl - 1, B.xa, B.xs, B.sh_inter, epilogue=ops.EPI_SWIGLU, stats_slot=base + 3 + nbk)
             self._linear(B.sh_inter, W["sh_dn"], base + 3 + nbk, B.sha, B.shs, B.sh_out)
+        pending.wait()
+        x_all = B.normed_all
+        # statistics of every bucket call over the rows of ALL ranks (relative slot 0 = slot base + 2 is not read in this mode)
+        ops.rows_minmax(x_all, st, slots=plan.tok_slots[l], slot_base=base + 2)
         eo = plan.expert_offsets[l][self.ep_e0: self.ep_e0 + self.ep_le + 1]   # row ranges of this rank's experts (device)
-        if not ep.active:
-            out_buf, c_map = B.e_out, plan.perm[l]
-        else:
-            out_buf, c_map = B.xsend.view(-1, H), B.row_map[l]                 # rows of other ranks' experts: never read
+        out_buf, c_map = B.xsend.view(-1, H), B.row_map[l]                     # rows of other ranks' experts: never read
         if R <= self.FUSE_MAX_ROWS:
             e_gu = ops.gemm_desc(x_all, W["exp_gu"].w_q, W["exp_gu"].w_s, B.e_inter, a_src_row=plan.perm[l], a_src_mod=n_all,
                                  a_row_slot=plan.sorted_bucket[l], a_slot_base=base + 3, group_offsets=eo, epilogue=ops.EPI_SWIGLU,
@@ -511,14 +510,13 @@ class I64MoEModel:
                      ops.ptr(st), ops.ptr(B.eia), ops.ptr(B.eis), 0, ops._stream())
             ops.gemm_i8_pair(ops.gemm_desc(B.eia, W["exp_dn"].w_q, W["exp_dn"].w_s, out_buf, row_scale=B.eis, group_offsets=eo, m_total=R,
                                            c_row_map=c_map))
-        if not ep.active:
-            return B.e_out, None
         return ep.exchange(B.xsend, recv=B.xrecv).view(-1, H), B.recv_map[l]
 
     # ---- stand-alone MoE layer (operator form of TokenRoutedMLP.forward) ----
     def moe_layer(self, l: int, x: torch.Tensor, token_ids: torch.Tensor) -> torch.Tensor:
         """out = TokenRoutedMLP_l(x, token_ids) with int8 dynamic Linears; x fp32 [N, H]."""
         cfg = self.cfg
+        assert self.ep is None, "the stand-alone layer call is the single-rank operator"
         n = x.shape[0]
         B = self.buffers(n, n)
         B.plan.run(token_ids, self.tables)
