@@ -351,7 +351,9 @@ def main():
         # and leave without the orderly shutdown if that does not come back
         import gc
         import threading
-        threading.Timer(30.0, lambda: os._exit(0)).start()
+        bail = threading.Timer(30.0, lambda: os._exit(0))
+        bail.daemon = True
+        bail.start()
         for d in (dec,):
             d.graph = None
         model = dec = r_model = gm = None  # noqa: F841
@@ -359,7 +361,7 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         dist.destroy_process_group()
-        os._exit(0)
+        bail.cancel()
 
 
 if __name__ == "__main__":

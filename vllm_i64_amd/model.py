@@ -482,26 +482,31 @@ class I64MoEModel:
         plan = B.plan
         n, n_all, R = B.h.shape[0], plan.n, plan.rows
         H, spl = cfg.hidden_size, self.spl
-        # the gather of the MoE input rows runs beside the shared expert (this rank's rows only: independent of it)
-        pending = ep.all_gather_start(B.normed, B.normed_all)
-        if cfg.shared_intermediate_size:
-            self._linear(B.normed, W["sh_gu"], base + spl - 1, B.xa, B.xs, B.sh_inter, epilogue=ops.EPI_SWIGLU, stats_slot=base + 3 + nbk)
-            self._linear(B.sh_inter, W["sh_dn"], base + 3 + nbk, B.sha, B.shs, B.sh_out)
-        pending.wait()
-        x_all = B.normed_all
+        # (issuing the gather asynchronously to run it beside the shared expert was measured: the cross-stream edges it puts
+        # into the captured graph cost more per layer than the overlap saves)
+        x_all = ep.all_gather(B.normed, out=B.normed_all)
+        shared = bool(cfg.shared_intermediate_size)
         # statistics of every bucket call over the rows of ALL ranks (relative slot 0 = slot base + 2 is not read in this mode)
         ops.rows_minmax(x_all, st, slots=plan.tok_slots[l], slot_base=base + 2)
         eo = plan.expert_offsets[l][self.ep_e0: self.ep_e0 + self.ep_le + 1]   # row ranges of this rank's experts (device)
         out_buf, c_map = B.xsend.view(-1, H), B.row_map[l]                     # rows of other ranks' experts: never read
         if R <= self.FUSE_MAX_ROWS:
+            # two launches, each with this rank's experts and its shared expert as the second problem
             e_gu = ops.gemm_desc(x_all, W["exp_gu"].w_q, W["exp_gu"].w_s, B.e_inter, a_src_row=plan.perm[l], a_src_mod=n_all,
                                  a_row_slot=plan.sorted_bucket[l], a_slot_base=base + 3, group_offsets=eo, epilogue=ops.EPI_SWIGLU,
                                  out_row_slot=plan.sorted_bucket[l], out_slot_base=base + 4 + nbk, stats=st, want_stats=True, m_total=R)
-            ops.gemm_i8_pair(e_gu)
+            s_gu = ops.gemm_desc(B.normed, W["sh_gu"].w_q, W["sh_gu"].w_s, B.sh_inter, a_slot_base=base + spl - 1, epilogue=ops.EPI_SWIGLU,
+                                 out_slot_base=base + 3 + nbk, stats=st, want_stats=True) if shared else None
+            ops.gemm_i8_pair(e_gu, s_gu)
             e_dn = ops.gemm_desc(B.e_inter, W["exp_dn"].w_q, W["exp_dn"].w_s, out_buf, a_row_slot=plan.sorted_bucket[l],
                                  a_slot_base=base + 4 + nbk, group_offsets=eo, stats=st, m_total=R, c_row_map=c_map)
-            ops.gemm_i8_pair(e_dn)
-        elif R > 0:
+            s_dn = ops.gemm_desc(B.sh_inter, W["sh_dn"].w_q, W["sh_dn"].w_s, B.sh_out, a_slot_base=base + 3 + nbk, stats=st) if shared else None
+            ops.gemm_i8_pair(e_dn, s_dn)
+            return ep.exchange(B.xsend, recv=B.xrecv).view(-1, H), B.recv_map[l]
+        if shared:
+            self._linear(B.normed, W["sh_gu"], base + spl - 1, B.xa, B.xs, B.sh_inter, epilogue=ops.EPI_SWIGLU, stats_slot=base + 3 + nbk)
+            self._linear(B.sh_inter, W["sh_dn"], base + 3 + nbk, B.sha, B.shs, B.sh_out)
+        if R > 0:
             ops.call("i64h_quantize_dynamic", ops.ptr(x_all), R, H, ops.ptr(plan.perm[l]), n_all, ops.ptr(plan.sorted_bucket[l]),
                      base + 3, ops.ptr(st), ops.ptr(B.ea), ops.ptr(B.es), 0, ops._stream())
             ops.gemm_i8(B.ea, B.es, W["exp_gu"].w_q, W["exp_gu"].w_s, group_offsets=eo, epilogue=ops.EPI_SWIGLU,
