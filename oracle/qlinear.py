@@ -21,8 +21,8 @@ restates that published algorithm in numpy:
   acc = sum_k (x_q - zp) * W_q   (int32, exact)
   y = float32(acc) * float32(float32(scale) * w_s)
 
-It is pinned by tests/test_oracle_qlinear.py against torch's own DynamicQuantizedLinear (the same
-call the reference makes) and by the golden vectors in tests/golden/ captured from the reference.
+It is pinned by tests/test_oracle_golden.py::test_qlinear_against_torch_dynamic_linear against torch's own
+DynamicQuantizedLinear (the same call the reference makes) and by the golden vectors in tests/golden/ captured from the reference.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
 """
