@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec
-MFMA_I8_PEAK_TOPS = 5000.0  # dense int8 MFMA peak (the datasheet's headline figure halved: it counts 2:1 sparsity)
+MFMA_I8_PEAK_TOPS = 5000.0  # dense int8 MFMA peak (the datasheet's headline figure halved: it counts 2:1 sparsity); dense fp8: the same
 PMC_PROFILE = "r02_pmc_traffic.json"  # HBM counter passes of the default command (tools/pmc_traffic.sh), under profiles/
 
 
@@ -54,6 +54,9 @@ def parse():
                     help="ep: the routed experts are sharded over the ranks (one all-gather of the MoE input rows and one all-to-all "
                          "of the expert rows per layer, RCCL) - the default with more than one GPU.  dp: every rank is an "
                          "independent replica (no data-path collective) - the default on one GPU")
+    ap.add_argument("--weights", default="int8", choices=["int8", "fp8"],
+                    help="int8: the CPU engine's dynamic int8 Linears (the headline configuration).  fp8: every Linear an fp8_linear "
+                         "(e4m3fn weights per output channel, e4m3fn activations per token) on the fp8 matrix cores")
     ap.add_argument("--no-replica-leg", action="store_true",
                     help="N > 1: skip the second, labelled measurement of independent replicas (reported beside the expert-parallel value)")
     return ap.parse_args()
@@ -74,8 +77,9 @@ def get_config(name):
     return {"trhash500m-synth": C.trhash500m_synth, "trmoe306-synth": C.trmoe306_synth, "dense306-synth": C.dense306_synth}[name]()
 
 
-def cpu_baseline(cfg, weights, batch, ctx, steps):
-    """The oracle's CPU engine (own model code + torch.ao dynamic int8 Linears = the reference's quantized kernels),
+def cpu_baseline(cfg, weights, batch, ctx, steps, mode="int8_torch"):
+    """The oracle's CPU engine (own model code + torch.ao dynamic int8 Linears = the reference's quantized kernels; for fp8
+    weights the branch the reference's fp8_linear takes on a CPU: weights dequantized at every call, fp32 GEMM),
     timed on this host's cores on a bounded sample: batch `batch`, context `ctx` (synthetic cache contents), `steps`
     decode steps after 1 warm-up.  kind = "port"."""
     from oracle import model_ref as M
@@ -84,7 +88,7 @@ def cpu_baseline(cfg, weights, batch, ctx, steps):
     torch.set_num_threads(ncores)
     ocfg = M.SynthConfig(**{f: getattr(cfg, f) for f in M.SynthConfig.__dataclass_fields__ if hasattr(cfg, f)})
     t0 = time.time()
-    eng = M.OracleEngine(ocfg, weights, mode="int8_torch", max_seqs=batch, num_blocks=batch * ((ctx + steps + 17) // 16 + 1))
+    eng = M.OracleEngine(ocfg, weights, mode=mode, max_seqs=batch, num_blocks=batch * ((ctx + steps + 17) // 16 + 1))
     g = torch.Generator().manual_seed(99)
     for s in range(batch):
         eng.kv.ensure(s, ctx + steps + 1)
@@ -152,14 +156,15 @@ def main():
         cfg = dataclasses.replace(cfg, max_pos=(need + 255) // 256 * 256)
     t0 = time.time()
     weights = synth.make_weights(cfg, seed=0)
-    ep_mode = cfg.is_moe and (args.parallelism == "ep" or (args.parallelism == "auto" and world > 1))
+    fp8 = args.weights == "fp8"
+    ep_mode = cfg.is_moe and not fp8 and (args.parallelism == "ep" or (args.parallelism == "auto" and world > 1))
     total_len = P + args.steps + args.warmup + 2
     ids = synth.make_token_ids(cfg, B * P, seed=7 + rank, zipf=args.zipf).view(B, P)
 
     def run_leg(expert_parallel: bool):
         """Build the runner, prefill (untimed; its own rate is reported), W warm-up steps, then exactly K timed steps bracketed
         by barrier + synchronize; the time is the maximum over the ranks."""
-        model = I64MoEModel(cfg, weights, device=dev, kv_dtype=kv_dtype, max_seqs=B, expert_parallel=expert_parallel)
+        model = I64MoEModel(cfg, weights, device=dev, kv_dtype=kv_dtype, max_seqs=B, expert_parallel=expert_parallel, quant=args.weights)
         dec = GreedyDecoder(model, B, use_graph=not args.no_graph)
         prefill_tps = fill_cache(model, dec)
         dec.prepare()  # buffer allocation and graph capture are set-up, not steps (no state advances)
@@ -253,7 +258,7 @@ def main():
     # --pmc WRITE_SIZE in runs of their own; FETCH_SIZE doubled, the gfx950 correction): a profiler cannot run inside this
     # process, so the figure is reported only when this run's workload is the one the passes were taken on
     traffic = None
-    this_workload = {"config": cfg.name, "batch": B, "prompt_len": P, "kv_dtype": args.kv_dtype, "steps": args.steps, "warmup": args.warmup,
+    this_workload = {"config": cfg.name, "weights": args.weights, "batch": B, "prompt_len": P, "kv_dtype": args.kv_dtype, "steps": args.steps, "warmup": args.warmup,
                      "splits": splits}
     try:
         with open(os.path.join(ROOT, "profiles", PMC_PROFILE)) as f:
@@ -293,13 +298,18 @@ def main():
         R = Bp.plan.rows
         Wg = gm.layers[0]["exp_gu"]
         a8 = torch.randint(-127, 128, (R, cfg.hidden_size), dtype=torch.int8, device=dev)
+        if fp8:  # any byte pattern but the two NaN codes
+            a8 = torch.randint(0, 0x7e, (R, cfg.hidden_size), dtype=torch.uint8, device=dev)
         rs = torch.rand(R, device=dev) * 1e-3
         o8 = torch.empty(R, cfg.expert_inter, device=dev)
         gevs = []
         for rep in range(12):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            ops.gemm_i8(a8, rs, Wg.w_q, Wg.w_s, group_offsets=Bp.plan.expert_offsets[0], epilogue=ops.EPI_SWIGLU, out=o8)
+            if fp8:
+                ops.gemm_fp8(a8, rs, Wg.w_q, Wg.w_s, o8, group_offsets=Bp.plan.expert_offsets[0], epilogue=ops.EPI_SWIGLU)
+            else:
+                ops.gemm_i8(a8, rs, Wg.w_q, Wg.w_s, group_offsets=Bp.plan.expert_offsets[0], epilogue=ops.EPI_SWIGLU, out=o8)
             e1.record()
             gevs.append((e0, e1))
         torch.cuda.synchronize()
@@ -307,8 +317,10 @@ def main():
         g_ms = sum(g_ms) / len(g_ms)
         g_ops = 2.0 * R * (2 * cfg.expert_inter) * cfg.hidden_size
         tops = g_ops / (g_ms * 1e-3) / 1e12
-        mfma = {"bound": "mfma", "kernel": "gemm_i8_rs_kernel<SWIGLU> grouped expert gate_up, one prefill chunk",
-                "achieved": round(tops, 1), "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s", "frac": round(tops / MFMA_I8_PEAK_TOPS, 4),
+        mfma = {"bound": "mfma", "kernel": ("gemm_fp8_kernel<SWIGLU> (v_mfma_f32_16x16x32_fp8_fp8: the non-scaled form, which runs at the bf16 "
+                                            "rate, half the peak below)" if fp8 else "gemm_i8_rs_kernel<SWIGLU>") +
+                " grouped expert gate_up, one prefill chunk",
+                "achieved": round(tops, 1), "peak": MFMA_I8_PEAK_TOPS, "unit": "TFLOP/s" if fp8 else "TOP/s", "frac": round(tops / MFMA_I8_PEAK_TOPS, 4),
                 "traffic": None, "avg_launch_ms": round(g_ms, 4), "algorithmic_ops_per_launch": g_ops, "rows": R,
                 "groups": cfg.num_experts, "N": 2 * cfg.expert_inter, "K": cfg.hidden_size}
         del a8, rs, o8
@@ -318,9 +330,11 @@ def main():
     out = {
         "metric": "decode tokens/sec tr-hash-moe-500m int8 batch64; % INT8-MFMA roofline", "value": round(value, 1), "unit": "tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "int8 (i8 x i8 -> i32 MFMA, fp32 rescale; fp32 attention math)",
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": ("fp8 (e4m3 x e4m3 -> fp32 MFMA, fp32 rescale; fp32 attention math)" if fp8 else
+                  "int8 (i8 x i8 -> i32 MFMA, fp32 rescale; fp32 attention math)"),
         "data": "synthetic",
-        "config": {"workload": f"{cfg.name} int8 dynamic-Linear forward, batch {B} per GPU, {P}-token prompts"
+        "config": {"workload": f"{cfg.name} {'fp8-Linear (e4m3fn weights and activations)' if fp8 else 'int8 dynamic-Linear'} forward, batch {B} per GPU, {P}-token prompts"
                                f"{' (synthetic KV)' if args.synthetic_kv else ' (real prefill)'} + greedy decode, KV cache {args.kv_dtype}",
                    "global_batch": B * world, "seq_len": P,
                    "parallelism": (f"ep{world} (experts sharded over the ranks; per MoE layer one all-gather of the input rows and one "
@@ -339,7 +353,7 @@ def main():
     out["setup_s"] = round(t_setup, 1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(cfg, weights, B, args.cpu_ctx, args.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(cfg, weights, B, args.cpu_ctx, args.cpu_steps, "fp8_dequant" if fp8 else "int8_torch")
             out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 2)
         except Exception as e:  # the baseline is a reported extra; never lose the GPU line to it
             out["cpu_baseline"] = {"error": repr(e)}

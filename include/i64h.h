@@ -170,6 +170,12 @@ int i64h_quantize_fp8_rows(const float* x, int64_t rows, int64_t K, uint8_t* q, 
  * matrix.  epilogue 0: C fp32 [M, N]; 1: C fp32 [M, N / 2] = silu(C[:, :N/2]) * C[:, N/2:]. */
 int i64h_gemm_fp8(const uint8_t* A, const float* a_scale, const uint8_t* B, const float* b_scale, const int32_t* group_offsets,
                   int32_t num_groups, int64_t M, int32_t N, int32_t K, float* C, int32_t epilogue, void* stream);
+/* The same product with the row moves of the token-routed layer folded in (the boolean-mask gather and the scatter back of
+ * token_routed_mlp.py:136-151): operand row of output row r = A[a_src_row[r] % a_src_mod] (a_src_row NULL: r), output row r
+ * stored at row c_row_map[r] (NULL: r). */
+int i64h_gemm_fp8_ex(const uint8_t* A, const float* a_scale, const int32_t* a_src_row, int32_t a_src_mod, const uint8_t* B,
+                     const float* b_scale, const int32_t* group_offsets, int32_t num_groups, int64_t M, int32_t N, int32_t K, float* C,
+                     const int32_t* c_row_map, int32_t epilogue, void* stream);
 
 /* ---- one MoE layer behind one call --------------------------------------------------------------------------------------
  * out[n, H] = TokenRoutedMLP(x, token_ids) of the int8 CPU engine: routes = table[:, clamp(ids)], every (route, expert)

@@ -177,7 +177,10 @@ class LinearBank:
     """Holds every Linear of the model in the chosen back end; call as bank(name, x)."""
 
     def __init__(self, weights: Dict[str, torch.Tensor], mode: str, record: Optional[dict] = None):
-        assert mode in ("fp32", "int8", "int8_torch")
+        # "fp8": every Linear the torch._scaled_mm branch of fp8_linear (vllm_i64/core/fp8.py:169-193) restated - weights e4m3fn
+        # with one scale per output channel (quantize_fp8, fp8.py:77-110), activations e4m3fn per token; "fp8_dequant": the
+        # branch the reference takes on hardware its SM89 gate refuses (fp8.py:163-167) - the same weights dequantized, fp32 GEMM
+        assert mode in ("fp32", "int8", "int8_torch", "fp8", "fp8_dequant")
         self.mode = mode
         self.record = record
         self.w = weights
@@ -215,9 +218,21 @@ class LinearBank:
             self._mods[k] = qm[0]
         return self._mods[k]
 
+    def fp8_weight(self, name: str, idx: Optional[int] = None):
+        """(e4m3fn [N, K], fp32 scale [N]) of one Linear weight."""
+        from oracle import ops_ref as O
+        k = self._key(name, idx)
+        if k not in self._q:
+            self._q[k] = O.quantize_fp8_rows(self._weight(name, idx))
+        return self._q[k]
+
     def __call__(self, name: str, x: torch.Tensor, idx: Optional[int] = None, tag: Optional[str] = None):
         if self.mode == "fp32":
             return F.linear(x, self._weight(name, idx))
+        if self.mode in ("fp8", "fp8_dequant"):
+            from oracle import ops_ref as O
+            fn = O.fp8_linear_scaled_mm if self.mode == "fp8" else O.fp8_linear_dequant
+            return fn(x, *self.fp8_weight(name, idx))
         if self.mode == "int8_torch":
             return self._torch_mod(name, idx)(x)
         wq, ws = self.quantized(name, idx)

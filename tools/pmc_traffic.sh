@@ -24,7 +24,7 @@ json.dump(res, open("$OUT/summary.json", "w"), indent=1)
 line = [l for l in open("$OUT/fetch.log") if l.startswith("{")][-1]
 b = json.loads(line)
 import re
-wl = {"config": b["config"]["workload"].split(" ")[0], "batch": b["config"]["global_batch"], "prompt_len": b["config"]["seq_len"],
+wl = {"config": b["config"]["workload"].split(" ")[0], "weights": "fp8" if "fp8-Linear" in b["config"]["workload"] else "int8", "batch": b["config"]["global_batch"], "prompt_len": b["config"]["seq_len"],
       "kv_dtype": b["config"]["kv_dtype"], "steps": b["steps"], "warmup": b["warmup"], "splits": b["roofline"]["splits"]}
 out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over `python3 bench.py --no-cpu-baseline "
                "--no-graph` on MI355X; values are KB per launch (mean of the last 24 launches = the last decode step). gfx950 correction: "

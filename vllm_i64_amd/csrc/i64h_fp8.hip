@@ -37,9 +37,10 @@ __global__ __launch_bounds__(256) void quantize_fp8_rows_kernel(const float* __r
 
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_fp8_kernel(const uint8_t* __restrict__ A, const float* __restrict__ a_scale,
+                                                       const int32_t* __restrict__ a_src_row, int a_src_mod,
                                                        const uint8_t* __restrict__ B, const float* __restrict__ b_scale,
                                                        const int32_t* __restrict__ group_off, int G, int M, int N, int K,
-                                                       float* __restrict__ C) {
+                                                       float* __restrict__ C, const int32_t* __restrict__ c_row_map) {
     __shared__ __attribute__((aligned(16))) char smem[2 * (F8_BM + F8_BN) * F8_LD];
     __shared__ int s_info[4];
     constexpr int STAGE = (F8_BM + F8_BN) * F8_LD;
@@ -73,7 +74,9 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(const uint8_t* __restrict
     for (int i = 0; i < 2; ++i) {
         const int r = ld_r + 32 * i;
         aok[i] = r < rows;
-        ap[i] = A + (int64_t)(row0 + (aok[i] ? r : 0)) * K + ld_c * 16;
+        int64_t arow = row0 + (aok[i] ? r : 0);
+        if (a_src_row) arow = a_src_row[arow] % a_src_mod;  // operand rows gathered (expert buckets out of the token rows)
+        ap[i] = A + arow * K + ld_c * 16;
         int col;
         if (EPI) {  // tile row -> gate column or its up partner: fragments 0 / 1 of a wave are gate / up of the same 16 outputs
             const int j = nt * (F8_BN / 2) + (r >> 5) * 16 + (r & 15);
@@ -136,19 +139,20 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(const uint8_t* __restrict
         for (int reg = 0; reg < 4; ++reg) {
             const int r = wm * 32 + i * 16 + fq * 4 + reg;
             if (r >= rows) continue;
-            const float as = a_scale[row0 + r];
+            const float as = a_scale[a_src_row ? a_src_row[row0 + r] % a_src_mod : row0 + r];
+            const int64_t crow = c_row_map ? c_row_map[row0 + r] : row0 + r;
             if (EPI) {
                 const int c = nt * (F8_BN / 2) + wn * 16 + fr;
                 if (c < I) {
                     const float gate = acc[i][0][reg] * (as * b_scale[(int64_t)g * N + c]);
                     const float up = acc[i][1][reg] * (as * b_scale[(int64_t)g * N + I + c]);
-                    C[(int64_t)(row0 + r) * I + c] = (gate / (1.0f + expf(-gate))) * up;
+                    C[crow * I + c] = (gate / (1.0f + expf(-gate))) * up;
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int c = nt * F8_BN + wn * 32 + j * 16 + fr;
-                    if (c < N) C[(int64_t)(row0 + r) * N + c] = acc[i][j][reg] * (as * b_scale[(int64_t)g * N + c]);
+                    if (c < N) C[crow * N + c] = acc[i][j][reg] * (as * b_scale[(int64_t)g * N + c]);
                 }
             }
         }
@@ -165,26 +169,34 @@ int i64h_quantize_fp8_rows(const float* x, int64_t rows, int64_t K, uint8_t* q, 
     return 0;
 }
 
-// A e4m3fn [M, K] with a_scale [M]; B e4m3fn [G][N][K] with b_scale [G][N]; group_offsets [G + 1] (device) or NULL (G = 1).
-// epilogue 0: C fp32 [M, N]; 1: C fp32 [M, N / 2] = silu(C[:, :N/2]) * C[:, N/2:]
-int i64h_gemm_fp8(const uint8_t* A, const float* a_scale, const uint8_t* B, const float* b_scale, const int32_t* group_offsets,
-                  int32_t num_groups, int64_t M, int32_t N, int32_t K, float* C, int32_t epilogue, void* stream) {
+// A e4m3fn [*, K] with a_scale [*]; B e4m3fn [G][N][K] with b_scale [G][N]; group_offsets [G + 1] (device) or NULL (G = 1).
+// a_src_row (optional): operand row of output row r is A[a_src_row[r] % a_src_mod] (and its scale); c_row_map (optional):
+// output row r is stored at row c_row_map[r].  epilogue 0: C fp32 [M, N]; 1: C fp32 [M, N / 2] = silu(C[:, :N/2]) * C[:, N/2:]
+int i64h_gemm_fp8_ex(const uint8_t* A, const float* a_scale, const int32_t* a_src_row, int32_t a_src_mod, const uint8_t* B,
+                     const float* b_scale, const int32_t* group_offsets, int32_t num_groups, int64_t M, int32_t N, int32_t K, float* C,
+                     const int32_t* c_row_map, int32_t epilogue, void* stream) {
     I64H_CHECK_ARG(M >= 0 && M < (1ll << 31) && N > 0 && K > 0 && K % 16 == 0, "gemm_fp8: bad sizes (K=%d must be a multiple of 16)", K);
     I64H_CHECK_ARG(((uintptr_t)A | (uintptr_t)B) % 16 == 0, "gemm_fp8: operands must be 16-byte aligned");
     I64H_CHECK_ARG(num_groups >= 1 && num_groups <= 256 && (group_offsets != nullptr || num_groups == 1), "gemm_fp8: bad grouping");
     I64H_CHECK_ARG(epilogue == 0 || (epilogue == 1 && N % 2 == 0), "gemm_fp8: bad epilogue %d / N=%d", epilogue, N);
+    I64H_CHECK_ARG(a_src_row == nullptr || a_src_mod > 0, "gemm_fp8: a_src_row needs a_src_mod > 0");
     if (M == 0) return 0;
     const int G = group_offsets ? num_groups : 1;
     const int n_tiles = epilogue ? (N / 2 + F8_BN / 2 - 1) / (F8_BN / 2) : (N + F8_BN - 1) / F8_BN;
     const int m_tiles = (int)((M + F8_BM - 1) / F8_BM) + G;
     if (epilogue)
-        hipLaunchKernelGGL(gemm_fp8_kernel<1>, dim3((unsigned)(m_tiles * n_tiles)), dim3(256), 0, (hipStream_t)stream, A, a_scale, B, b_scale,
-                           group_offsets, G, (int)M, N, K, C);
+        hipLaunchKernelGGL(gemm_fp8_kernel<1>, dim3((unsigned)(m_tiles * n_tiles)), dim3(256), 0, (hipStream_t)stream, A, a_scale, a_src_row,
+                           a_src_mod, B, b_scale, group_offsets, G, (int)M, N, K, C, c_row_map);
     else
-        hipLaunchKernelGGL(gemm_fp8_kernel<0>, dim3((unsigned)(m_tiles * n_tiles)), dim3(256), 0, (hipStream_t)stream, A, a_scale, B, b_scale,
-                           group_offsets, G, (int)M, N, K, C);
+        hipLaunchKernelGGL(gemm_fp8_kernel<0>, dim3((unsigned)(m_tiles * n_tiles)), dim3(256), 0, (hipStream_t)stream, A, a_scale, a_src_row,
+                           a_src_mod, B, b_scale, group_offsets, G, (int)M, N, K, C, c_row_map);
     I64H_CHECK_LAUNCH();
     return 0;
+}
+
+int i64h_gemm_fp8(const uint8_t* A, const float* a_scale, const uint8_t* B, const float* b_scale, const int32_t* group_offsets,
+                  int32_t num_groups, int64_t M, int32_t N, int32_t K, float* C, int32_t epilogue, void* stream) {
+    return i64h_gemm_fp8_ex(A, a_scale, nullptr, 0, B, b_scale, group_offsets, num_groups, M, N, K, C, nullptr, epilogue, stream);
 }
 
 }  // extern "C"

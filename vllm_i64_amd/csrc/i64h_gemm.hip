@@ -615,6 +615,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 #define SK_AREA_MIN 4096  // >= 2 * I64H_STAT_TAB * 4 (statistics table) and >= 16 * 64 * 4 (head tile)
 static_assert(SK_AREA_MIN >= 2 * I64H_STAT_TAB * 4 && SK_AREA_MIN >= 16 * 64 * 4, "epilogue scratch of the decode-sized kernel");
 
+__host__ __device__ __forceinline__ int sk_pad_tiles(int n_tiles) { return n_tiles >= 6 ? (n_tiles + 7) & ~7 : n_tiles; }
+
 template <int EPI, int NW>
 __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const int bid, char* smem, const RowTailArgs& ta) {
     constexpr int NF = (EPI == EPI_SWIGLU) ? 2 : 1;  // B fragments per wave per step
@@ -631,8 +633,11 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
 
     const int nout = (EPI == EPI_SWIGLU) ? p.N / 2 : p.N;
     constexpr int BNB = NW * 16, NT = NW * 64;  // output columns / threads per workgroup
-    const int n_tiles = (nout + BNB - 1) / BNB;
-    const int mt = bid / n_tiles, nt = bid % n_tiles;
+    // workgroups are dealt to the 8 XCDs round-robin and every XCD has an L2 of its own: with the column-tile count padded to a
+    // multiple of 8, the row tiles that stream the same weight slice run on ONE XCD and the slice crosses the fabric once
+    const int n_tiles = (nout + BNB - 1) / BNB, n_pad = sk_pad_tiles(n_tiles);
+    const int mt = bid / n_pad, nt = bid % n_pad;
+    if (nt >= n_tiles) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 #define SK_STAMP(i) do { if (p.stamps && tid == 0) p.stamps[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     SK_STAMP(0);
@@ -1198,7 +1203,7 @@ static int skinny_blocks(const i64h_gemm_desc* d, int bnb) {
     const int G = d->group_offsets ? d->num_groups : 1;
     const int nout = d->epilogue == EPI_SWIGLU ? d->N / 2 : d->N;
     const int m_tiles = (int)((d->M_total + SK_BM - 1) / SK_BM) + G;
-    return d->M_total == 0 ? 0 : m_tiles * ((nout + bnb - 1) / bnb);
+    return d->M_total == 0 ? 0 : m_tiles * sk_pad_tiles((nout + bnb - 1) / bnb);
 }
 
 static int g_skinny_waves = 0;  // 0 = default; test/tuning override through i64h_set_skinny_waves

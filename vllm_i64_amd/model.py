@@ -59,6 +59,23 @@ def rope_table(max_pos: int, head_dim: int, theta: float) -> torch.Tensor:
     return torch.cat([freqs.cos(), freqs.sin()], dim=-1).contiguous()
 
 
+class PackedFp8:
+    """One Linear weight (or a stack of them) as e4m3fn bytes [G, N, K] + one fp32 scale per output channel [G, N]
+    (quantize_fp8 / quantize_experts_fp8 on the nn.Linear layout, vllm_i64/core/fp8.py:77-110,256-283)."""
+
+    def __init__(self, w_q: torch.Tensor, w_s: torch.Tensor):
+        self.w_q, self.w_s, self.G = w_q, w_s, w_q.shape[0]
+
+
+def pack_fp8(w: torch.Tensor, device) -> PackedFp8:
+    w = w.to(device=device, dtype=torch.float32)
+    if w.dim() == 2:
+        w = w.unsqueeze(0)
+    G, N, K = w.shape
+    q, s = ops.quantize_fp8_rows(w.reshape(G * N, K).contiguous())
+    return PackedFp8(q.view(G, N, K), s.view(G, N))
+
+
 # ---------------------------------------------------------------------------------------------------------
 # paged KV cache: reference layout (num_blocks, 16, kv_heads, head_dim) + int32 block table (core/kv_cache.py:84-107)
 # ---------------------------------------------------------------------------------------------------------
@@ -104,7 +121,8 @@ class _Buffers:
 
     def __init__(self, cfg: ModelConfig, n: int, n_logit_rows: int, device, ep_world: int = 0):
         """ep_world > 0: expert-parallel runner - the routing plan and the expert-side buffers span the tokens of ALL ranks
-        (n_all = ep_world * n rows), plus the fixed-shape exchange buffers."""
+        (n_all = ep_world * n rows), plus the fixed-shape exchange buffers.  The 8-bit operand buffers (xa, ea, eia, sha, da)
+        hold int8 codes or e4m3fn bytes, whichever the runner's Linears use."""
         H = cfg.hidden_size
         n_all = n * max(ep_world, 1)
         R = n_all * cfg.top_k
@@ -154,12 +172,20 @@ class _Buffers:
 
 class I64MoEModel:
     def __init__(self, cfg: ModelConfig, weights: Dict[str, torch.Tensor], device="cuda:0", kv_dtype=torch.float32,
-                 max_seqs: int = 64, num_kv_blocks: Optional[int] = None, expert_parallel: bool = False, ep_group=None):
-        """expert_parallel: the routed experts are sharded over the ranks of ep_group (one process per GPU); every rank keeps
+                 max_seqs: int = 64, num_kv_blocks: Optional[int] = None, expert_parallel: bool = False, ep_group=None,
+                 quant: str = "int8"):
+        """quant: "int8" - every Linear in the CPU engine's dynamic int8 scheme (per-call 7-bit activations, one weight scale per
+        fused matrix); "fp8" - every Linear an fp8_linear (vllm_i64/core/fp8.py:137-194): e4m3fn weights with one scale per
+        output channel, e4m3fn activations per token, fp32 accumulation on the fp8 matrix cores.
+        expert_parallel: the routed experts are sharded over the ranks of ep_group (one process per GPU); every rank keeps
         its own sequences, attention, dense projections and shared expert (an engine of its own for those calls), and each MoE
         layer exchanges the routed rows with one all-to-all each way (vllm_i64_amd/ep.py)."""
         self.cfg, self.device = cfg, torch.device(device)
         dev = self.device
+        assert quant in ("int8", "fp8")
+        self.quant = quant
+        assert not (quant == "fp8" and expert_parallel), "the expert-parallel runner is built for the int8 scheme"
+        pack = pack_per_tensor if quant == "int8" else pack_fp8
         self.ep = None            # expert-parallel communication (ep.EPComm) or None
         self.ep_e0 = self.ep_le = 0
         if expert_parallel and cfg.is_moe:
@@ -179,20 +205,20 @@ class I64MoEModel:
         for l in range(cfg.num_layers):
             p = f"l{l}."
             d = dict(ln1=f(weights[p + "ln1"]), ln2=f(weights[p + "ln2"]), q_norm=f(weights[p + "q_norm"]),
-                     k_norm=f(weights[p + "k_norm"]), qkv=pack_per_tensor(weights[p + "qkv"], dev), o=pack_per_tensor(weights[p + "o"], dev))
+                     k_norm=f(weights[p + "k_norm"]), qkv=pack(weights[p + "qkv"], dev), o=pack(weights[p + "o"], dev))
             if cfg.is_moe:
                 # expert parallel: this rank's experts only (one quantization scale per expert matrix, so slicing commutes with
                 # packing); the shared expert, the attention projections and the routing tables are replicated
                 mine = slice(self.ep_e0, self.ep_e0 + self.ep_le) if self.ep is not None else slice(None)
-                d["exp_gu"] = pack_per_tensor(weights[p + "exp_gate_up"][mine], dev)
-                d["exp_dn"] = pack_per_tensor(weights[p + "exp_down"][mine], dev)
+                d["exp_gu"] = pack(weights[p + "exp_gate_up"][mine], dev)
+                d["exp_dn"] = pack(weights[p + "exp_down"][mine], dev)
                 if cfg.shared_intermediate_size:
-                    d["sh_gu"] = pack_per_tensor(weights[p + "sh_gate_up"], dev)
-                    d["sh_dn"] = pack_per_tensor(weights[p + "sh_down"], dev)
+                    d["sh_gu"] = pack(weights[p + "sh_gate_up"], dev)
+                    d["sh_dn"] = pack(weights[p + "sh_down"], dev)
                 tables.append(weights[p + "table"].to(torch.int64))
             else:
-                d["gu"] = pack_per_tensor(weights[p + "gate_up"], dev)
-                d["dn"] = pack_per_tensor(weights[p + "down"], dev)
+                d["gu"] = pack(weights[p + "gate_up"], dev)
+                d["dn"] = pack(weights[p + "down"], dev)
             # output scales of the MoE combine: the configured ones, or this layer's learned scalar gates
             # (layers/token_routed_mlp.py:174-183)
             d["routed_scale"] = float(weights[p + "routed_gate"]) if p + "routed_gate" in weights else cfg.routed_scale
@@ -320,6 +346,9 @@ class I64MoEModel:
         cfg, st = self.cfg, self.stats
         kvc = kv if kv is not None else self.kv
         n = token_ids.numel()
+        if self.quant == "fp8":
+            assert inject is None, "teacher forcing is a facility of the int8 runner"
+            return self._forward_fp8(token_ids, positions, slot_ids, ctx_len, logit_rows, kvc, record, max_ctx_hint, rows_are_slots)
         if positions.device.type != "cuda" and n:  # host positions: check them (device positions are the caller's contract:
             # GreedyDecoder and EngineModel bound them on the host)
             if int(positions.max()) >= cfg.max_pos or int(positions.max()) // kvc.k[0].shape[1] >= kvc.block_table.shape[1]:
@@ -427,6 +456,77 @@ class I64MoEModel:
                                         stats=None if last else st)
                 if record is not None:
                     record[f"l{l}.out"] = B.h.clone()
+        ops.call("i64h_gemm_f32", ops.ptr(B.normed), ops.ptr(logit_rows), ops.ptr(self.embed), ops.ptr(B.logits), B.logits.shape[0],
+                 cfg.vocab_size, H, ops._stream())
+        return B.logits
+
+    def _forward_fp8(self, token_ids, positions, slot_ids, ctx_len, logit_rows, kvc, record, max_ctx_hint, rows_are_slots):
+        """The forward with every Linear an fp8_linear (vllm_i64/core/fp8.py:137-194, its torch._scaled_mm branch): activations are
+        quantized per token, so no call-wide statistics exist and the expert rows need no per-bucket treatment - one
+        quantization of the normalised rows serves the shared expert and, gathered inside the GEMM, every routed expert."""
+        cfg = self.cfg
+        n = token_ids.numel()
+        if positions.device.type != "cuda" and n:
+            if int(positions.max()) >= cfg.max_pos or int(positions.max()) // kvc.k[0].shape[1] >= kvc.block_table.shape[1]:
+                raise ValueError(f"position {int(positions.max())} outside the rotary table ({cfg.max_pos}) or the block table")
+            positions = positions.to(device=self.device, dtype=torch.int32)
+        B = self.buffers(n, logit_rows.numel() if logit_rows is not None else n)
+        H, eps, rw = cfg.hidden_size, cfg.rms_eps, cfg.route_weights
+        if cfg.is_moe:
+            B.plan.run(token_ids, self.tables)
+        ops.embedding(token_ids, self.embed, out=B.h)
+        splits = 1
+        if max_ctx_hint >= 256 and n <= 256:
+            splits = max(1, min(32, self.attn_target_wgs // n, max_ctx_hint // 64))
+        if splits > 1 and (B.attn_ws is None or B.attn_splits != splits):
+            B.attn_ws = ops.attn_workspace(n, cfg.num_heads, cfg.head_dim, splits, self.device)
+            B.attn_splits = splits
+        ops.fused_residual_norm(B.h, self.layers[0]["ln1"], eps, h_out=B.h, normed=B.normed)
+        S = cfg.shared_intermediate_size if cfg.is_moe else 0
+        for l, W in enumerate(self.layers):
+            if record is not None:
+                record[f"l{l}.in"] = B.h.clone()
+            ops.quantize_fp8_rows(B.normed, B.xa, B.xs)
+            ops.gemm_fp8(B.xa, B.xs, W["qkv"].w_q, W["qkv"].w_s, B.qkv)
+            ops.qk_norm_rope_kv(B.qkv, W["q_norm"], W["k_norm"], 1e-6, self.rope, positions, slot_ids, kvc.block_table,
+                                kvc.k[l], kvc.v[l], cfg.num_heads, cfg.num_kv_heads, cfg.head_dim, q_out=B.q)
+            ops.paged_attn(B.q, kvc.k[l], kvc.v[l], kvc.block_table, ctx_len, slot_ids=None if rows_are_slots else slot_ids,
+                           softmax_scale=1.0 / math.sqrt(cfg.head_dim), splits=splits, out=B.attn, workspace=B.attn_ws)
+            attn2d = B.attn.view(n, H)
+            if record is not None:
+                record[f"l{l}.attn_out"] = attn2d.clone()
+            ops.quantize_fp8_rows(attn2d, B.xa, B.xs)
+            ops.gemm_fp8(B.xa, B.xs, W["o"].w_q, W["o"].w_s, B.o)
+            ops.fused_residual_norm(B.h, W["ln2"], eps, add=B.o, h_out=B.h, normed=B.normed)
+            if record is not None:
+                record[f"l{l}.mlp_in"] = B.normed.clone()
+            ops.quantize_fp8_rows(B.normed, B.xa, B.xs)
+            nxt = self.layers[l + 1]["ln1"] if l + 1 < cfg.num_layers else self.final_norm
+            if cfg.is_moe:
+                plan = B.plan
+                R = plan.rows
+                if R:
+                    # rows in bucket order are grouped by expert; the gather out of the token rows and the scatter back into
+                    # (route, token) order ride in the GEMMs
+                    ops.gemm_fp8(B.xa, B.xs, W["exp_gu"].w_q, W["exp_gu"].w_s, B.e_inter, m=R, a_src_row=plan.perm[l], a_src_mod=n,
+                                 group_offsets=plan.expert_offsets[l], epilogue=ops.EPI_SWIGLU)
+                    ops.quantize_fp8_rows(B.e_inter, B.eia, B.eis)
+                    ops.gemm_fp8(B.eia, B.eis, W["exp_dn"].w_q, W["exp_dn"].w_s, B.e_out, group_offsets=plan.expert_offsets[l],
+                                 c_row_map=plan.perm[l])
+                if S:
+                    ops.gemm_fp8(B.xa, B.xs, W["sh_gu"].w_q, W["sh_gu"].w_s, B.sh_inter, epilogue=ops.EPI_SWIGLU)
+                    ops.quantize_fp8_rows(B.sh_inter, B.sha, B.shs)
+                    ops.gemm_fp8(B.sha, B.shs, W["sh_dn"].w_q, W["sh_dn"].w_s, B.sh_out)
+                ops.fused_residual_norm(B.h, nxt, eps, moe_rows=B.e_out, moe_inv=None, moe_shared=B.sh_out if S else None,
+                                        route_weights=rw, routed_scale=W["routed_scale"], shared_scale=W["shared_scale"], h_out=B.h,
+                                        normed=B.normed)
+            else:
+                ops.gemm_fp8(B.xa, B.xs, W["gu"].w_q, W["gu"].w_s, B.d_inter, epilogue=ops.EPI_SWIGLU)
+                ops.quantize_fp8_rows(B.d_inter, B.da, B.ds)
+                ops.gemm_fp8(B.da, B.ds, W["dn"].w_q, W["dn"].w_s, B.d_out)
+                ops.fused_residual_norm(B.h, nxt, eps, add=B.d_out, h_out=B.h, normed=B.normed)
+            if record is not None:
+                record[f"l{l}.out"] = B.h.clone()
         ops.call("i64h_gemm_f32", ops.ptr(B.normed), ops.ptr(logit_rows), ops.ptr(self.embed), ops.ptr(B.logits), B.logits.shape[0],
                  cfg.vocab_size, H, ops._stream())
         return B.logits

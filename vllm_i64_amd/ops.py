@@ -234,6 +234,31 @@ def gemm_i8_pair(a_desc, b_desc=None):
     call("i64h_gemm_i8_pair", ctypes.addressof(a_desc), ctypes.addressof(b_desc) if b_desc is not None else 0, _stream())
 
 
+def quantize_fp8_rows(x: torch.Tensor, q: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None):
+    """Per-row e4m3fn quantization (quantize_fp8 / quantize_activations_fp8, vllm_i64/core/fp8.py:77-130): (bytes [rows, K], scale [rows])."""
+    _chk(x, torch.float32, "x")
+    rows, K = x.shape
+    if q is None:
+        q = torch.empty(rows, K, dtype=torch.uint8, device=x.device)
+    if scale is None:
+        scale = torch.empty(rows, dtype=torch.float32, device=x.device)
+    call("i64h_quantize_fp8_rows", ptr(x), rows, K, ptr(q), ptr(scale), _stream())
+    return q, scale
+
+
+def gemm_fp8(a: torch.Tensor, a_scale: torch.Tensor, w: torch.Tensor, w_scale: torch.Tensor, out: torch.Tensor, *, m: Optional[int] = None,
+             a_src_row=None, a_src_mod: int = 0, group_offsets=None, c_row_map=None, epilogue: int = EPI_STORE) -> torch.Tensor:
+    """out rows = (e4m3fn a rows) . (e4m3fn w [G, N, K])^T * a_scale[row] * w_scale[g, col] on the fp8 matrix cores (the
+    torch._scaled_mm branch of fp8_linear, vllm_i64/core/fp8.py:169-193); optional row gather / grouped weights / row scatter."""
+    if w.dim() == 2:
+        w, w_scale = w.unsqueeze(0), w_scale.reshape(1, -1)
+    G, N, K = w.shape
+    assert a.shape[1] == K and epilogue in (EPI_STORE, EPI_SWIGLU)
+    call("i64h_gemm_fp8_ex", ptr(a), ptr(a_scale), ptr(a_src_row), a_src_mod, ptr(w), ptr(w_scale), ptr(group_offsets), G,
+         m if m is not None else a.shape[0], N, K, ptr(out), ptr(c_row_map), epilogue, _stream())
+    return out
+
+
 def gemm_i8_qkv_rope_kv(desc, q_norm_w, k_norm_w, qk_eps, rope_tab, positions, slot_ids, block_table, k_cache, v_cache, q_out,
                         num_heads: int, num_kv_heads: int, head_dim: int):
     """qkv projection (desc: fp32 operand, decode-sized) + QK norm + RoPE + paged-KV write in one launch."""
