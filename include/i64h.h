@@ -144,6 +144,16 @@ int i64h_debug_set_stamps(void* buffer, int64_t capacity_workgroups); /* diagnos
 int i64h_set_skinny_waves(int32_t waves); /* tuning knob of the decode-sized (weight-streaming) kernel: 4, 8, 16 or 0 = default */
 /* C[M, N] = A[a_rows ? a_rows[m] : m, :K] . B[N, K]^T in fp32 (tied lm_head, vllm_i64/models/complexity_deep/model.py:436-437). */
 int i64h_gemm_f32(const float* A, const int32_t* a_rows, const float* B, float* C, int64_t M, int32_t N, int32_t K, void* stream);
+/* Grouped float expert contraction in one launch: C[r, :] = A[a_src_row ? a_src_row[r] : r, :K] @ B[g][:K, :N] for the rows
+ * r in [group_offsets[g], group_offsets[g + 1]) (device offsets, NULL = one group), stored at row c_row_map ? c_row_map[r] : r.
+ * B in the reference's expert layout [E][K][N] (gate_up_proj [E, H, 2I], down_proj [E, I, H]), fp32 (b_int8 = 0) or int8 with
+ * one fp32 scale per weight row b_row_scale [E][K] (b_int8 = 1, the weight-only form w = int8 * scale[:, None]).  epilogue 1:
+ * C [M, N / 2] = silu(y[:, :N/2]) * y[:, N/2:].  Replaces the per-expert loops of fused_token_routed_forward and
+ * fused_token_routed_forward_int8 (vllm_i64/kernels/fused_experts.py:65-150,153-291) and expert_forward
+ * (csrc/i64_expert_dispatch.cu:144-233). */
+int i64h_gemm_f32_grouped(const float* A, const int32_t* a_src_row, const void* B, int32_t b_int8, const float* b_row_scale,
+                          const int32_t* group_offsets, int32_t num_groups, int64_t M, int32_t N, int32_t K, float* C,
+                          const int32_t* c_row_map, int32_t epilogue, void* stream);
 /* fp32 activations x int8 weights with per-output-channel scale: I64_gemm_dequant_int8 / I64_gemm_silu_int8
  * (csrc/I64_gemm.cu:40-126). */
 int i64h_gemm_w8a32(const float* x, const int8_t* w, const float* w_scale, float* out, int64_t M, int32_t N, int32_t K, void* stream);

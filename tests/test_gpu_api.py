@@ -91,6 +91,56 @@ def test_fused_token_routed_forward_float(dev):
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("N,H,I,E", [(300, 72, 50, 5), (1, 64, 48, 4), (1000, 128, 33, 16), (130, 30, 7, 3)])
+def test_grouped_float_expert_mlp_odd_shapes_and_empty_experts(dev, N, H, I, E):
+    """The one-launch grouped contraction behind fused_token_routed_forward / i64_expert_forward / ..._int8: sizes that are no
+    multiple of the tile or of the vector width, experts without rows, more than one row tile per expert; fp64 reference."""
+    from vllm_i64_amd import kernels as K
+    g = torch.Generator().manual_seed(N + H)
+    x = torch.randn(N, H, generator=g)
+    gu = torch.randn(E, H, 2 * I, generator=g) * 0.1
+    dn = torch.randn(E, I, H, generator=g) * 0.1
+    eid = torch.randint(0, E, (N,), generator=g)
+    eid[eid == 1] = 0                                    # expert 1 stays empty
+    def ref_of(gu_, dn_):
+        ref = torch.zeros(N, H, dtype=torch.float64)
+        for e in range(E):
+            m = eid == e
+            t = x[m].double() @ gu_[e].double()
+            ref[m] = (torch.nn.functional.silu(t[:, :I]) * t[:, I:]) @ dn_[e].double()
+        return ref
+    out = K.fused_token_routed_forward(x.to(dev), gu.to(dev), dn.to(dev), eid.to(dev), E, I)
+    torch.testing.assert_close(out.cpu().double(), ref_of(gu, dn), rtol=1e-4, atol=1e-5)
+    # weight-only int8 form: int8 weights with one scale per weight row
+    gs, ds = gu.abs().amax(-1) / 127.0, dn.abs().amax(-1) / 127.0
+    gq, dq = torch.round(gu / gs[..., None]).to(torch.int8), torch.round(dn / ds[..., None]).to(torch.int8)
+    out8 = K.fused_token_routed_forward_int8(x.to(dev), gq.to(dev), gs.to(dev), dq.to(dev), ds.to(dev), eid.to(dev), E, I)
+    torch.testing.assert_close(out8.cpu().double(), ref_of(gq.float() * gs[..., None], dq.float() * ds[..., None]), rtol=1e-4, atol=1e-5)
+
+
+def test_grouped_float_expert_mlp_never_reads_back_to_the_host(dev):
+    """The whole operator (grouping + two launches) is captured into a HIP graph: any device-to-host read would fail the
+    capture.  Replayed on new inputs of the same shape it gives the new answer."""
+    from vllm_i64_amd import kernels as K
+    g = torch.Generator().manual_seed(8)
+    N, H, I, E = 200, 64, 48, 8
+    x = torch.randn(N, H, generator=g).to(dev)
+    gu = (torch.randn(E, H, 2 * I, generator=g) * 0.1).to(dev)
+    dn = (torch.randn(E, I, H, generator=g) * 0.1).to(dev)
+    eid = torch.randint(0, E, (N,), generator=g).to(dev)
+    K.fused_token_routed_forward(x, gu, dn, eid, E, I)  # warm-up outside the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = K.fused_token_routed_forward(x, gu, dn, eid, E, I)
+    x.copy_(torch.randn(N, H, generator=g))
+    eid.copy_(torch.randint(0, E, (N,), generator=g))
+    graph.replay()
+    torch.cuda.synchronize()
+    want = K.fused_token_routed_forward(x, gu, dn, eid, E, I)
+    assert torch.equal(out, want)
+
+
 def test_layer_functions(dev, golden_dir):
     from vllm_i64_amd import layers as L
     z = np.load(os.path.join(golden_dir, "ops.npz"))

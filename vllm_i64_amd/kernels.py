@@ -198,27 +198,37 @@ def is_i64_cuda_available() -> bool:
     return torch.cuda.is_available()
 
 
+def _grouped_f32(a: torch.Tensor, w: torch.Tensor, offsets: torch.Tensor, out: torch.Tensor, *, a_src_row=None, c_row_map=None,
+                 row_scale: Optional[torch.Tensor] = None, swiglu: bool = False, m: Optional[int] = None) -> torch.Tensor:
+    """One launch: rows [offsets[e], offsets[e+1]) of a (gathered through a_src_row) @ w[e] ([E, K, N], the reference's expert
+    layout; int8 with row_scale [E, K] for the weight-only form), optional SwiGLU, rows stored through c_row_map."""
+    E, K, N = w.shape
+    ops.call("i64h_gemm_f32_grouped", ops.ptr(a), ops.ptr(a_src_row), ops.ptr(w), int(w.dtype == torch.int8), ops.ptr(row_scale),
+             ops.ptr(offsets), E, m if m is not None else a.shape[0], N, K, ops.ptr(out), ops.ptr(c_row_map), 1 if swiglu else 0, ops._stream())
+    return out
+
+
+def _expert_mlp_grouped(xf, gate_up, down, offsets, perm, inter_size, gu_scale=None, dn_scale=None, scatter_back=True):
+    n = perm.numel() if perm is not None else xf.shape[0]
+    assert gate_up.shape[2] == 2 * inter_size and down.shape[1] == inter_size
+    inter = torch.empty(n, inter_size, dtype=torch.float32, device=xf.device)
+    _grouped_f32(xf, gate_up, offsets, inter, a_src_row=perm, row_scale=gu_scale, swiglu=True, m=n)
+    out = torch.empty(n, down.shape[2], dtype=torch.float32, device=xf.device)
+    return _grouped_f32(inter, down, offsets, out, c_row_map=perm if scatter_back else None, row_scale=dn_scale)
+
+
 def fused_token_routed_forward(x: torch.Tensor, gate_up_proj: torch.Tensor, down_proj: torch.Tensor, expert_ids: torch.Tensor,
                                num_experts: int, intermediate_per_tp: int, bmm_threshold: int = 64) -> torch.Tensor:
     """Float expert MLP grouped by expert (fused_experts.py:29-150): x [N,H], gate_up_proj [E,H,2I], down_proj [E,I,H],
-    expert_ids long [N].  fp32 math on the f32 matrix cores; one stable grouping, per-expert contractions, un-grouping.
-    Like the reference's chunked mode this reads the per-expert offsets on the host (one synchronisation)."""
+    expert_ids long [N].  fp32 math on the f32 matrix cores: one stable grouping on the device, then TWO launches for all
+    experts - the gather into expert order rides in the first (with the SwiGLU), the scatter back in the second.  Nothing is
+    read back to the host; the weights are used in the layout they arrive in."""
     n = x.shape[0]
     if n == 0:
         return x
-    xf = _f32(x)
-    offsets, perm, inv, _ = ops.bucketize(expert_ids.to(torch.int32).contiguous(), num_experts)
-    xs = ops.gather_rows(xf, perm)
-    off = offsets.tolist()
-    out_sorted = torch.empty(n, down_proj.shape[2], dtype=torch.float32, device=x.device)
-    for e in range(num_experts):
-        s, t = off[e], off[e + 1]
-        if s == t:
-            continue
-        gu = ops.gemm_f32(xs[s:t].contiguous(), _f32(gate_up_proj[e].t()))   # [m, 2I]
-        inter = ops.silu_mul(gu, intermediate_per_tp)
-        out_sorted[s:t] = ops.gemm_f32(inter, _f32(down_proj[e].t()))
-    return ops.gather_rows(out_sorted, inv).to(x.dtype)
+    offsets, perm, _, _ = ops.bucketize(expert_ids.to(torch.int32).contiguous(), num_experts)
+    out = _expert_mlp_grouped(_f32(x), _f32(gate_up_proj), _f32(down_proj), offsets, perm, intermediate_per_tp)
+    return out.to(x.dtype)
 
 
 # ---- per-token int8 operator path (vllm_i64/core/quantization.py:103-286, the torch._int_mm branch) -----------------------
@@ -254,29 +264,16 @@ def int8_fused_gate_up_native(x: torch.Tensor, fused_int8: torch.Tensor, fused_s
 def fused_token_routed_forward_int8(x: torch.Tensor, gate_up_int8: torch.Tensor, gate_up_scale: torch.Tensor, down_int8: torch.Tensor,
                                     down_scale: torch.Tensor, expert_ids: torch.Tensor, num_experts: int, intermediate_per_tp: int,
                                     bmm_threshold: int = 64) -> torch.Tensor:
-    """Weight-only int8 expert MLP (fused_experts.py:153-291): gate_up_int8 [E, H, 2I] with scale [E, H] per INPUT channel,
-    down_int8 [E, I, H] with scale [E, I]; fp32 activations.  x @ (W * s[:, None]) is evaluated as (x * s) @ W: the scaled
-    rows go through the fp32-activation x int8-weight kernel with unit output scales.  Grouping as in the float variant
-    (one host read of the per-expert offsets, like the reference's chunked mode)."""
+    """Weight-only int8 expert MLP (fused_experts.py:153-291): gate_up_int8 [E, H, 2I] with scale [E, H] (one per weight row),
+    down_int8 [E, I, H] with scale [E, I]; fp32 activations.  The weight tiles are dequantized (int8 * scale[row], the
+    reference's w.float() * scale) while they are staged, then the same two grouped launches as the float variant."""
     n = x.shape[0]
     if n == 0:
         return x
-    xf = _f32(x)
-    E, H, I2 = gate_up_int8.shape
-    offsets, perm, inv, _ = ops.bucketize(expert_ids.to(torch.int32).contiguous(), num_experts)
-    xs = ops.gather_rows(xf, perm)
-    off = offsets.tolist()
-    out_sorted = torch.empty(n, down_int8.shape[2], dtype=torch.float32, device=x.device)
-    ones_gu = torch.ones(I2, dtype=torch.float32, device=x.device)
-    ones_dn = torch.ones(down_int8.shape[2], dtype=torch.float32, device=x.device)
-    for e in range(num_experts):
-        s, t = off[e], off[e + 1]
-        if s == t:
-            continue
-        gu = ops.gemm_w8a32((xs[s:t] * _f32(gate_up_scale[e])).contiguous(), gate_up_int8[e].t().contiguous(), ones_gu)
-        inter = ops.silu_mul(gu, intermediate_per_tp)
-        out_sorted[s:t] = ops.gemm_w8a32((inter * _f32(down_scale[e])).contiguous(), down_int8[e].t().contiguous(), ones_dn)
-    return ops.gather_rows(out_sorted, inv).to(x.dtype)
+    offsets, perm, _, _ = ops.bucketize(expert_ids.to(torch.int32).contiguous(), num_experts)
+    out = _expert_mlp_grouped(_f32(x), gate_up_int8.contiguous(), down_int8.contiguous(), offsets, perm, intermediate_per_tp,
+                              gu_scale=_f32(gate_up_scale), dn_scale=_f32(down_scale))
+    return out.to(x.dtype)
 
 
 # ---- operator-library pipeline (vllm_i64/kernels/i64_ops.py:17-193) -------------------------------------------------------
@@ -298,18 +295,18 @@ def i64_gather(expert_output: torch.Tensor, scatter_indices: torch.Tensor) -> to
 def i64_expert_forward(scattered: torch.Tensor, gate_up_weights: torch.Tensor, down_weights: torch.Tensor, expert_offsets: torch.Tensor,
                        expert_counts: torch.Tensor, num_experts: int) -> torch.Tensor:
     """Expert MLP over rows already grouped by expert (i64_ops.py:100-158, csrc/i64_expert_dispatch.cu:144-233):
-    gate_up_weights [E, H, 2*ei], down_weights [E, ei, H].  fp32 math on the f32 matrix cores; like the reference it reads
-    the per-expert counts on the host."""
-    out = torch.zeros(scattered.shape, dtype=torch.float32, device=scattered.device)
+    gate_up_weights [E, H, 2*ei], down_weights [E, ei, H]; expert e owns rows [expert_offsets[e], + expert_counts[e]).  fp32 math
+    on the f32 matrix cores, two launches, offsets and counts stay on the device.  Rows no expert owns come back zero."""
+    n = scattered.shape[0]
+    if n == 0:
+        return scattered
+    start = expert_offsets.to(torch.int32).reshape(-1)[:num_experts]
+    off = torch.cat([start, (start[-1:] + expert_counts.to(torch.int32).reshape(-1)[num_experts - 1:num_experts])]).contiguous()
     ei = down_weights.shape[1]
-    xf = _f32(scattered)
-    off, cnt = expert_offsets.tolist(), expert_counts.tolist()
-    for e in range(num_experts):
-        s, c = int(off[e]), int(cnt[e])
-        if c == 0:
-            continue
-        gu = ops.gemm_f32(xf[s:s + c].contiguous(), _f32(gate_up_weights[e].t()))
-        out[s:s + c] = ops.gemm_f32(ops.silu_mul(gu, ei), _f32(down_weights[e].t()))
+    inter = torch.zeros(n, ei, dtype=torch.float32, device=scattered.device)
+    _grouped_f32(_f32(scattered), _f32(gate_up_weights), off, inter, swiglu=True)
+    out = torch.zeros(n, down_weights.shape[2], dtype=torch.float32, device=scattered.device)
+    _grouped_f32(inter, _f32(down_weights), off, out)
     return out.to(scattered.dtype)
 
 
