@@ -138,6 +138,7 @@ int i64h_gemm_i8_colscale(const int8_t* A, const float* row_scale, const int8_t*
                           float* C, void* stream);
 int i64h_set_gemm_rowstream(int32_t mode); /* tuning knob: int8 problems with >= 1024 rows per group that use the row-streaming kernel: 0 none, 1 SwiGLU epilogue only (default), 2 every epilogue */
 int i64h_set_gemm_rs_grid(int32_t workgroups, int32_t stagger_cycles); /* tuning knobs of the row-streaming kernel: size of its persistent grid (default 512) and start delay of the grid's second half (default 0) */
+int i64h_set_gemm_rs_depth(int32_t depth); /* tuning knob of the row-streaming kernel: K steps of operand fragments in flight per wave, 2 (default) or 4 */
 int i64h_set_gemm_stage64(int32_t on); /* tuning knob: 0 = 128-byte LDS stages for every prefill-sized problem (default 1: 64-byte stages, four workgroups per CU, when K <= 2048) */
 int64_t i64h_debug_stamp_cursor(void);
 int i64h_debug_set_stamps(void* buffer, int64_t capacity_workgroups); /* diagnostics: 8 uint64 per workgroup of s_memtime phase stamps from the decode-sized kernel, launches appended; NULL = off */

@@ -195,5 +195,10 @@ if __name__ == "__main__":
             ops.call("i64h_set_gemm_rs_grid", wgs, stagger)
             print(f"--- row-streaming kernel: grid <= {wgs} workgroups, stagger {stagger} cycles")
             bench_gemm_prefill(only)
+        ops.call("i64h_set_gemm_rs_grid", 512, 0)
+        ops.call("i64h_set_gemm_rs_depth", 4)
+        print("--- row-streaming kernel: grid <= 512 workgroups, 4 K steps of operand fragments in flight")
+        bench_gemm_prefill(only)
+        ops.call("i64h_set_gemm_rs_depth", 2)
         ops.call("i64h_set_gemm_rowstream", 1)
         ops.call("i64h_set_gemm_rs_grid", 512, 0)

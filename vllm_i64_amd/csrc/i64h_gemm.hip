@@ -1169,6 +1169,7 @@ static int g_rowstream = 1;  // tuning knob: 0 = row-streaming kernel off, 1 = f
 
 static int g_rs_wgs = 512;     // tuning knob: workgroups the persistent grid may use (two per CU)
 static int g_rs_stagger = 0;   // tuning knob: start delay (cycles) of the second half of the grid
+static int g_rs_depth = 2;     // tuning knob: K steps of operand fragments a wave keeps in flight (2 or 4)
 
 template <int EPI, int D>
 static int launch_rs(const i64h_gemm_desc* a, const i64h_gemm_desc* b, hipStream_t st) {
@@ -1272,6 +1273,13 @@ int i64h_set_gemm_rs_grid(int32_t workgroups, int32_t stagger_cycles) {
     return 0;
 }
 
+// tuning knob of the row-streaming kernel: K steps of operand fragments in flight per wave (2 or 4)
+int i64h_set_gemm_rs_depth(int32_t depth) {
+    I64H_CHECK_ARG(depth == 2 || depth == 4, "set_gemm_rs_depth: %d not in {2,4}", depth);
+    g_rs_depth = depth;
+    return 0;
+}
+
 // diagnostics: device buffer of 8 uint64 per workgroup that the weight-streaming kernel fills with s_memtime stamps at its
 // phase boundaries (0 entry, 1 weights requested, 2 row parameters ready, 3 operand rows quantized, 4 K loop done, 5 stores
 // drained, 6 tile located, 7 statistics requested); successive launches append (launch i's workgroups follow launch i-1's) until the capacity is used up; NULL
@@ -1309,7 +1317,10 @@ int i64h_gemm_i8_pair(const i64h_gemm_desc* a, const i64h_gemm_desc* b, void* st
     // prefill-sized int8 operands: the row-streaming kernel where it is the faster one (measured: SwiGLU problems, -20 %; plain
     // stores are bound by the output stream and do better with four small workgroups per CU)
     if (!mapped && rs_ok(a) && (!b || rs_ok(b)) && (g_rowstream == 2 || (g_rowstream == 1 && a->epilogue == EPI_SWIGLU)))
+    {
+        if (g_rs_depth == 4) return a->epilogue == EPI_STORE ? launch_rs<EPI_STORE, 4>(a, b, st) : launch_rs<EPI_SWIGLU, 4>(a, b, st);
         return a->epilogue == EPI_STORE ? launch_rs<EPI_STORE, 2>(a, b, st) : launch_rs<EPI_SWIGLU, 2>(a, b, st);
+    }
     const int64_t rows = a->M_total / a->num_groups;
     const bool big = !a->a_fp32 && rows >= 256;  // fp32 operands are meant for small M (quantized per workgroup)
     // short K: a tile's K loop is a handful of steps, so occupancy (4 workgroups per CU) hides the per-tile prologue and
