@@ -1227,6 +1227,13 @@ static int launch_skinny(const i64h_gemm_desc* a, const i64h_gemm_desc* b, hipSt
     size_t area = (size_t)SK_BM * (kmax + 32);
     if (area < SK_AREA_MIN) area = SK_AREA_MIN;  // the epilogues reuse the operand area
     const size_t lds = area + 16 + 3 * SK_BM * 4;
+    if (lds > 64 * 1024) {  // long K (e.g. a dense down projection with K = 4096): more dynamic LDS than the default limit
+        static bool raised = false;  // per instantiation
+        if (!raised) {
+            I64H_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_i8_skinny_kernel<EPI, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            raised = true;
+        }
+    }
     hipLaunchKernelGGL((gemm_i8_skinny_kernel<EPI, NW>), dim3((unsigned)total), dim3(NW * 64), lds, st, pp, ta);
     I64H_CHECK_LAUNCH();
     return 0;
@@ -1243,9 +1250,11 @@ static int launch_skinny_nw(const i64h_gemm_desc* a, const i64h_gemm_desc* b, hi
 
 static int g_stage64 = 1;  // tuning knob: 0 = 128-byte stages (two workgroups per CU) for every prefill-sized problem
 
+#define SK_MAX_K 8192  // 16 operand rows x (K + 32) bytes of LDS: 129 KB at this K
+
 static bool skinny_ok(const i64h_gemm_desc* d) {
     // weight-streaming kernel: fp32 operand, K a multiple of 64 that fits LDS, few rows per group
-    return d->a_fp32 && d->K % 64 == 0 && d->K <= 2048 && d->M_total <= 512;
+    return d->a_fp32 && d->K % 64 == 0 && d->K <= SK_MAX_K && d->M_total <= 512;
 }
 
 extern "C" {
