@@ -26,10 +26,14 @@ def main():
     ocfg = M.named_config("tiny-moe")
     w = M.make_weights(ocfg, seed=0)
     bank = M.LinearBank(w, "int8")
-    lens, prompts = ep_oracle.make_case(ocfg, world)
+    big = len(sys.argv) > 2 and sys.argv[2] == "big"
+    if big:
+        import dataclasses
+        ocfg = dataclasses.replace(ocfg, max_pos=512)
+    lens, prompts = ep_oracle.make_case(ocfg, world, big=big)
     nseq = len(lens[0])
     # the single-process statement, for all ranks (every rank computes it: tiny)
-    kvs = [M.PagedKV(ocfg, 32, nseq) for _ in range(world)]
+    kvs = [M.PagedKV(ocfg, 64, nseq) for _ in range(world)]
     steps = []   # per step: (ids per rank, positions per rank, tokens per seq)
     ids = [torch.cat(p) for p in prompts]
     pos = [torch.cat([torch.arange(n) for n in ls]) for ls in lens]
@@ -48,7 +52,7 @@ def main():
         tps = [[1] * nseq for _ in range(world)]
     worst, agree = 0.0, 1.0
     if mode == "cpu":
-        kv = M.PagedKV(ocfg, 32, nseq)
+        kv = M.PagedKV(ocfg, 64, nseq)
         for step, (sids, spos, stps) in enumerate(steps):
             lg = ep_oracle.rank_step(ocfg, bank, comm, sids[rank], spos[rank], kv, list(range(nseq)), stps[rank])
             if step == 0:
@@ -58,7 +62,7 @@ def main():
         from vllm_i64_amd.config import ModelConfig
         from vllm_i64_amd.model import I64MoEModel
         dev = torch.device("cuda:0")
-        model = I64MoEModel(ModelConfig.from_any(ocfg), w, device=dev, max_seqs=nseq, num_kv_blocks=32, expert_parallel=True)
+        model = I64MoEModel(ModelConfig.from_any(ocfg), w, device=dev, max_seqs=nseq, num_kv_blocks=64, expert_parallel=True)
         assert model.ep.world == world and not model.ep.direct
         for s in range(nseq):
             model.kv.reserve(s, lens[rank][s] + 4)

@@ -12,16 +12,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,port,force", [(2, 29551, "0"), (4, 29552, "0"), (1, 29553, "1")])
-def test_expert_parallel_runner_against_single_process_oracle(world, port, force):
+@pytest.mark.parametrize("world,port,force,case", [(2, 29551, "0", "small"), (4, 29552, "0", "small"), (1, 29553, "1", "small"),
+                                                   (2, 29554, "0", "big")])
+def test_expert_parallel_runner_against_single_process_oracle(world, port, force, case):
     """Prefill (ragged prompts, equal token count per rank) and two greedy decode steps.  Bound: the quantization-noise scale
     of the model tests (a flipped 7-bit activation LSB moves a logit by ~1e-2); greedy tokens identical.  world 1 with forced
-    collectives walks the exchange path (gather, row maps, all-to-all, owner-indexed combine) at one rank."""
+    collectives walks the exchange path (gather, row maps, all-to-all, owner-indexed combine) at one rank; "big": 300 tokens per
+    rank, i.e. 1200 pooled expert rows in the prefill step (the separately quantized, prefill-sized expert path)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", I64H_EP_FORCE_COLLECTIVES=force)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
-                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "ep_model_worker.py"), "gpu"],
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "ep_model_worker.py"), "gpu", case],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     line = [l for l in r.stdout.splitlines() if l.startswith("EP_MODEL_RESULT")][0].split()

@@ -1250,11 +1250,12 @@ static int launch_skinny_nw(const i64h_gemm_desc* a, const i64h_gemm_desc* b, hi
 
 static int g_stage64 = 1;  // tuning knob: 0 = 128-byte stages (two workgroups per CU) for every prefill-sized problem
 
+#define SK_MAX_ROWS 1024  // beyond this the operand is worth quantizing once instead of once per column tile
 #define SK_MAX_K 8192  // 16 operand rows x (K + 32) bytes of LDS: 129 KB at this K
 
 static bool skinny_ok(const i64h_gemm_desc* d) {
     // weight-streaming kernel: fp32 operand, K a multiple of 64 that fits LDS, few rows per group
-    return d->a_fp32 && d->K % 64 == 0 && d->K <= SK_MAX_K && d->M_total <= 512;
+    return d->a_fp32 && d->K % 64 == 0 && d->K <= SK_MAX_K && d->M_total <= SK_MAX_ROWS;
 }
 
 extern "C" {

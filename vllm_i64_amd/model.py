@@ -244,6 +244,7 @@ class I64MoEModel:
         return self._bufs[key]
 
     FUSE_MAX_ROWS = 256  # up to this many operand rows the quantizer runs inside the GEMM (one launch per Linear call)
+    EP_FUSE_MAX_ROWS = 1024  # the same for the pooled expert rows of the expert-parallel runner (8 ranks x 64 sequences x top-2)
     fuse_qkr = True   # decode-sized steps: QK norm / RoPE / cache write inside the qkv GEMM
     attn_target_wgs = int(os.environ.get("I64H_ATTN_WGS", "256"))  # decode attention: rows x splits aimed at = one 4-wave workgroup per CU (measured: 256 beats 512 and 1024 at batch 64, ctx 2048)
 
@@ -590,7 +591,7 @@ class I64MoEModel:
         ops.rows_minmax(x_all, st, slots=plan.tok_slots[l], slot_base=base + 2)
         eo = plan.expert_offsets[l][self.ep_e0: self.ep_e0 + self.ep_le + 1]   # row ranges of this rank's experts (device)
         out_buf, c_map = B.xsend.view(-1, H), B.row_map[l]                     # rows of other ranks' experts: never read
-        if R <= self.FUSE_MAX_ROWS:
+        if R <= self.EP_FUSE_MAX_ROWS:
             # two launches, each with this rank's experts and its shared expert as the second problem
             e_gu = ops.gemm_desc(x_all, W["exp_gu"].w_q, W["exp_gu"].w_s, B.e_inter, a_src_row=plan.perm[l], a_src_mod=n_all,
                                  a_row_slot=plan.sorted_bucket[l], a_slot_base=base + 3, group_offsets=eo, epilogue=ops.EPI_SWIGLU,
