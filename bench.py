@@ -168,6 +168,15 @@ def main():
         dec = GreedyDecoder(model, B, use_graph=not args.no_graph)
         prefill_tps = fill_cache(model, dec)
         dec.prepare()  # buffer allocation and graph capture are set-up, not steps (no state advances)
+        guard = None
+        if dist is not None:
+            # a collective that never completes (ranks out of step, a library that cannot replay its captured kernels) would
+            # hang every rank for good: end the run with an error after a bounded time instead
+            import threading
+            guard = threading.Timer(float(os.environ.get("I64_BENCH_STEP_GUARD_S", "240")), lambda: (sys.stderr.write(
+                "bench.py: the decode steps did not complete in time (collective stuck?); giving up\n"), sys.stderr.flush(), os._exit(4)))
+            guard.daemon = True
+            guard.start()
         for _ in range(args.warmup):
             dec.step()
         torch.cuda.synchronize()
@@ -186,6 +195,8 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+        if guard is not None:
+            guard.cancel()
         return model, dec, prefill_tps, elapsed
 
     def fill_cache(model, dec):
