@@ -187,6 +187,12 @@ int i64h_gemm_fp8(const uint8_t* A, const float* a_scale, const uint8_t* B, cons
 int i64h_gemm_fp8_ex(const uint8_t* A, const float* a_scale, const int32_t* a_src_row, int32_t a_src_mod, const uint8_t* B,
                      const float* b_scale, const int32_t* group_offsets, int32_t num_groups, int64_t M, int32_t N, int32_t K, float* C,
                      const int32_t* c_row_map, int32_t epilogue, void* stream);
+/* Decode-sized form of fp8_linear (fp8.py:137-194): fp32 operand rows in, quantize_activations_fp8 (fp8.py:113-130) applied per
+ * row INSIDE the kernel (a row's scale needs only that row), then the same product - one launch instead of two, codes and
+ * scales bit for bit those of i64h_quantize_fp8_rows.  K a multiple of 64 up to 8192; other arguments as i64h_gemm_fp8_ex. */
+int i64h_gemm_fp8_rows(const float* A, const int32_t* a_src_row, int32_t a_src_mod, const uint8_t* B, const float* b_scale,
+                       const int32_t* group_offsets, int32_t num_groups, int64_t M, int32_t N, int32_t K, float* C,
+                       const int32_t* c_row_map, int32_t epilogue, void* stream);
 
 /* ---- one MoE layer behind one call --------------------------------------------------------------------------------------
  * out[n, H] = TokenRoutedMLP(x, token_ids) of the int8 CPU engine: routes = table[:, clamp(ids)], every (route, expert)

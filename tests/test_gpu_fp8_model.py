@@ -116,6 +116,63 @@ def test_fp8_gemm_on_identical_operands_is_the_exact_sum_up_to_matrix_core_preci
     assert d.max() <= 5e-5 * want.abs().max()
 
 
+def test_fp8_hardware_conversion_equals_torch_cast_value_by_value(dev):
+    """The quantizers convert through the hardware instruction.  Rows that contain 448 have scale exactly 1, so their codes
+    are the plain cast of their values: a million values - every e4m3 code, every midpoint between neighbours (ties), the
+    subnormal range and below, both signs - against torch's CPU cast."""
+    from vllm_i64_amd import ops
+    codes = torch.arange(0, 127, dtype=torch.uint8).view(torch.float8_e4m3fn).float()          # all finite non-negative values
+    mids = (codes[:-1] + codes[1:]) / 2                                                            # exact ties
+    near = torch.cat([mids * (1 + 2 ** -20), mids * (1 - 2 ** -20)])
+    g = torch.Generator().manual_seed(0)
+    rnd = torch.cat([torch.empty(400000).uniform_(-448, 448, generator=g), torch.empty(300000).normal_(0, 0.01, generator=g),
+                     torch.empty(200000).uniform_(-2 ** -6, 2 ** -6, generator=g), torch.empty(50000).uniform_(-2 ** -10, 2 ** -10, generator=g)])
+    vals = torch.cat([codes, -codes, mids, -mids, near, -near, rnd])
+    K = 1024
+    pad = (-vals.numel()) % (K - 1)
+    vals = torch.cat([vals, torch.zeros(pad)]).view(-1, K - 1)
+    x = torch.cat([torch.full((vals.shape[0], 1), 448.0), vals], dim=1).contiguous()
+    q, s = ops.quantize_fp8_rows(x.to(dev))
+    assert torch.all(s.cpu() == 1.0)
+    want = x.to(torch.float8_e4m3fn).view(torch.uint8)
+    got = q.cpu()
+    bad = (got != want).nonzero()
+    assert bad.numel() == 0, (bad[:5], x[bad[0, 0], bad[0, 1]].item())
+
+
+@pytest.mark.parametrize("K,N,epi", [(1024, 896, 1), (448, 1024, 0), (1792, 1024, 0), (4096, 320, 0), (64, 48, 1)])
+def test_fp8_rows_gemm_quantizes_like_the_row_quantizer(dev, K, N, epi):
+    """The decode-sized one-launch form (fp32 rows in, per-token quantization inside the kernel): against the exact sum over
+    the codes and scales the stand-alone quantizer produces, grouped, gathered and scattered; real K of the three models."""
+    from oracle import ops_ref as O
+    from vllm_i64_amd import ops
+    g = torch.Generator().manual_seed(K + N)
+    n, R, G = 40, 70, 3
+    x = torch.empty(n, K).normal_(0, 1, generator=g)
+    x[3] = 0.0                                               # an all-zero row: scale 1e-12 / 448, codes 0
+    w = torch.empty(G, N, K).normal_(0, 0.05, generator=g)
+    xq, xs = O.quantize_fp8_rows(x)
+    wq, ws = O.quantize_fp8_rows(w.reshape(-1, K))
+    wq, ws = wq.view(G, N, K), ws.view(G, N)
+    src = torch.randint(0, 3 * n, (R,), generator=g).to(torch.int32)          # gather: source row = src % n
+    dst = torch.randperm(R, generator=g).to(torch.int32)
+    off = torch.tensor([0, 25, 25, R], dtype=torch.int32)
+    out = torch.zeros(R, N // 2 if epi else N, device=dev)
+    ops.gemm_fp8_rows(x.to(dev), wq.view(torch.uint8).to(dev), ws.to(dev), out, m=R, a_src_row=src.to(dev), a_src_mod=n,
+                      group_offsets=off.to(dev), c_row_map=dst.to(dev), epilogue=epi)
+    want = torch.zeros(R, N // 2 if epi else N, dtype=torch.float64)
+    for j in range(R):
+        grp = 0 if j < 25 else 2
+        r = int(src[j]) % n
+        y = (xq[r].double() @ wq[grp].double().t()) * xs[r].double() * ws[grp].double()
+        if epi:
+            y = torch.nn.functional.silu(y[:N // 2]) * y[N // 2:]
+        want[int(dst[j])] = y
+    d = (out.cpu().double() - want).abs()
+    print(f"fp8 rows GEMM K={K} N={N} epi={epi}: max {d.max():.3e} (|y| max {want.abs().max():.3f})")
+    assert d.max() <= 1e-4 * max(1.0, float(want.abs().max()))
+
+
 def test_fp8_graph_decode_matches_eager(dev):
     from vllm_i64_amd.model import GreedyDecoder
     ocfg, w, model = _model("tiny-moe", dev)

@@ -40,6 +40,7 @@ SIGNATURES: Dict[str, str] = {
     "i64h_gemm_fp8": "pppppiliipip",
     "i64h_set_gemm_rs_depth": "i",
     "i64h_gemm_fp8_ex": "pppipppiliippip",
+    "i64h_gemm_fp8_rows": "ppipppiliippip",
     "i64h_gemm_f32_grouped": "pppippiliippip",
     "i64h_embedding": "pppli" + "lp",
     "i64h_embedding_stats_reset": "pppli" + "lplp",

@@ -13,6 +13,17 @@
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// four floats already clamped to [-448, 448] -> four e4m3fn codes (x0 in the low byte) through the hardware conversion
+// (v_cvt_pk_fp8_f32 on gfx950: OCP e4m3fn, round to nearest even, subnormal results exact) - the same codes as torch's cast
+// and as the bit-level routine f32_to_e4m3fn, checked value by value in tests/test_gpu_fp8_model.py
+__device__ __forceinline__ uint32_t pack4_e4m3fn(float x0, float x1, float x2, float x3) {
+    int v = 0;
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(x0, x1, v, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(x2, x3, v, true);
+    return (uint32_t)v;
+}
+__device__ __forceinline__ float clamp448(float x) { return fminf(fmaxf(x, -448.0f), 448.0f); }
+
 __global__ __launch_bounds__(256) void quantize_fp8_rows_kernel(const float* __restrict__ x, int64_t K, uint8_t* __restrict__ q,
                                                                 float* __restrict__ scale) {
     __shared__ float red[4];
@@ -27,7 +38,14 @@ __global__ __launch_bounds__(256) void quantize_fp8_rows_kernel(const float* __r
     const float s = fmaxf(m, 1e-12f) / 448.0f;
     if (threadIdx.x == 0) scale[row] = s;
     uint8_t* qr = q + row * K;
-    for (int64_t i = threadIdx.x; i < K; i += 256) qr[i] = f32_to_e4m3fn(fminf(fmaxf(xr[i] / s, -448.0f), 448.0f));
+    if ((K & 3) == 0 && (((uintptr_t)xr | (uintptr_t)qr) & 15) == 0) {
+        for (int64_t i = threadIdx.x; i < K / 4; i += 256) {
+            const float4 x = ((const float4*)xr)[i];
+            ((uint32_t*)qr)[i] = pack4_e4m3fn(clamp448(x.x / s), clamp448(x.y / s), clamp448(x.z / s), clamp448(x.w / s));
+        }
+    } else {
+        for (int64_t i = threadIdx.x; i < K; i += 256) qr[i] = (uint8_t)(pack4_e4m3fn(clamp448(xr[i] / s), 0.f, 0.f, 0.f) & 0xff);
+    }
 }
 
 #define F8_BM 64
@@ -158,6 +176,169 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(const uint8_t* __restrict
         }
 }
 
+// ---- decode-sized problems: weight-streaming kernel with the per-token quantizer in front ----------------------------------
+// For a few rows per group the contraction is a weight stream.  A row's e4m3 scale needs only that row
+// (quantize_activations_fp8, fp8.py:113-130), and a workgroup holds its 16 operand rows whole - so it quantizes them itself:
+// fp32 rows in (gathered through a_src_row), amax per row by the row's 16 threads, e4m3 codes into LDS for the whole K.  No
+// separate quantization launch and no quantized copy of the activations in memory; the codes and scales are bit for bit the
+// ones quantize_fp8_rows_kernel writes.  Weights go from global memory straight into MFMA fragments.
+// K is consumed in blocks of 64 bytes: lane (fr, fq) takes bytes [64 t + 16 fq, + 16) of its row / weight column and feeds the
+// first 8 to one v_mfma_f32_16x16x32_fp8_fp8 and the second 8 to the next - both operands use the same assignment, so the sum
+// runs over all of K (in an order of its own: results differ from the tiled kernel's in the last bits).
+// Workgroup = 4 waves, 16 rows x 64 outputs (EPI: 64 gate columns and their 64 up partners... per wave 16 + 16).
+#define F8S_BM 16
+#define F8S_MAXV 32  // float4 per thread kept in registers between the amax pass and the quantization: K <= 2048
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_fp8_skinny_kernel(const float* __restrict__ A, const int32_t* __restrict__ a_src_row, int a_src_mod,
+                                                              const uint8_t* __restrict__ B, const float* __restrict__ b_scale,
+                                                              const int32_t* __restrict__ group_off, int G, int M, int N, int K,
+                                                              float* __restrict__ C, const int32_t* __restrict__ c_row_map) {
+    extern __shared__ __attribute__((aligned(16))) char f8s_smem[];
+    constexpr int NF = EPI ? 2 : 1;
+    const int LDA = K + 32;
+    char* rows_q = f8s_smem;                                 // [16][LDA] e4m3 codes
+    float* row_s = (float*)(f8s_smem + F8S_BM * LDA);        // [16] scales
+    int* s_info = (int*)(row_s + F8S_BM);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int I = N / 2, nout = EPI ? I : N;
+    const int n_tiles = (nout + 63) / 64;
+    const int mt = blockIdx.x / n_tiles, nt = blockIdx.x % n_tiles;
+    if (wid == 0) {  // (group, first row, rows) of m-tile mt: lane i looks at group c0 + i; the grid is an upper bound
+        int g = -1, row0 = 0, rows = 0, base = 0;
+        const int ng = group_off ? G : 1;
+        for (int c0 = 0; c0 < ng && g < 0; c0 += 64) {
+            const int i = c0 + lane;
+            int b = 0, e = 0;
+            if (i < ng) { b = group_off ? group_off[i] : 0; e = group_off ? group_off[i + 1] : M; }
+            const int tiles = (e - b + F8S_BM - 1) / F8S_BM;
+            int incl = tiles;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            const int excl = base + incl - tiles;
+            const unsigned long long hit = __ballot(i < ng && mt >= excl && mt < excl + tiles);
+            if (hit) {
+                const int src = __ffsll(hit) - 1;
+                g = c0 + src;
+                row0 = __shfl(b, src) + (mt - __shfl(excl, src)) * F8S_BM;
+                rows = min(F8S_BM, __shfl(e, src) - row0);
+            }
+            base += __shfl(incl, 63);
+        }
+        if (lane == 0) { s_info[0] = g; s_info[1] = row0; s_info[2] = rows; }
+    }
+    __syncthreads();
+    const int g = s_info[0], row0 = s_info[1], rows = s_info[2];
+    if (g < 0) return;
+
+    // ---- operand rows: thread (r = tid / 16, c = tid % 16) owns float4 chunks c, c + 16, ... of row r ----
+    const int r = tid >> 4, c = tid & 15;
+    const bool rok = r < rows;
+    int64_t src = row0 + (rok ? r : 0);
+    if (a_src_row) src = a_src_row[src] % a_src_mod;
+    const float4* ap = (const float4*)(A + src * K);
+    const int nv = K / 4;
+    // this lane's weight columns, requested behind the rows (loads return in order: the rows can be quantized while the
+    // weights are still on their way)
+    const int col = nt * 64 + wid * 16 + fr;
+    const bool col_ok = col < nout;
+    const uint8_t* Bg = B + (int64_t)g * N * K;
+    const uint8_t* bp[NF];
+    bp[0] = Bg + (int64_t)(col_ok ? col : 0) * K + fq * 16;
+    if (NF == 2) bp[1] = Bg + (int64_t)(I + (col_ok ? col : 0)) * K + fq * 16;
+    float m = 0.0f;
+    const bool in_regs = nv <= 16 * F8S_MAXV;
+    float4 v[F8S_MAXV];
+    const int nblk = K / 64;
+    constexpr int BATCH = 8;
+    uint4 bq[NF][BATCH];
+    auto bload = [&](int t0) {
+#pragma unroll
+        for (int t = 0; t < BATCH; ++t) {
+            const int tt = min(t0 + t, nblk - 1);  // clamped: always a valid address, surplus fragments are not used
+#pragma unroll
+            for (int f = 0; f < NF; ++f) bq[f][t] = *(const uint4*)(bp[f] + tt * 64);
+        }
+    };
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < F8S_MAXV; ++j) {
+            const int i = c + 16 * j;
+            v[j] = (rok && i < nv) ? ap[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        bload(0);
+#pragma unroll
+        for (int j = 0; j < F8S_MAXV; ++j) m = fmaxf(m, fmaxf(fmaxf(fabsf(v[j].x), fabsf(v[j].y)), fmaxf(fabsf(v[j].z), fabsf(v[j].w))));
+    } else {
+        for (int i = c; i < nv; i += 16) {
+            const float4 x = rok ? ap[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w))));
+        }
+        bload(0);
+    }
+    m = row16_max(m);  // the 16 threads of a row are 16 consecutive lanes
+    const float sc = fmaxf(m, 1e-12f) / 448.0f;
+    if (c == 0) row_s[r] = rok ? sc : 0.0f;
+    auto q4 = [&](float4 x) -> uint32_t { return pack4_e4m3fn(clamp448(x.x / sc), clamp448(x.y / sc), clamp448(x.z / sc), clamp448(x.w / sc)); };
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < F8S_MAXV; ++j) {
+            const int i = c + 16 * j;
+            if (i < nv) *(uint32_t*)(rows_q + r * LDA + i * 4) = rok ? q4(v[j]) : 0u;
+        }
+    } else {
+        for (int i = c; i < nv; i += 16) *(uint32_t*)(rows_q + r * LDA + i * 4) = rok ? q4(ap[i]) : 0u;  // second read: cache
+    }
+    __syncthreads();
+
+    // ---- K loop: weight fragments in batches of 8 blocks of 64 bytes (the first batch was requested behind the rows) ----
+    v4f acc[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) acc[f] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int t0 = 0; t0 < nblk; t0 += BATCH) {
+        uint4 bc[NF][BATCH];
+#pragma unroll
+        for (int t = 0; t < BATCH; ++t)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) bc[f][t] = bq[f][t];
+        if (t0 + BATCH < nblk) bload(t0 + BATCH);  // next batch streams in behind the MFMAs of this one
+#pragma unroll
+        for (int t = 0; t < BATCH; ++t) {
+            if (t0 + t >= nblk) break;
+            const uint4 a = *(const uint4*)(rows_q + fr * LDA + (t0 + t) * 64 + fq * 16);
+            const long a0 = (long)(((unsigned long long)a.y << 32) | a.x), a1 = (long)(((unsigned long long)a.w << 32) | a.z);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const long b0 = (long)(((unsigned long long)bc[f][t].y << 32) | bc[f][t].x);
+                const long b1 = (long)(((unsigned long long)bc[f][t].w << 32) | bc[f][t].z);
+                acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a0, b0, acc[f], 0, 0, 0);
+                acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a1, b1, acc[f], 0, 0, 0);
+            }
+        }
+    }
+    // ---- epilogue: D[row = 4 fq + reg][col = fr] ----
+    if (!col_ok) return;
+    const float ws0 = b_scale[(int64_t)g * N + col];
+    const float ws1 = EPI ? b_scale[(int64_t)g * N + I + col] : 0.0f;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int rr = fq * 4 + reg;
+        if (rr >= rows) continue;
+        const float as = row_s[rr];
+        const int64_t crow = c_row_map ? c_row_map[row0 + rr] : row0 + rr;
+        if (EPI) {
+            const float gate = acc[0][reg] * (as * ws0), up = acc[NF - 1][reg] * (as * ws1);
+            C[crow * I + col] = (gate / (1.0f + expf(-gate))) * up;
+        } else {
+            C[crow * N + col] = acc[0][reg] * (as * ws0);
+        }
+    }
+}
+
 extern "C" {
 
 // x fp32 [rows, K] -> q e4m3fn bytes [rows, K], scale fp32 [rows]
@@ -197,6 +378,46 @@ int i64h_gemm_fp8_ex(const uint8_t* A, const float* a_scale, const int32_t* a_sr
 int i64h_gemm_fp8(const uint8_t* A, const float* a_scale, const uint8_t* B, const float* b_scale, const int32_t* group_offsets,
                   int32_t num_groups, int64_t M, int32_t N, int32_t K, float* C, int32_t epilogue, void* stream) {
     return i64h_gemm_fp8_ex(A, a_scale, nullptr, 0, B, b_scale, group_offsets, num_groups, M, N, K, C, nullptr, epilogue, stream);
+}
+
+
+// Decode-sized form: fp32 operand rows, quantized per token inside the kernel (the arithmetic of i64h_quantize_fp8_rows
+// followed by i64h_gemm_fp8_ex, one launch, no quantized copy in memory).  K a multiple of 64 up to 8192.
+int i64h_gemm_fp8_rows(const float* A, const int32_t* a_src_row, int32_t a_src_mod, const uint8_t* B, const float* b_scale,
+                       const int32_t* group_offsets, int32_t num_groups, int64_t M, int32_t N, int32_t K, float* C,
+                       const int32_t* c_row_map, int32_t epilogue, void* stream) {
+    I64H_CHECK_ARG(M >= 0 && M < (1ll << 31) && N > 0 && K > 0 && K % 64 == 0 && K <= 8192, "gemm_fp8_rows: bad sizes (K=%d: a multiple of 64 up to 8192)", K);
+    I64H_CHECK_ARG(((uintptr_t)A | (uintptr_t)B) % 16 == 0, "gemm_fp8_rows: operands must be 16-byte aligned");
+    I64H_CHECK_ARG(num_groups >= 1 && num_groups <= 4096 && (group_offsets != nullptr || num_groups == 1), "gemm_fp8_rows: bad grouping");
+    I64H_CHECK_ARG(epilogue == 0 || (epilogue == 1 && N % 2 == 0), "gemm_fp8_rows: bad epilogue %d / N=%d", epilogue, N);
+    I64H_CHECK_ARG(a_src_row == nullptr || a_src_mod > 0, "gemm_fp8_rows: a_src_row needs a_src_mod > 0");
+    if (M == 0) return 0;
+    const int G = group_offsets ? num_groups : 1;
+    const int nout = epilogue ? N / 2 : N;
+    const int64_t m_tiles = (M + F8S_BM - 1) / F8S_BM + G;
+    const int n_tiles = (nout + 63) / 64;
+    I64H_CHECK_ARG(m_tiles * n_tiles < (1ll << 31), "gemm_fp8_rows: grid too large");
+    const size_t lds = (size_t)F8S_BM * (K + 32) + F8S_BM * 4 + 16;
+    hipStream_t st = (hipStream_t)stream;
+    if (epilogue) {
+        static bool raised = false;
+        if (lds > 64 * 1024 && !raised) {
+            I64H_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_fp8_skinny_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            raised = true;
+        }
+        hipLaunchKernelGGL(gemm_fp8_skinny_kernel<1>, dim3((unsigned)(m_tiles * n_tiles)), dim3(256), lds, st, A, a_src_row, a_src_mod, B, b_scale,
+                           group_offsets, G, (int)M, N, K, C, c_row_map);
+    } else {
+        static bool raised = false;
+        if (lds > 64 * 1024 && !raised) {
+            I64H_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_fp8_skinny_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            raised = true;
+        }
+        hipLaunchKernelGGL(gemm_fp8_skinny_kernel<0>, dim3((unsigned)(m_tiles * n_tiles)), dim3(256), lds, st, A, a_src_row, a_src_mod, B, b_scale,
+                           group_offsets, G, (int)M, N, K, C, c_row_map);
+    }
+    I64H_CHECK_LAUNCH();
+    return 0;
 }
 
 }  // extern "C"

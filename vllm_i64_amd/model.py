@@ -484,11 +484,22 @@ class I64MoEModel:
             B.attn_splits = splits
         ops.fused_residual_norm(B.h, self.layers[0]["ln1"], eps, h_out=B.h, normed=B.normed)
         S = cfg.shared_intermediate_size if cfg.is_moe else 0
+        small = n * max(1, cfg.top_k if cfg.is_moe else 1) <= self.FUSE_MAX_ROWS
+
+        def linear(x, xq, xs, Wp, out, **kw):
+            """One fp8_linear: decode-sized steps quantize the rows inside the GEMM (one launch); otherwise the rows are
+            quantized once (xq / xs: where to, or already there when x is None) and the tiled GEMM runs on the codes."""
+            K = Wp.w_q.shape[-1]
+            if small and x is not None and ops.fp8_rows_ok(K):
+                return ops.gemm_fp8_rows(x, Wp.w_q, Wp.w_s, out, **kw)
+            if x is not None:
+                ops.quantize_fp8_rows(x, xq, xs)
+            return ops.gemm_fp8(xq, xs, Wp.w_q, Wp.w_s, out, **kw)
+
         for l, W in enumerate(self.layers):
             if record is not None:
                 record[f"l{l}.in"] = B.h.clone()
-            ops.quantize_fp8_rows(B.normed, B.xa, B.xs)
-            ops.gemm_fp8(B.xa, B.xs, W["qkv"].w_q, W["qkv"].w_s, B.qkv)
+            linear(B.normed, B.xa, B.xs, W["qkv"], B.qkv)
             ops.qk_norm_rope_kv(B.qkv, W["q_norm"], W["k_norm"], 1e-6, self.rope, positions, slot_ids, kvc.block_table,
                                 kvc.k[l], kvc.v[l], cfg.num_heads, cfg.num_kv_heads, cfg.head_dim, q_out=B.q)
             ops.paged_attn(B.q, kvc.k[l], kvc.v[l], kvc.block_table, ctx_len, slot_ids=None if rows_are_slots else slot_ids,
@@ -496,35 +507,33 @@ class I64MoEModel:
             attn2d = B.attn.view(n, H)
             if record is not None:
                 record[f"l{l}.attn_out"] = attn2d.clone()
-            ops.quantize_fp8_rows(attn2d, B.xa, B.xs)
-            ops.gemm_fp8(B.xa, B.xs, W["o"].w_q, W["o"].w_s, B.o)
+            linear(attn2d, B.xa, B.xs, W["o"], B.o)
             ops.fused_residual_norm(B.h, W["ln2"], eps, add=B.o, h_out=B.h, normed=B.normed)
             if record is not None:
                 record[f"l{l}.mlp_in"] = B.normed.clone()
-            ops.quantize_fp8_rows(B.normed, B.xa, B.xs)
             nxt = self.layers[l + 1]["ln1"] if l + 1 < cfg.num_layers else self.final_norm
+            fused_in = small and ops.fp8_rows_ok(H)   # the normalised rows go into their GEMMs as fp32
+            if not fused_in:
+                ops.quantize_fp8_rows(B.normed, B.xa, B.xs)  # one quantization serves the shared expert and every routed expert
+            x_in = B.normed if fused_in else None
             if cfg.is_moe:
                 plan = B.plan
                 R = plan.rows
                 if R:
                     # rows in bucket order are grouped by expert; the gather out of the token rows and the scatter back into
                     # (route, token) order ride in the GEMMs
-                    ops.gemm_fp8(B.xa, B.xs, W["exp_gu"].w_q, W["exp_gu"].w_s, B.e_inter, m=R, a_src_row=plan.perm[l], a_src_mod=n,
-                                 group_offsets=plan.expert_offsets[l], epilogue=ops.EPI_SWIGLU)
-                    ops.quantize_fp8_rows(B.e_inter, B.eia, B.eis)
-                    ops.gemm_fp8(B.eia, B.eis, W["exp_dn"].w_q, W["exp_dn"].w_s, B.e_out, group_offsets=plan.expert_offsets[l],
-                                 c_row_map=plan.perm[l])
+                    linear(x_in, B.xa, B.xs, W["exp_gu"], B.e_inter, m=R, a_src_row=plan.perm[l], a_src_mod=n,
+                           group_offsets=plan.expert_offsets[l], epilogue=ops.EPI_SWIGLU)
+                    linear(B.e_inter, B.eia, B.eis, W["exp_dn"], B.e_out, group_offsets=plan.expert_offsets[l], c_row_map=plan.perm[l])
                 if S:
-                    ops.gemm_fp8(B.xa, B.xs, W["sh_gu"].w_q, W["sh_gu"].w_s, B.sh_inter, epilogue=ops.EPI_SWIGLU)
-                    ops.quantize_fp8_rows(B.sh_inter, B.sha, B.shs)
-                    ops.gemm_fp8(B.sha, B.shs, W["sh_dn"].w_q, W["sh_dn"].w_s, B.sh_out)
+                    linear(x_in, B.xa, B.xs, W["sh_gu"], B.sh_inter, epilogue=ops.EPI_SWIGLU)
+                    linear(B.sh_inter, B.sha, B.shs, W["sh_dn"], B.sh_out)
                 ops.fused_residual_norm(B.h, nxt, eps, moe_rows=B.e_out, moe_inv=None, moe_shared=B.sh_out if S else None,
                                         route_weights=rw, routed_scale=W["routed_scale"], shared_scale=W["shared_scale"], h_out=B.h,
                                         normed=B.normed)
             else:
-                ops.gemm_fp8(B.xa, B.xs, W["gu"].w_q, W["gu"].w_s, B.d_inter, epilogue=ops.EPI_SWIGLU)
-                ops.quantize_fp8_rows(B.d_inter, B.da, B.ds)
-                ops.gemm_fp8(B.da, B.ds, W["dn"].w_q, W["dn"].w_s, B.d_out)
+                linear(x_in, B.xa, B.xs, W["gu"], B.d_inter, epilogue=ops.EPI_SWIGLU)
+                linear(B.d_inter, B.da, B.ds, W["dn"], B.d_out)
                 ops.fused_residual_norm(B.h, nxt, eps, add=B.d_out, h_out=B.h, normed=B.normed)
             if record is not None:
                 record[f"l{l}.out"] = B.h.clone()

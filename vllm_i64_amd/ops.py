@@ -259,6 +259,24 @@ def gemm_fp8(a: torch.Tensor, a_scale: torch.Tensor, w: torch.Tensor, w_scale: t
     return out
 
 
+def gemm_fp8_rows(a: torch.Tensor, w: torch.Tensor, w_scale: torch.Tensor, out: torch.Tensor, *, m: Optional[int] = None, a_src_row=None,
+                  a_src_mod: int = 0, group_offsets=None, c_row_map=None, epilogue: int = EPI_STORE) -> torch.Tensor:
+    """Decode-sized fp8_linear in one launch: fp32 rows `a`, per-token e4m3fn quantization inside the kernel (bit for bit
+    quantize_fp8_rows), then the product of gemm_fp8.  K a multiple of 64 up to 8192."""
+    _chk(a, torch.float32, "a")
+    if w.dim() == 2:
+        w, w_scale = w.unsqueeze(0), w_scale.reshape(1, -1)
+    G, N, K = w.shape
+    assert a.shape[1] == K and epilogue in (EPI_STORE, EPI_SWIGLU)
+    call("i64h_gemm_fp8_rows", ptr(a), ptr(a_src_row), a_src_mod, ptr(w), ptr(w_scale), ptr(group_offsets), G,
+         m if m is not None else a.shape[0], N, K, ptr(out), ptr(c_row_map), epilogue, _stream())
+    return out
+
+
+def fp8_rows_ok(k: int) -> bool:
+    return k % 64 == 0 and k <= 8192
+
+
 def gemm_i8_qkv_rope_kv(desc, q_norm_w, k_norm_w, qk_eps, rope_tab, positions, slot_ids, block_table, k_cache, v_cache, q_out,
                         num_heads: int, num_kv_heads: int, head_dim: int):
     """qkv projection (desc: fp32 operand, decode-sized) + QK norm + RoPE + paged-KV write in one launch."""
