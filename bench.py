@@ -150,31 +150,57 @@ def main():
     kv_dtype = {"bf16": torch.bfloat16, "fp32": torch.float32, "fp16": torch.float16, "fp8": torch.float8_e4m3fn,
                 "fp8_e5m2": torch.float8_e5m2}[args.kv_dtype]
     B, P = args.batch, args.prompt_len
-    need = P + args.steps + args.warmup + 2
+    fp8 = args.weights == "fp8"
+    ep_mode = cfg.is_moe and not fp8 and (args.parallelism == "ep" or (args.parallelism == "auto" and world > 1))
+    # positions a sequence may reach: prompt + warm-up + timed steps (twice for multi-rank expert parallelism, which is measured
+    # eagerly and then as a graph)
+    need = P + (2 if ep_mode and (world > 1 or os.environ.get("I64H_EP_FORCE_COLLECTIVES") == "1") else 1) * (args.steps + args.warmup) + 2
     if need > cfg.max_pos:  # a longer run than the config's position range: extend the range (rope table, block table, cache) for it
         import dataclasses
         cfg = dataclasses.replace(cfg, max_pos=(need + 255) // 256 * 256)
     t0 = time.time()
     weights = synth.make_weights(cfg, seed=0)
-    fp8 = args.weights == "fp8"
-    ep_mode = cfg.is_moe and not fp8 and (args.parallelism == "ep" or (args.parallelism == "auto" and world > 1))
-    total_len = P + args.steps + args.warmup + 2
+    total_len = need
+    headline = cfg.name == "trhash500m-synth" and not fp8 and B == 64
+
+    def result_line(elapsed, used_graph, prefill_tps, note=None):
+        """The result object without the roofline / baseline extras."""
+        line = {
+            "metric": ("decode tokens/sec tr-hash-moe-500m int8 batch64; % INT8-MFMA roofline" if headline else
+                       f"decode tokens/sec {cfg.name} {args.weights} batch{B} (a side configuration, not the headline metric)"),
+            "value": round(B * world * args.steps / elapsed, 1), "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": ("fp8 (e4m3 x e4m3 -> fp32 MFMA, fp32 rescale; fp32 attention math)" if fp8 else
+                      "int8 (i8 x i8 -> i32 MFMA, fp32 rescale; fp32 attention math)"),
+            "data": "synthetic",
+            "config": {"workload": f"{cfg.name} {'fp8-Linear (e4m3fn weights and activations)' if fp8 else 'int8 dynamic-Linear'} forward, "
+                                   f"batch {B} per GPU, {P}-token prompts{' (synthetic KV)' if args.synthetic_kv else ' (real prefill)'} + greedy "
+                                   f"decode, KV cache {args.kv_dtype}",
+                       "global_batch": B * world, "seq_len": P,
+                       "parallelism": (f"ep{world} (experts sharded over the ranks; per MoE layer one all-gather of the input rows and one "
+                                       f"equal-split all-to-all of the expert rows, RCCL)" if ep_mode else
+                                       f"dp{world} (independent replicas, no collective)" if world > 1 else "single GPU"),
+                       "kv_dtype": args.kv_dtype, "hip_graph": used_graph,
+                       "prompt_ids": f"zipf({args.zipf})" if args.zipf > 0 else "uniform"},
+        }
+        if note:
+            line["note"] = note
+        if prefill_tps is not None:
+            line["prefill_tokens_per_s"] = round(prefill_tps, 1)
+        return line
+
     ids = synth.make_token_ids(cfg, B * P, seed=7 + rank, zipf=args.zipf).view(B, P)
 
-    def run_leg(expert_parallel: bool):
-        """Build the runner, prefill (untimed; its own rate is reported), W warm-up steps, then exactly K timed steps bracketed
-        by barrier + synchronize; the time is the maximum over the ranks."""
-        model = I64MoEModel(cfg, weights, device=dev, kv_dtype=kv_dtype, max_seqs=B, expert_parallel=expert_parallel, quant=args.weights)
-        dec = GreedyDecoder(model, B, use_graph=not args.no_graph)
-        prefill_tps = fill_cache(model, dec)
-        dec.prepare()  # buffer allocation and graph capture are set-up, not steps (no state advances)
+    contingency = {}   # multi-rank expert parallelism: the eagerly launched measurement, kept in case the graph replay never returns
+
+    def timed_steps(dec, guard_action):
+        """W warm-up steps, then exactly K timed steps bracketed by barrier + synchronize; maximum over the ranks.  With several
+        ranks a collective that never completes would hang every rank for good: after a bounded time guard_action runs instead."""
         guard = None
         if dist is not None:
-            # a collective that never completes (ranks out of step, a library that cannot replay its captured kernels) would
-            # hang every rank for good: end the run with an error after a bounded time instead
             import threading
-            guard = threading.Timer(float(os.environ.get("I64_BENCH_STEP_GUARD_S", "240")), lambda: (sys.stderr.write(
-                "bench.py: the decode steps did not complete in time (collective stuck?); giving up\n"), sys.stderr.flush(), os._exit(4)))
+            guard = threading.Timer(float(os.environ.get("I64_BENCH_STEP_GUARD_S", "240")), guard_action)
             guard.daemon = True
             guard.start()
         for _ in range(args.warmup):
@@ -197,6 +223,38 @@ def main():
             elapsed = float(t.item())
         if guard is not None:
             guard.cancel()
+        return elapsed
+
+    def give_up():
+        sys.stderr.write("bench.py: the decode steps did not complete in time (collective stuck?); giving up\n")
+        sys.stderr.flush()
+        os._exit(4)
+
+    def emit_contingency():
+        """The graph replay with captured collectives did not come back: report the eagerly launched measurement of the same
+        steps (complete and valid, taken before the graph was tried) and leave."""
+        sys.stderr.write("bench.py: graph replay with captured collectives did not complete; reporting the eager measurement\n")
+        sys.stderr.flush()
+        if rank == 0 and contingency:
+            os.write(result_fd, (json.dumps(contingency) + "\n").encode())
+        os._exit(0)
+
+    def run_leg(expert_parallel: bool):
+        """Build the runner, prefill (untimed; its own rate is reported), then the timed decode steps.  Expert parallelism over
+        several ranks is measured twice: launched eagerly (nothing captured - cannot hang on a replay), then as one HIP graph
+        with the collectives captured; the graph figure is the result, the eager one the fallback."""
+        model = I64MoEModel(cfg, weights, device=dev, kv_dtype=kv_dtype, max_seqs=B, expert_parallel=expert_parallel, quant=args.weights)
+        multi_ep = model.ep is not None   # collectives on the data path (several ranks, or one rank with them forced)
+        dec = GreedyDecoder(model, B, use_graph=not (args.no_graph or multi_ep))
+        prefill_tps = fill_cache(model, dec)
+        dec.prepare()  # buffer allocation and graph capture are set-up, not steps (no state advances)
+        elapsed = timed_steps(dec, give_up)
+        if multi_ep and not args.no_graph:
+            contingency.update(result_line(elapsed, False, prefill_tps, note="eager launches; the graph replay of the step did not complete"))
+            dec.use_graph = True
+            dec.prepare()
+            if dec.graph is not None:
+                elapsed = timed_steps(dec, emit_contingency)
         return model, dec, prefill_tps, elapsed
 
     def fill_cache(model, dec):
@@ -247,7 +305,7 @@ def main():
         model, dec = ep_model, ep_dec
 
     # ---- roofline of the dominant kernel: paged-KV attention of one layer, timed with HIP events on the launch stream ----
-    ctx_now = P + args.warmup + args.steps
+    ctx_now = max(dec.host_lens)   # tokens every sequence holds now
     kvb = {torch.bfloat16: 2, torch.float16: 2, torch.float32: 4, torch.float8_e4m3fn: 1, torch.float8_e5m2: 1}[kv_dtype]
     Bf = model.buffers(B, B)
     splits = Bf.attn_splits
@@ -338,32 +396,10 @@ def main():
     except Exception as e:  # an extra; never lose the headline line to it
         mfma = {"error": repr(e)}
 
-    headline = cfg.name == "trhash500m-synth" and not fp8 and B == 64
-    out = {
-        "metric": ("decode tokens/sec tr-hash-moe-500m int8 batch64; % INT8-MFMA roofline" if headline else
-                   f"decode tokens/sec {cfg.name} {args.weights} batch{B} (a side configuration, not the headline metric)"),
-        "value": round(value, 1), "unit": "tokens/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None,
-        "dtype": ("fp8 (e4m3 x e4m3 -> fp32 MFMA, fp32 rescale; fp32 attention math)" if fp8 else
-                  "int8 (i8 x i8 -> i32 MFMA, fp32 rescale; fp32 attention math)"),
-        "data": "synthetic",
-        "config": {"workload": f"{cfg.name} {'fp8-Linear (e4m3fn weights and activations)' if fp8 else 'int8 dynamic-Linear'} forward, batch {B} per GPU, {P}-token prompts"
-                               f"{' (synthetic KV)' if args.synthetic_kv else ' (real prefill)'} + greedy decode, KV cache {args.kv_dtype}",
-                   "global_batch": B * world, "seq_len": P,
-                   "parallelism": (f"ep{world} (experts sharded over the ranks; per MoE layer one all-gather of the input rows and one "
-                                   f"equal-split all-to-all of the expert rows, RCCL)" if ep_mode else
-                                   f"dp{world} (independent replicas, no collective)" if world > 1 else "single GPU"),
-                   "kv_dtype": args.kv_dtype, "hip_graph": used_graph,
-                   "prompt_ids": f"zipf({args.zipf})" if args.zipf > 0 else "uniform"},
-        "roofline": roofline,
-        "roofline_step": step_roof,
-        "roofline_mfma": mfma,
-    }
+    out = result_line(elapsed, used_graph, prefill_tps)
+    out.update({"roofline": roofline, "roofline_step": step_roof, "roofline_mfma": mfma})
     if replica is not None:
         out["replica"] = replica
-    if prefill_tps is not None:
-        out["prefill_tokens_per_s"] = round(prefill_tps, 1)
     out["setup_s"] = round(t_setup, 1)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

@@ -339,6 +339,18 @@ __global__ __launch_bounds__(256) void gemm_fp8_skinny_kernel(const float* __res
     }
 }
 
+// long K: more dynamic LDS than the default limit; once per kernel and device (one process may drive several GPUs)
+static int raise_lds_limit(const void* kernel, int which) {
+    static bool raised[2][64] = {};
+    int device = 0;
+    I64H_CHECK_HIP(hipGetDevice(&device));
+    if (device < 0 || device >= 64 || !raised[which][device]) {
+        I64H_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (device >= 0 && device < 64) raised[which][device] = true;
+    }
+    return 0;
+}
+
 extern "C" {
 
 // x fp32 [rows, K] -> q e4m3fn bytes [rows, K], scale fp32 [rows]
@@ -400,19 +412,11 @@ int i64h_gemm_fp8_rows(const float* A, const int32_t* a_src_row, int32_t a_src_m
     const size_t lds = (size_t)F8S_BM * (K + 32) + F8S_BM * 4 + 16;
     hipStream_t st = (hipStream_t)stream;
     if (epilogue) {
-        static bool raised = false;
-        if (lds > 64 * 1024 && !raised) {
-            I64H_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_fp8_skinny_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            raised = true;
-        }
+        if (lds > 64 * 1024 && raise_lds_limit((const void*)gemm_fp8_skinny_kernel<1>, 1)) return 1;
         hipLaunchKernelGGL(gemm_fp8_skinny_kernel<1>, dim3((unsigned)(m_tiles * n_tiles)), dim3(256), lds, st, A, a_src_row, a_src_mod, B, b_scale,
                            group_offsets, G, (int)M, N, K, C, c_row_map);
     } else {
-        static bool raised = false;
-        if (lds > 64 * 1024 && !raised) {
-            I64H_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_fp8_skinny_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            raised = true;
-        }
+        if (lds > 64 * 1024 && raise_lds_limit((const void*)gemm_fp8_skinny_kernel<0>, 0)) return 1;
         hipLaunchKernelGGL(gemm_fp8_skinny_kernel<0>, dim3((unsigned)(m_tiles * n_tiles)), dim3(256), lds, st, A, a_src_row, a_src_mod, B, b_scale,
                            group_offsets, G, (int)M, N, K, C, c_row_map);
     }

@@ -1228,10 +1228,12 @@ static int launch_skinny(const i64h_gemm_desc* a, const i64h_gemm_desc* b, hipSt
     if (area < SK_AREA_MIN) area = SK_AREA_MIN;  // the epilogues reuse the operand area
     const size_t lds = area + 16 + 3 * SK_BM * 4;
     if (lds > 64 * 1024) {  // long K (e.g. a dense down projection with K = 4096): more dynamic LDS than the default limit
-        static bool raised = false;  // per instantiation
-        if (!raised) {
+        static bool raised[64] = {};  // per instantiation and device (one process may drive several GPUs)
+        int device = 0;
+        I64H_CHECK_HIP(hipGetDevice(&device));
+        if (device < 0 || device >= 64 || !raised[device]) {
             I64H_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_i8_skinny_kernel<EPI, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            raised = true;
+            if (device >= 0 && device < 64) raised[device] = true;
         }
     }
     hipLaunchKernelGGL((gemm_i8_skinny_kernel<EPI, NW>), dim3((unsigned)total), dim3(NW * 64), lds, st, pp, ta);
