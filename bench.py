@@ -192,6 +192,7 @@ def main():
 
     ids = synth.make_token_ids(cfg, B * P, seed=7 + rank, zipf=args.zipf).view(B, P)
 
+    extras = {}
     contingency = {}   # multi-rank expert parallelism: the eagerly launched measurement, kept in case the graph replay never returns
 
     def timed_steps(dec, guard_action):
@@ -251,6 +252,7 @@ def main():
         elapsed = timed_steps(dec, give_up)
         if multi_ep and not args.no_graph:
             contingency.update(result_line(elapsed, False, prefill_tps, note="eager launches; the graph replay of the step did not complete"))
+            extras["ep_eager_ms_per_step"] = round(elapsed / args.steps * 1e3, 4)   # the same steps launched one by one
             dec.use_graph = True
             dec.prepare()
             if dec.graph is not None:
@@ -398,6 +400,7 @@ def main():
 
     out = result_line(elapsed, used_graph, prefill_tps)
     out.update({"roofline": roofline, "roofline_step": step_roof, "roofline_mfma": mfma})
+    out.update(extras)
     if replica is not None:
         out["replica"] = replica
     out["setup_s"] = round(t_setup, 1)
