@@ -6,6 +6,8 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$TAG
 timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/$TAG/tests.log 2>&1
 tail -1 gpurun_out/$TAG/tests.log
+timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/$TAG/smoke.log 2>&1
+tail -1 gpurun_out/$TAG/smoke.log
 timeout -k 10 400 python bench.py > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err
 cut -c1-300 gpurun_out/$TAG/bench.json
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d gpurun_out/$TAG/prof -o bench --output-format csv -- python3 bench.py --no-cpu-baseline > gpurun_out/$TAG/prof.log 2>&1
