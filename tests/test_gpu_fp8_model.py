@@ -84,7 +84,7 @@ def test_fp8_model_logits(dev, golden_dir, name):
         gap_max, gap_mean = z[f"{name}_scaled_mm_gap{i}"]
         print(f"{name} step {i}: GPU vs oracle fp8 max {d_o.max():.3e} mean {d_o.mean():.3e}; GPU vs reference (dequantizing branch) max "
               f"{d_r.max():.3e} mean {d_r.mean():.3e} (oracle fp8 vs reference: max {gap_max:.3e} mean {gap_mean:.3e})")
-        assert d_o.max() <= gap_max and d_o.mean() <= 0.5 * gap_mean
+        assert d_o.max() <= gap_max and d_o.mean() <= 0.75 * gap_mean   # measured: max 0.2-0.5x, mean 0.3-0.45x
         assert d_r.max() <= 2 * gap_max and d_r.mean() <= 2 * gap_mean
         assert torch.equal(g.argmax(-1), o.argmax(-1))
 
