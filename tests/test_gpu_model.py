@@ -313,6 +313,9 @@ _SWEEP = [
          shared_intermediate_size=256, top_k=2, primary_weight=0.5, routed_scale=2.0, shared_scale=0.25, max_pos=320),
     dict(vocab_size=64, hidden_size=64, num_layers=1, num_heads=4, num_kv_heads=1, intermediate_size=128, num_experts=8,
          shared_intermediate_size=64, top_k=2, primary_weight=0.5, max_pos=64),
+    # head size 64 but a hidden size beyond the fused qkv + RoPE + cache-write launch (K <= 2048): the two-kernel form runs
+    dict(vocab_size=256, hidden_size=2112, num_layers=1, num_heads=33, num_kv_heads=3, intermediate_size=256, num_experts=2,
+         shared_intermediate_size=64, top_k=1, primary_weight=1.0, max_pos=128),
 ]
 
 
