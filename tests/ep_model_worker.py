@@ -26,10 +26,15 @@ def main():
     ocfg = M.named_config("tiny-moe")
     w = M.make_weights(ocfg, seed=0)
     bank = M.LinearBank(w, "int8")
-    big = len(sys.argv) > 2 and sys.argv[2] == "big"
+    case = sys.argv[2] if len(sys.argv) > 2 else "small"
+    big = case == "big"
+    import dataclasses
     if big:
-        import dataclasses
         ocfg = dataclasses.replace(ocfg, max_pos=512)
+    if case == "real2":   # the benchmark model's real dimensions (hidden 1024, 8 experts of width 448, shared 1792), two layers deep
+        ocfg = dataclasses.replace(M.named_config("trhash500m-synth"), num_layers=2, max_pos=256, name="trhash500m-cut2")
+        w = M.make_weights(ocfg, seed=0)
+        bank = M.LinearBank(w, "int8")
     lens, prompts = ep_oracle.make_case(ocfg, world, big=big)
     nseq = len(lens[0])
     # the single-process statement, for all ranks (every rank computes it: tiny)
