@@ -193,6 +193,22 @@ int i64h_gemm_fp8_ex(const uint8_t* A, const float* a_scale, const int32_t* a_sr
 int i64h_gemm_fp8_rows(const float* A, const int32_t* a_src_row, int32_t a_src_mod, const uint8_t* B, const float* b_scale,
                        const int32_t* group_offsets, int32_t num_groups, int64_t M, int32_t N, int32_t K, float* C,
                        const int32_t* c_row_map, int32_t epilogue, void* stream);
+/* The same with up to two problems of one epilogue in one launch (the routed experts and the shared expert of a
+ * TokenRoutedMLP layer, token_routed_mlp.py:154-187); b may be NULL. */
+typedef struct i64h_fp8_rows_desc {
+    const float* A;                 /* fp32 [*, K] */
+    const int32_t* a_src_row;       /* operand row of output row r = A[a_src_row[r] % a_src_mod] (NULL: r) */
+    int32_t a_src_mod;
+    const uint8_t* B;               /* e4m3fn [G][N][K] */
+    const float* b_scale;           /* [G][N] */
+    const int32_t* group_offsets;   /* [G + 1] device, or NULL: one group */
+    int32_t num_groups;
+    int64_t M;
+    int32_t N, K;
+    float* C;                       /* [M, N] or [M, N / 2] (epilogue 1) */
+    const int32_t* c_row_map;       /* output row r stored at row c_row_map[r] (NULL: r) */
+} i64h_fp8_rows_desc;
+int i64h_gemm_fp8_rows_pair(const i64h_fp8_rows_desc* a, const i64h_fp8_rows_desc* b, int32_t epilogue, void* stream);
 
 /* ---- one MoE layer behind one call --------------------------------------------------------------------------------------
  * out[n, H] = TokenRoutedMLP(x, token_ids) of the int8 CPU engine: routes = table[:, clamp(ids)], every (route, expert)

@@ -173,6 +173,27 @@ def test_fp8_rows_gemm_quantizes_like_the_row_quantizer(dev, K, N, epi):
     assert d.max() <= 1e-4 * max(1.0, float(want.abs().max()))
 
 
+def test_fp8_rows_pair_equals_two_single_launches(dev):
+    """Two problems in one launch (routed experts + shared expert) give bit for bit what two launches give."""
+    from vllm_i64_amd import ops
+    g = torch.Generator().manual_seed(5)
+    n, R, G, K, N, S = 64, 128, 8, 1024, 896, 3584
+    x = torch.empty(n, K).normal_(0, 1, generator=g).to(dev)
+    we, se = ops.quantize_fp8_rows(torch.empty(G * N, K).normal_(0, 0.05, generator=g).to(dev))
+    ws_, ss = ops.quantize_fp8_rows(torch.empty(S, K).normal_(0, 0.05, generator=g).to(dev))
+    we, se = we.view(G, N, K), se.view(G, N)
+    perm = torch.randperm(R, generator=g).to(torch.int32).to(dev)
+    cnt = torch.tensor([16, 0, 40, 8, 16, 16, 31, 1])
+    off = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(cnt, 0)]).to(torch.int32).to(dev)
+    e1, s1 = torch.zeros(R, N // 2, device=dev), torch.zeros(n, S // 2, device=dev)
+    e2, s2 = torch.zeros_like(e1), torch.zeros_like(s1)
+    ops.gemm_fp8_rows(x, we, se, e1, m=R, a_src_row=perm, a_src_mod=n, group_offsets=off, epilogue=ops.EPI_SWIGLU)
+    ops.gemm_fp8_rows(x, ws_, ss, s1, epilogue=ops.EPI_SWIGLU)
+    ops.gemm_fp8_rows_pair(ops.fp8_rows_desc(x, we, se, e2, m=R, a_src_row=perm, a_src_mod=n, group_offsets=off),
+                           ops.fp8_rows_desc(x, ws_, ss, s2), epilogue=ops.EPI_SWIGLU)
+    assert torch.equal(e1, e2) and torch.equal(s1, s2) and bool(e1.abs().sum() > 0) and bool(s1.abs().sum() > 0)
+
+
 def test_fp8_graph_decode_matches_eager(dev):
     from vllm_i64_amd.model import GreedyDecoder
     ocfg, w, model = _model("tiny-moe", dev)

@@ -41,6 +41,7 @@ SIGNATURES: Dict[str, str] = {
     "i64h_set_gemm_rs_depth": "i",
     "i64h_gemm_fp8_ex": "pppipppiliippip",
     "i64h_gemm_fp8_rows": "ppipppiliippip",
+    "i64h_gemm_fp8_rows_pair": "ppip",
     "i64h_gemm_f32_grouped": "pppippiliippip",
     "i64h_embedding": "pppli" + "lp",
     "i64h_embedding_stats_reset": "pppli" + "lplp",
@@ -96,6 +97,12 @@ class GemmDesc(ctypes.Structure):
                 ("a_slot_base", _I), ("B", _P), ("w_scale", _P), ("group_offsets", _P), ("num_groups", _I), ("M_total", _L),
                 ("N", _I), ("K", _I), ("C", _P), ("epilogue", _I), ("out_row_slot", _P), ("out_slot_base", _I), ("stats", _P),
                 ("want_stats", _I), ("col_scale", _P), ("c_row_map", _P), ("a_group_slots", _I)]
+
+
+class Fp8RowsDesc(ctypes.Structure):
+    """Mirror of i64h_fp8_rows_desc (include/i64h.h)."""
+    _fields_ = [("A", _P), ("a_src_row", _P), ("a_src_mod", _I), ("B", _P), ("b_scale", _P), ("group_offsets", _P), ("num_groups", _I),
+                ("M", _L), ("N", _I), ("K", _I), ("C", _P), ("c_row_map", _P)]
 
 
 class MoeLayer(ctypes.Structure):

@@ -10,6 +10,7 @@
 //   fp8.py:256-283) and a SwiGLU epilogue silu(gate) * up over the fused [2I, K] weight.
 // Workgroup = 4 waves (2 x 2), tile 64 x 64, K stages of 128 bytes, double-buffered LDS (row stride 144 bytes).
 #include "i64h_common.h"
+#include "i64h.h"
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
@@ -189,12 +190,37 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(const uint8_t* __restrict
 #define F8S_BM 16
 #define F8S_MAXV 32  // float4 per thread kept in registers between the amax pass and the quantization: K <= 2048
 
+struct Fp8RowsArgs {
+    const float* A;
+    const int32_t* a_src_row;
+    int a_src_mod;
+    const uint8_t* B;
+    const float* b_scale;
+    const int32_t* group_off;
+    int G, M, N, K;
+    float* C;
+    const int32_t* c_row_map;
+};
+struct Fp8RowsPair {
+    Fp8RowsArgs p[2];
+    int nblk0;  // workgroups [0, nblk0) run p[0], the rest p[1] (e.g. the routed experts and the shared expert of one layer)
+};
+
 template <int EPI>
-__global__ __launch_bounds__(256) void gemm_fp8_skinny_kernel(const float* __restrict__ A, const int32_t* __restrict__ a_src_row, int a_src_mod,
-                                                              const uint8_t* __restrict__ B, const float* __restrict__ b_scale,
-                                                              const int32_t* __restrict__ group_off, int G, int M, int N, int K,
-                                                              float* __restrict__ C, const int32_t* __restrict__ c_row_map) {
+__global__ __launch_bounds__(256) void gemm_fp8_skinny_kernel(Fp8RowsPair pp) {
     extern __shared__ __attribute__((aligned(16))) char f8s_smem[];
+    const bool second = (int)blockIdx.x >= pp.nblk0;
+    const Fp8RowsArgs& p = pp.p[second ? 1 : 0];
+    const int bid = second ? (int)blockIdx.x - pp.nblk0 : (int)blockIdx.x;
+    const float* __restrict__ A = p.A;
+    const int32_t* __restrict__ a_src_row = p.a_src_row;
+    const int a_src_mod = p.a_src_mod;
+    const uint8_t* __restrict__ B = p.B;
+    const float* __restrict__ b_scale = p.b_scale;
+    const int32_t* __restrict__ group_off = p.group_off;
+    const int G = p.G, M = p.M, N = p.N, K = p.K;
+    float* __restrict__ C = p.C;
+    const int32_t* __restrict__ c_row_map = p.c_row_map;
     constexpr int NF = EPI ? 2 : 1;
     const int LDA = K + 32;
     char* rows_q = f8s_smem;                                 // [16][LDA] e4m3 codes
@@ -204,7 +230,7 @@ __global__ __launch_bounds__(256) void gemm_fp8_skinny_kernel(const float* __res
     const int fr = lane & 15, fq = lane >> 4;
     const int I = N / 2, nout = EPI ? I : N;
     const int n_tiles = (nout + 63) / 64;
-    const int mt = blockIdx.x / n_tiles, nt = blockIdx.x % n_tiles;
+    const int mt = bid / n_tiles, nt = bid % n_tiles;
     if (wid == 0) {  // (group, first row, rows) of m-tile mt: lane i looks at group c0 + i; the grid is an upper bound
         int g = -1, row0 = 0, rows = 0, base = 0;
         const int ng = group_off ? G : 1;
@@ -249,7 +275,7 @@ __global__ __launch_bounds__(256) void gemm_fp8_skinny_kernel(const float* __res
     const uint8_t* Bg = B + (int64_t)g * N * K;
     const uint8_t* bp[NF];
     bp[0] = Bg + (int64_t)(col_ok ? col : 0) * K + fq * 16;
-    if (NF == 2) bp[1] = Bg + (int64_t)(I + (col_ok ? col : 0)) * K + fq * 16;
+    if constexpr (NF == 2) bp[1] = Bg + (int64_t)(I + (col_ok ? col : 0)) * K + fq * 16;
     float m = 0.0f;
     const bool in_regs = nv <= 16 * F8S_MAXV;
     float4 v[F8S_MAXV];
@@ -394,34 +420,63 @@ int i64h_gemm_fp8(const uint8_t* A, const float* a_scale, const uint8_t* B, cons
 
 
 // Decode-sized form: fp32 operand rows, quantized per token inside the kernel (the arithmetic of i64h_quantize_fp8_rows
-// followed by i64h_gemm_fp8_ex, one launch, no quantized copy in memory).  K a multiple of 64 up to 8192.
-int i64h_gemm_fp8_rows(const float* A, const int32_t* a_src_row, int32_t a_src_mod, const uint8_t* B, const float* b_scale,
-                       const int32_t* group_offsets, int32_t num_groups, int64_t M, int32_t N, int32_t K, float* C,
-                       const int32_t* c_row_map, int32_t epilogue, void* stream) {
-    I64H_CHECK_ARG(M >= 0 && M < (1ll << 31) && N > 0 && K > 0 && K % 64 == 0 && K <= 8192, "gemm_fp8_rows: bad sizes (K=%d: a multiple of 64 up to 8192)", K);
-    I64H_CHECK_ARG(((uintptr_t)A | (uintptr_t)B) % 16 == 0, "gemm_fp8_rows: operands must be 16-byte aligned");
-    I64H_CHECK_ARG(num_groups >= 1 && num_groups <= 4096 && (group_offsets != nullptr || num_groups == 1), "gemm_fp8_rows: bad grouping");
-    I64H_CHECK_ARG(epilogue == 0 || (epilogue == 1 && N % 2 == 0), "gemm_fp8_rows: bad epilogue %d / N=%d", epilogue, N);
-    I64H_CHECK_ARG(a_src_row == nullptr || a_src_mod > 0, "gemm_fp8_rows: a_src_row needs a_src_mod > 0");
-    if (M == 0) return 0;
-    const int G = group_offsets ? num_groups : 1;
-    const int nout = epilogue ? N / 2 : N;
-    const int64_t m_tiles = (M + F8S_BM - 1) / F8S_BM + G;
-    const int n_tiles = (nout + 63) / 64;
-    I64H_CHECK_ARG(m_tiles * n_tiles < (1ll << 31), "gemm_fp8_rows: grid too large");
-    const size_t lds = (size_t)F8S_BM * (K + 32) + F8S_BM * 4 + 16;
+// followed by i64h_gemm_fp8_ex, one launch, no quantized copy in memory).  K a multiple of 64 up to 8192.  Up to two problems
+// with the same epilogue per launch.
+static int fp8_rows_check(const i64h_fp8_rows_desc* d, int epilogue, const char* who) {
+    I64H_CHECK_ARG(d->M >= 0 && d->M < (1ll << 31) && d->N > 0 && d->K > 0 && d->K % 64 == 0 && d->K <= 8192,
+                   "%s: bad sizes (K=%d: a multiple of 64 up to 8192)", who, d->K);
+    I64H_CHECK_ARG(((uintptr_t)d->A | (uintptr_t)d->B) % 16 == 0, "%s: operands must be 16-byte aligned", who);
+    I64H_CHECK_ARG(d->num_groups >= 1 && d->num_groups <= 4096 && (d->group_offsets != nullptr || d->num_groups == 1), "%s: bad grouping", who);
+    I64H_CHECK_ARG(epilogue == 0 || (epilogue == 1 && d->N % 2 == 0), "%s: bad epilogue %d / N=%d", who, epilogue, d->N);
+    I64H_CHECK_ARG(d->a_src_row == nullptr || d->a_src_mod > 0, "%s: a_src_row needs a_src_mod > 0", who);
+    return 0;
+}
+static Fp8RowsArgs fp8_rows_args(const i64h_fp8_rows_desc* d) {
+    Fp8RowsArgs p;
+    p.A = d->A; p.a_src_row = d->a_src_row; p.a_src_mod = d->a_src_mod; p.B = d->B; p.b_scale = d->b_scale; p.group_off = d->group_offsets;
+    p.G = d->group_offsets ? d->num_groups : 1; p.M = (int)d->M; p.N = d->N; p.K = d->K; p.C = d->C; p.c_row_map = d->c_row_map;
+    return p;
+}
+static int64_t fp8_rows_blocks(const i64h_fp8_rows_desc* d, int epilogue) {
+    if (d->M == 0) return 0;
+    const int G = d->group_offsets ? d->num_groups : 1;
+    const int nout = epilogue ? d->N / 2 : d->N;
+    return ((d->M + F8S_BM - 1) / F8S_BM + G) * (int64_t)((nout + 63) / 64);
+}
+
+int i64h_gemm_fp8_rows_pair(const i64h_fp8_rows_desc* a, const i64h_fp8_rows_desc* b, int32_t epilogue, void* stream) {
+    I64H_CHECK_ARG(a != nullptr, "gemm_fp8_rows_pair: first problem missing");
+    if (fp8_rows_check(a, epilogue, "gemm_fp8_rows[0]")) return 1;
+    if (b && fp8_rows_check(b, epilogue, "gemm_fp8_rows[1]")) return 1;
+    if (b && a->M == 0) { a = b; b = nullptr; }
+    Fp8RowsPair pp;
+    pp.p[0] = fp8_rows_args(a);
+    pp.p[1] = fp8_rows_args(b ? b : a);
+    const int64_t n0 = fp8_rows_blocks(a, epilogue), n1 = b ? fp8_rows_blocks(b, epilogue) : 0;
+    I64H_CHECK_ARG(n0 + n1 < (1ll << 31), "gemm_fp8_rows: grid too large");
+    if (n0 + n1 == 0) return 0;
+    pp.nblk0 = (int)n0;
+    const int kmax = b && b->K > a->K ? b->K : a->K;
+    const size_t lds = (size_t)F8S_BM * (kmax + 32) + F8S_BM * 4 + 16;
     hipStream_t st = (hipStream_t)stream;
     if (epilogue) {
         if (lds > 64 * 1024 && raise_lds_limit((const void*)gemm_fp8_skinny_kernel<1>, 1)) return 1;
-        hipLaunchKernelGGL(gemm_fp8_skinny_kernel<1>, dim3((unsigned)(m_tiles * n_tiles)), dim3(256), lds, st, A, a_src_row, a_src_mod, B, b_scale,
-                           group_offsets, G, (int)M, N, K, C, c_row_map);
+        hipLaunchKernelGGL(gemm_fp8_skinny_kernel<1>, dim3((unsigned)(n0 + n1)), dim3(256), lds, st, pp);
     } else {
         if (lds > 64 * 1024 && raise_lds_limit((const void*)gemm_fp8_skinny_kernel<0>, 0)) return 1;
-        hipLaunchKernelGGL(gemm_fp8_skinny_kernel<0>, dim3((unsigned)(m_tiles * n_tiles)), dim3(256), lds, st, A, a_src_row, a_src_mod, B, b_scale,
-                           group_offsets, G, (int)M, N, K, C, c_row_map);
+        hipLaunchKernelGGL(gemm_fp8_skinny_kernel<0>, dim3((unsigned)(n0 + n1)), dim3(256), lds, st, pp);
     }
     I64H_CHECK_LAUNCH();
     return 0;
+}
+
+int i64h_gemm_fp8_rows(const float* A, const int32_t* a_src_row, int32_t a_src_mod, const uint8_t* B, const float* b_scale,
+                       const int32_t* group_offsets, int32_t num_groups, int64_t M, int32_t N, int32_t K, float* C,
+                       const int32_t* c_row_map, int32_t epilogue, void* stream) {
+    i64h_fp8_rows_desc d;
+    d.A = A; d.a_src_row = a_src_row; d.a_src_mod = a_src_mod; d.B = B; d.b_scale = b_scale; d.group_offsets = group_offsets;
+    d.num_groups = num_groups; d.M = M; d.N = N; d.K = K; d.C = C; d.c_row_map = c_row_map;
+    return i64h_gemm_fp8_rows_pair(&d, nullptr, epilogue, stream);
 }
 
 }  // extern "C"

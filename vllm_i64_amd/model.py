@@ -519,15 +519,28 @@ class I64MoEModel:
             if cfg.is_moe:
                 plan = B.plan
                 R = plan.rows
-                if R:
-                    # rows in bucket order are grouped by expert; the gather out of the token rows and the scatter back into
-                    # (route, token) order ride in the GEMMs
-                    linear(x_in, B.xa, B.xs, W["exp_gu"], B.e_inter, m=R, a_src_row=plan.perm[l], a_src_mod=n,
-                           group_offsets=plan.expert_offsets[l], epilogue=ops.EPI_SWIGLU)
-                    linear(B.e_inter, B.eia, B.eis, W["exp_dn"], B.e_out, group_offsets=plan.expert_offsets[l], c_row_map=plan.perm[l])
-                if S:
-                    linear(x_in, B.xa, B.xs, W["sh_gu"], B.sh_inter, epilogue=ops.EPI_SWIGLU)
-                    linear(B.sh_inter, B.sha, B.shs, W["sh_dn"], B.sh_out)
+                paired = (fused_in and R and S and ops.fp8_rows_ok(cfg.expert_inter) and ops.fp8_rows_ok(S))
+                if paired:
+                    # decode-sized step: two launches, each with the routed experts (rows gathered in bucket order = grouped by
+                    # expert, results scattered back into (route, token) order) and the shared expert as its second problem
+                    ops.gemm_fp8_rows_pair(
+                        ops.fp8_rows_desc(B.normed, W["exp_gu"].w_q, W["exp_gu"].w_s, B.e_inter, m=R, a_src_row=plan.perm[l], a_src_mod=n,
+                                          group_offsets=plan.expert_offsets[l]),
+                        ops.fp8_rows_desc(B.normed, W["sh_gu"].w_q, W["sh_gu"].w_s, B.sh_inter), epilogue=ops.EPI_SWIGLU)
+                    ops.gemm_fp8_rows_pair(
+                        ops.fp8_rows_desc(B.e_inter, W["exp_dn"].w_q, W["exp_dn"].w_s, B.e_out, group_offsets=plan.expert_offsets[l],
+                                          c_row_map=plan.perm[l]),
+                        ops.fp8_rows_desc(B.sh_inter, W["sh_dn"].w_q, W["sh_dn"].w_s, B.sh_out))
+                else:
+                    if R:
+                        # rows in bucket order are grouped by expert; the gather out of the token rows and the scatter back into
+                        # (route, token) order ride in the GEMMs
+                        linear(x_in, B.xa, B.xs, W["exp_gu"], B.e_inter, m=R, a_src_row=plan.perm[l], a_src_mod=n,
+                               group_offsets=plan.expert_offsets[l], epilogue=ops.EPI_SWIGLU)
+                        linear(B.e_inter, B.eia, B.eis, W["exp_dn"], B.e_out, group_offsets=plan.expert_offsets[l], c_row_map=plan.perm[l])
+                    if S:
+                        linear(x_in, B.xa, B.xs, W["sh_gu"], B.sh_inter, epilogue=ops.EPI_SWIGLU)
+                        linear(B.sh_inter, B.sha, B.shs, W["sh_dn"], B.sh_out)
                 ops.fused_residual_norm(B.h, nxt, eps, moe_rows=B.e_out, moe_inv=None, moe_shared=B.sh_out if S else None,
                                         route_weights=rw, routed_scale=W["routed_scale"], shared_scale=W["shared_scale"], h_out=B.h,
                                         normed=B.normed)

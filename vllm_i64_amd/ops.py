@@ -273,6 +273,25 @@ def gemm_fp8_rows(a: torch.Tensor, w: torch.Tensor, w_scale: torch.Tensor, out: 
     return out
 
 
+def fp8_rows_desc(a: torch.Tensor, w: torch.Tensor, w_scale: torch.Tensor, out: torch.Tensor, *, m: Optional[int] = None, a_src_row=None,
+                  a_src_mod: int = 0, group_offsets=None, c_row_map=None):
+    """One problem of gemm_fp8_rows_pair (arguments as gemm_fp8_rows)."""
+    _chk(a, torch.float32, "a")
+    if w.dim() == 2:
+        w, w_scale = w.unsqueeze(0), w_scale.reshape(1, -1)
+    G, N, K = w.shape
+    assert a.shape[1] == K
+    d = _lib.Fp8RowsDesc()
+    d.A, d.a_src_row, d.a_src_mod, d.B, d.b_scale = ptr(a), ptr(a_src_row), a_src_mod, ptr(w), ptr(w_scale)
+    d.group_offsets, d.num_groups, d.M, d.N, d.K = ptr(group_offsets), G, m if m is not None else a.shape[0], N, K
+    d.C, d.c_row_map = ptr(out), ptr(c_row_map)
+    return d
+
+
+def gemm_fp8_rows_pair(a_desc, b_desc=None, epilogue: int = EPI_STORE):
+    call("i64h_gemm_fp8_rows_pair", ctypes.addressof(a_desc), ctypes.addressof(b_desc) if b_desc is not None else 0, epilogue, _stream())
+
+
 def fp8_rows_ok(k: int) -> bool:
     return k % 64 == 0 and k <= 8192
 
