@@ -1,4 +1,4 @@
-# Round-end measurement set on the GPU box: GPU tests, the default bench line, its rocprofv3 kernel summary, the HBM counter passes.
+# Measurement set on the GPU box: GPU tests, the default bench line, its rocprofv3 kernel summary, the HBM counter passes.
 # usage (from the repository root on the box): bash tools/final_measure.sh <tag>     (results under gpurun_out/<tag>/)
 set -e
 TAG=${1:-final}
