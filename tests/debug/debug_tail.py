@@ -1,6 +1,6 @@
 """Compare the intermediate buffers of the persistent decode launch with the launch-per-call path (1- and 2-layer cuts)."""
 import dataclasses, sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import model_ref as M
 from vllm_i64_amd.config import ModelConfig
