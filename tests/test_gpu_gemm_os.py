@@ -1,0 +1,120 @@
+"""GPU parity tests of the operand-stationary int8 GEMM (weights as a fragment pack): exact int32 accumulators against a
+float64 product, and bit-identity with the row-major-weight kernels on the SwiGLU epilogue and its statistics.  -m gpu."""
+import warnings
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+warnings.filterwarnings("ignore")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from vllm_i64_amd import _lib
+    lib = _lib.load()
+    assert lib.i64h_device_check() == 0, lib.i64h_last_error().decode()
+    return torch.device("cuda:0")
+
+
+def _ops():
+    from vllm_i64_amd import ops
+    return ops
+
+
+def test_weight_fragment_pack_layout(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    G, N, K = 3, 48, 192
+    w = torch.randint(-128, 128, (G, N, K), generator=g, dtype=torch.int8)
+    packed = ops.pack_weight_frags(w.to(dev)).cpu()
+    # fragment (g, c, ks): lane l = 16 fq + fr holds row 16 c + fr, K bytes [64 ks + 16 fq, + 16)
+    want = w.view(G, N // 16, 16, K // 64, 4, 16).permute(0, 1, 3, 4, 2, 5).reshape(G, N // 16, K // 64, 1024)
+    assert torch.equal(packed, want)
+
+
+def _offsets(M_, G_, g):
+    cuts = sorted(torch.randint(0, M_ + 1, (G_ - 1,), generator=g).tolist()) if G_ > 1 else []
+    if G_ > 2:
+        cuts[1] = cuts[0]  # an empty group
+    return [0] + cuts + [M_]
+
+
+@pytest.mark.parametrize("depth", [2, 3, 4])
+@pytest.mark.parametrize("M_,N_,K_,G_", [(1, 64, 64, 1), (77, 192, 448, 1), (4133, 128, 256, 3), (9000, 1024, 448, 8), (2500, 1536, 1024, 1),
+                                          (40000, 64, 128, 5)])
+def test_gemm_i8_frags_exact(dev, M_, N_, K_, G_, depth):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M_ * 3 + N_ + depth)
+    a = torch.randint(-127, 128, (M_, K_), generator=g, dtype=torch.int8)
+    w = torch.randint(-128, 128, (G_, N_, K_), generator=g, dtype=torch.int8)
+    off = _offsets(M_, G_, g)
+    rs = torch.rand(M_, generator=g) + 0.5
+    ws = torch.rand(G_, generator=g) + 0.5
+    ref = torch.empty(M_, N_)
+    for gi in range(G_):
+        s, e = off[gi], off[gi + 1]
+        ref[s:e] = (a[s:e].double() @ w[gi].double().t()).float() * (rs[s:e].unsqueeze(1) * ws[gi])
+    assert ops.gemm_i8_frags_ok(N_, K_, ops.EPI_STORE)
+    ops.call("i64h_set_gemm_os", 256, depth)
+    try:
+        wf = ops.pack_weight_frags(w.to(dev))
+        out = ops.gemm_i8_frags(a.to(dev), rs.to(dev), wf, ws.to(dev), N_,
+                                group_offsets=torch.tensor(off, dtype=torch.int32, device=dev) if G_ > 1 else None)
+    finally:
+        ops.call("i64h_set_gemm_os", 256, 3)
+    assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("grid", [256, 40])
+@pytest.mark.parametrize("I_,K_", [(448, 1024), (64, 128), (1792, 1024), (96, 320)])
+def test_gemm_i8_frags_swiglu_and_stats_match_the_row_major_kernels(dev, I_, K_, grid):
+    ops = _ops()
+    g = torch.Generator().manual_seed(13 + I_)
+    M_, G_ = 4133, 3
+    a = torch.randint(-127, 128, (M_, K_), generator=g, dtype=torch.int8).to(dev)
+    w = torch.randint(-128, 128, (G_, 2 * I_, K_), generator=g, dtype=torch.int8).to(dev)
+    off = torch.tensor([0, 1500, 1500, M_], dtype=torch.int32, device=dev)
+    rs = ((torch.rand(M_, generator=g) + 0.5) * 1e-3).to(dev)
+    ws = ((torch.rand(G_, generator=g) + 0.5) * 1e-2).to(dev)
+    slot = torch.randint(0, 4, (M_,), generator=g, dtype=torch.int32).to(dev)
+    stats_a, stats_b = ops.stats_alloc(8, dev), ops.stats_alloc(8, dev)
+    ops.stats_reset(stats_a)
+    ops.stats_reset(stats_b)
+    ops.call("i64h_set_gemm_rowstream", 2)
+    ops.call("i64h_set_gemm_os", grid, 3)
+    try:
+        want = ops.gemm_i8(a, rs, w, ws, group_offsets=off, epilogue=ops.EPI_SWIGLU, row_slot=slot, slot_base=2, stats=stats_a)
+        got = ops.gemm_i8_frags(a, rs, ops.pack_weight_frags(w), ws, 2 * I_, group_offsets=off, epilogue=ops.EPI_SWIGLU, row_slot=slot,
+                                slot_base=2, stats=stats_b)
+    finally:
+        ops.call("i64h_set_gemm_rowstream", 1)
+        ops.call("i64h_set_gemm_os", 256, 3)
+    assert torch.equal(got, want)
+    assert torch.equal(ops.qparams(stats_a, 8)[2], ops.qparams(stats_b, 8)[2])
+    lohi, o = ops.qparams(stats_b, 8)[2].cpu(), got.cpu()
+    for s in range(4):
+        rows = o[(slot == s).cpu()]
+        assert lohi[2 + s, 0] == min(rows.min().item(), 0.0) and lohi[2 + s, 1] == max(rows.max().item(), 0.0)
+
+
+def test_gemm_i8_frags_column_scale(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    M_, N_, K_ = 700, 256, 512
+    a = torch.randint(-127, 128, (M_, K_), generator=g, dtype=torch.int8)
+    w = torch.randint(-128, 128, (1, N_, K_), generator=g, dtype=torch.int8)
+    rs = torch.rand(M_, generator=g) + 0.5
+    cs = torch.rand(N_, generator=g) + 0.5
+    ref = (a.double() @ w[0].double().t()).float() * (rs.unsqueeze(1) * cs.unsqueeze(0))
+    out = ops.gemm_i8_frags(a.to(dev), rs.to(dev), ops.pack_weight_frags(w.to(dev)), cs.to(dev), N_, col_scale=cs.to(dev))
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_gemm_i8_frags_refuses_unsupported_shapes(dev):
+    ops = _ops()
+    assert not ops.gemm_i8_frags_ok(1024, 1792, ops.EPI_STORE)  # 128 rows x K bytes beyond LDS
+    assert not ops.gemm_i8_frags_ok(100, 256, ops.EPI_STORE)
+    assert not ops.gemm_i8_frags_ok(128, 96, ops.EPI_SWIGLU)

@@ -123,6 +123,31 @@ def bench_gemm():
     print(f"gemm down pair    (experts 8x[~16,448]x1024 + shared [64,1792]x1024): {med:6.1f}/{best:6.1f} us; weights {(E * ei * H + S * H) / 1e6:.2f} MB")
 
 
+def bench_gemm_os(only=None):
+    """The operand-stationary kernel (weights as a fragment pack) on the prefill shapes it takes, per depth of its weight stream."""
+    torch.manual_seed(0)
+    shapes = [("expert gate_up (grouped, SwiGLU)", 32768, 896, 1024, 8, 1), ("expert down (grouped)", 32768, 1024, 448, 8, 0),
+              ("shared gate_up (SwiGLU)", 16384, 3584, 1024, 1, 1), ("qkv", 16384, 1536, 1024, 1, 0), ("o", 16384, 1024, 1024, 1, 0)]
+    for name, M, N, K, G, epi in shapes:
+        if only and only not in name:
+            continue
+        a = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=dev)
+        w = torch.randint(-128, 128, (G, N, K), dtype=torch.int8, device=dev)
+        wf = ops.pack_weight_frags(w)
+        rs = torch.rand(M, device=dev) * 1e-3
+        ws = torch.rand(G, device=dev) * 1e-2
+        off = (torch.arange(G + 1, device=dev) * (M // G)).to(torch.int32) if G > 1 else None
+        out = torch.empty(M, N // 2 if epi else N, device=dev)
+        for grid, depth in ((256, 2), (256, 3), (256, 4), (248, 3)):
+            ops.call("i64h_set_gemm_os", grid, depth)
+            med, best = timeit(lambda: ops.gemm_i8_frags(a, rs, wf, ws, N, group_offsets=off, epilogue=epi, out=out), iters=5, warm=2, inner=5)
+            print(f"gemm_i8_frags {name:34s} M={M} N={N} K={K} G={G} grid {grid} depth {depth}: {med:8.1f} us -> "
+                  f"{2 * M * N * K / med / 1e6:7.1f} TOP/s ({2 * M * N * K / med / 1e6 / 5000 * 100:4.1f}% of 5 POP/s)")
+        ops.call("i64h_set_gemm_os", 256, 3)
+        ref = ops.gemm_i8(a, rs, w, ws, group_offsets=off, epilogue=epi)
+        print("   equal to the row-major-weight kernel:", bool(torch.equal(ref, ops.gemm_i8_frags(a, rs, wf, ws, N, group_offsets=off, epilogue=epi))))
+
+
 def bench_gemm_prefill(only=None):
     """Prefill-shaped int8 GEMMs (operands already quantized): achieved int8 TOP/s = 2*M*N*K / time."""
     torch.manual_seed(0)
@@ -172,6 +197,9 @@ if __name__ == "__main__":
     if what == "gemm1":  # one shape, one variant: python tools/kbench.py gemm1 <variant> <name substring> (for counter passes)
         ops.call("i64h_set_gemm_rowstream", int(sys.argv[2]))  # variant: 0 = LDS-tiled kernel, 2 = row-streaming kernel
         bench_gemm_prefill(sys.argv[3])
+        sys.exit(0)
+    if what == "gemmos":
+        bench_gemm_os(sys.argv[2] if len(sys.argv) > 2 else None)
         sys.exit(0)
     if what == "attnp":
         bench_attn_prefill()

@@ -76,6 +76,10 @@ SIGNATURES: Dict[str, str] = {
     "i64h_set_gemm_stage64": "i",
     "i64h_set_gemm_rowstream": "i",
     "i64h_set_gemm_rs_grid": "ii",
+    "i64h_pack_weight_frags": "ppiiip",
+    "i64h_gemm_i8_frags": "pppppiliipipippp",
+    "i64h_gemm_i8_frags_ok": "iii",
+    "i64h_set_gemm_os": "ii",
 }
 _KIND = {"p": _P, "i": _I, "l": _L, "f": _F}
 

@@ -210,6 +210,39 @@ def gemm_i8(a: torch.Tensor, row_scale: torch.Tensor, w: torch.Tensor, w_scale: 
     return out
 
 
+def pack_weight_frags(w: torch.Tensor) -> torch.Tensor:
+    """int8 weights [G, N, K] (or [N, K]) -> the fragment pack of i64h_gemm_i8_frags (same bytes, [G, N/16, K/64, 1024])."""
+    _chk(w, torch.int8, "w")
+    if w.dim() == 2:
+        w = w.unsqueeze(0)
+    G, N, K = w.shape
+    out = torch.empty(G, N // 16, K // 64, 1024, dtype=torch.int8, device=w.device)
+    call("i64h_pack_weight_frags", ptr(w.contiguous()), ptr(out), G, N, K, _stream())
+    return out
+
+
+def gemm_i8_frags_ok(N: int, K: int, epilogue: int = EPI_STORE) -> bool:
+    return bool(_lib.load().i64h_gemm_i8_frags_ok(N, K, epilogue))
+
+
+def gemm_i8_frags(a: torch.Tensor, row_scale: torch.Tensor, w_frags: torch.Tensor, w_scale: torch.Tensor, N: int,
+                  group_offsets: Optional[torch.Tensor] = None, epilogue: int = EPI_STORE, row_slot: Optional[torch.Tensor] = None,
+                  slot_base: int = 0, stats: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                  col_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """gemm_i8 with the weights as a fragment pack (pack_weight_frags): the operand-stationary kernel for prefill-sized
+    problems with K <= 1024.  Same results bit for bit."""
+    _chk(a, torch.int8, "a"), _chk(w_frags, torch.int8, "w_frags"), _chk(row_scale, torch.float32, "row_scale")
+    M, K = a.shape
+    G = w_frags.shape[0]
+    assert w_frags.numel() == G * N * K
+    n_out = N // 2 if epilogue == EPI_SWIGLU else N
+    if out is None:
+        out = torch.empty(M, n_out, dtype=torch.float32, device=a.device)
+    call("i64h_gemm_i8_frags", ptr(a), ptr(row_scale), ptr(w_frags), ptr(w_scale), ptr(group_offsets), G, M, N, K, ptr(out), epilogue,
+         ptr(row_slot), slot_base, ptr(stats), ptr(col_scale), _stream())
+    return out
+
+
 def gemm_desc(a: torch.Tensor, w: torch.Tensor, w_scale: torch.Tensor, out: torch.Tensor, *, row_scale=None, a_src_row=None,
               a_src_mod: int = 0, a_row_slot=None, a_slot_base: int = 0, group_offsets=None, epilogue: int = EPI_STORE,
               out_row_slot=None, out_slot_base: int = 0, stats=None, want_stats: bool = False, m_total: Optional[int] = None,
