@@ -380,7 +380,7 @@ def main():
             if fp8:
                 ops.gemm_fp8(a8, rs, Wg.w_q, Wg.w_s, o8, group_offsets=Bp.plan.expert_offsets[0], epilogue=ops.EPI_SWIGLU)
             else:
-                ops.gemm_i8(a8, rs, Wg.w_q, Wg.w_s, group_offsets=Bp.plan.expert_offsets[0], epilogue=ops.EPI_SWIGLU, out=o8)
+                gm._gemm_i8(a8, rs, Wg, o8, group_offsets=Bp.plan.expert_offsets[0], epilogue=ops.EPI_SWIGLU)  # the runner's own dispatch
             e1.record()
             gevs.append((e0, e1))
         torch.cuda.synchronize()
@@ -389,7 +389,10 @@ def main():
         g_ops = 2.0 * R * (2 * cfg.expert_inter) * cfg.hidden_size
         tops = g_ops / (g_ms * 1e-3) / 1e12
         mfma = {"bound": "mfma", "kernel": ("gemm_fp8_kernel<SWIGLU> (v_mfma_f32_16x16x32_fp8_fp8: the non-scaled form, which runs at the bf16 "
-                                            "rate, half the peak below)" if fp8 else "gemm_i8_rs_kernel<SWIGLU>") +
+                                            "rate, half the peak below)" if fp8 else
+                                           ("gemm_i8_os_kernel<SWIGLU> (operand-stationary, weights as a fragment pack)"
+                                            if R >= gm.FRAGS_MIN_ROWS and ops.gemm_i8_frags_ok(2 * cfg.expert_inter, cfg.hidden_size, ops.EPI_SWIGLU)
+                                            else "gemm_i8_rs_kernel<SWIGLU>")) +
                 " grouped expert gate_up, one prefill chunk",
                 "achieved": round(tops, 1), "peak": MFMA_I8_PEAK_TOPS, "unit": "TFLOP/s" if fp8 else "TOP/s", "frac": round(tops / MFMA_I8_PEAK_TOPS, 4),
                 "traffic": None, "avg_launch_ms": round(g_ms, 4), "algorithmic_ops_per_launch": g_ops, "rows": R,

@@ -137,7 +137,7 @@ int i64h_gemm_i8_qkv_rope_kv(const i64h_gemm_desc* d, const float* q_norm_w, con
 int i64h_gemm_i8_colscale(const int8_t* A, const float* row_scale, const int8_t* B, const float* col_scale, int64_t M, int32_t N, int32_t K,
                           float* C, void* stream);
 /* Operand-stationary form of i64h_gemm_i8 for prefill-sized problems with a short K (K % 64 == 0, 128 rows x K bytes must fit
- * LDS: K <= 1024; N % 64 == 0): a workgroup keeps 128 operand rows in LDS for all output columns, the weights are read as a
+ * LDS: K <= 1024; N % 32 == 0): a workgroup keeps 128 operand rows in LDS for all output columns, the weights are read as a
  * fragment pack made once by i64h_pack_weight_frags ([G][N/16][K/64] pieces of 1 KB in matrix-core lane order).  Results are
  * bit-identical to i64h_gemm_i8.  Same reference counterpart as i64h_gemm_i8 (csrc/i64_expert_dispatch.cu:144-233,
  * token_routed_mlp.py:135-144); the pack replaces nothing in the reference (its weights stay in the nn.Linear layout). */
@@ -146,7 +146,11 @@ int i64h_gemm_i8_frags(const int8_t* A, const float* row_scale, const int8_t* B_
                        int32_t num_groups, int64_t M_total, int32_t N, int32_t K, float* C, int32_t epilogue, const int32_t* row_slot,
                        int32_t slot_base, uint32_t* stats, const float* col_scale, void* stream);
 int i64h_gemm_i8_frags_ok(int32_t N, int32_t K, int32_t epilogue); /* 1 if i64h_gemm_i8_frags takes the shape (returns a flag, not a status) */
-int i64h_set_gemm_os(int32_t workgroups, int32_t depth); /* tuning knobs of the operand-stationary kernel: persistent grid (default 256) and K steps of weight fragments in flight per wave (2-4) */
+int i64h_debug_set_os_stamps(void* buffer); /* diagnostics: 64 uint64 per workgroup (8 waves x 8 s_memtime stamps of its first tile); NULL = off */
+int i64h_set_gemm_os_waves(int32_t waves); /* tuning knob of the operand-stationary kernel: waves per workgroup, 8 (blocks of 64 columns), 12 (blocks of 32 columns), 0 = chosen by epilogue (default) */
+int i64h_set_gemm_os_tall(int32_t on); /* tuning knob of the operand-stationary kernel: 0 = tiles of 128 rows only (default 1: 144-row tiles when they need fewer rounds of the grid) */
+int i64h_set_gemm_os_rotation(int32_t k_stride); /* tuning knob of the operand-stationary kernel: wave v of workgroup w starts at K step (w * k_stride + v) mod steps; 0 = off */
+int i64h_set_gemm_os(int32_t workgroups, int32_t depth); /* tuning knobs of the operand-stationary kernel: persistent grid (default 256) and K steps of weight fragments in flight per wave (2 or 3) */
 int i64h_set_gemm_rowstream(int32_t mode); /* tuning knob: int8 problems with >= 1024 rows per group that use the row-streaming kernel: 0 none, 1 SwiGLU epilogue only (default), 2 every epilogue */
 int i64h_set_gemm_rs_grid(int32_t workgroups, int32_t stagger_cycles); /* tuning knobs of the row-streaming kernel: size of its persistent grid (default 512) and start delay of the grid's second half (default 0) */
 int i64h_set_gemm_rs_depth(int32_t depth); /* tuning knob of the row-streaming kernel: K steps of operand fragments in flight per wave, 2 (default) or 4 */

@@ -42,9 +42,9 @@ def _offsets(M_, G_, g):
     return [0] + cuts + [M_]
 
 
-@pytest.mark.parametrize("depth", [2, 3, 4])
-@pytest.mark.parametrize("M_,N_,K_,G_", [(1, 64, 64, 1), (77, 192, 448, 1), (4133, 128, 256, 3), (9000, 1024, 448, 8), (2500, 1536, 1024, 1),
-                                          (40000, 64, 128, 5)])
+@pytest.mark.parametrize("depth", [2, 3])
+@pytest.mark.parametrize("M_,N_,K_,G_", [(1, 64, 64, 1), (77, 192, 448, 1), (4133, 160, 256, 3), (9000, 1024, 448, 8), (2500, 1536, 1024, 1),
+                                          (40000, 32, 128, 5), (300, 1120, 192, 2)])
 def test_gemm_i8_frags_exact(dev, M_, N_, K_, G_, depth):
     ops = _ops()
     g = torch.Generator().manual_seed(M_ * 3 + N_ + depth)
@@ -64,12 +64,12 @@ def test_gemm_i8_frags_exact(dev, M_, N_, K_, G_, depth):
         out = ops.gemm_i8_frags(a.to(dev), rs.to(dev), wf, ws.to(dev), N_,
                                 group_offsets=torch.tensor(off, dtype=torch.int32, device=dev) if G_ > 1 else None)
     finally:
-        ops.call("i64h_set_gemm_os", 256, 3)
+        ops.call("i64h_set_gemm_os", 256, 2)
     assert torch.equal(out.cpu(), ref)
 
 
 @pytest.mark.parametrize("grid", [256, 40])
-@pytest.mark.parametrize("I_,K_", [(448, 1024), (64, 128), (1792, 1024), (96, 320)])
+@pytest.mark.parametrize("I_,K_", [(448, 1024), (64, 128), (1792, 1024), (96, 320), (16, 64), (272, 512)])
 def test_gemm_i8_frags_swiglu_and_stats_match_the_row_major_kernels(dev, I_, K_, grid):
     ops = _ops()
     g = torch.Generator().manual_seed(13 + I_)
@@ -85,19 +85,46 @@ def test_gemm_i8_frags_swiglu_and_stats_match_the_row_major_kernels(dev, I_, K_,
     ops.stats_reset(stats_b)
     ops.call("i64h_set_gemm_rowstream", 2)
     ops.call("i64h_set_gemm_os", grid, 3)
+    ops.call("i64h_set_gemm_os_rotation", 3 if grid == 40 else 0)
     try:
         want = ops.gemm_i8(a, rs, w, ws, group_offsets=off, epilogue=ops.EPI_SWIGLU, row_slot=slot, slot_base=2, stats=stats_a)
         got = ops.gemm_i8_frags(a, rs, ops.pack_weight_frags(w), ws, 2 * I_, group_offsets=off, epilogue=ops.EPI_SWIGLU, row_slot=slot,
                                 slot_base=2, stats=stats_b)
     finally:
         ops.call("i64h_set_gemm_rowstream", 1)
-        ops.call("i64h_set_gemm_os", 256, 3)
+        ops.call("i64h_set_gemm_os", 256, 2)
+        ops.call("i64h_set_gemm_os_rotation", 0)
     assert torch.equal(got, want)
     assert torch.equal(ops.qparams(stats_a, 8)[2], ops.qparams(stats_b, 8)[2])
     lohi, o = ops.qparams(stats_b, 8)[2].cpu(), got.cpu()
     for s in range(4):
         rows = o[(slot == s).cpu()]
         assert lohi[2 + s, 0] == min(rows.min().item(), 0.0) and lohi[2 + s, 1] == max(rows.max().item(), 0.0)
+
+
+@pytest.mark.parametrize("waves,tall", [(8, 0), (8, 1), (12, 0), (12, 1)])
+def test_gemm_i8_frags_tile_heights_and_wave_counts(dev, waves, tall):
+    """Eight ragged groups of about 4096 rows: 260 tiles of 128 rows or 232 of 144 (what the kernel picks when `tall` is allowed)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(waves + tall)
+    G_, N_, K_ = 8, 128, 256
+    sizes = (4096 + torch.randint(-90, 91, (G_,), generator=g)).tolist()
+    M_ = sum(sizes)
+    off = torch.tensor([0] + torch.tensor(sizes).cumsum(0).tolist(), dtype=torch.int32)
+    a = torch.randint(-127, 128, (M_, K_), generator=g, dtype=torch.int8).to(dev)
+    w = torch.randint(-128, 128, (G_, N_, K_), generator=g, dtype=torch.int8).to(dev)
+    rs = (torch.rand(M_, generator=g) + 0.5).to(dev)
+    ws = (torch.rand(G_, generator=g) + 0.5).to(dev)
+    ops.call("i64h_set_gemm_os_waves", waves)
+    ops.call("i64h_set_gemm_os_tall", tall)
+    try:
+        for epi in (ops.EPI_STORE, ops.EPI_SWIGLU):
+            got = ops.gemm_i8_frags(a, rs, ops.pack_weight_frags(w), ws, N_, group_offsets=off.to(dev), epilogue=epi)
+            want = ops.gemm_i8(a, rs, w, ws, group_offsets=off.to(dev), epilogue=epi)
+            assert torch.equal(got, want)
+    finally:
+        ops.call("i64h_set_gemm_os_waves", 0)
+        ops.call("i64h_set_gemm_os_tall", 1)
 
 
 def test_gemm_i8_frags_column_scale(dev):
@@ -118,3 +145,4 @@ def test_gemm_i8_frags_refuses_unsupported_shapes(dev):
     assert not ops.gemm_i8_frags_ok(1024, 1792, ops.EPI_STORE)  # 128 rows x K bytes beyond LDS
     assert not ops.gemm_i8_frags_ok(100, 256, ops.EPI_STORE)
     assert not ops.gemm_i8_frags_ok(128, 96, ops.EPI_SWIGLU)
+    assert not ops.gemm_i8_frags_ok(48, 128, ops.EPI_SWIGLU)

@@ -123,7 +123,7 @@ def bench_gemm():
     print(f"gemm down pair    (experts 8x[~16,448]x1024 + shared [64,1792]x1024): {med:6.1f}/{best:6.1f} us; weights {(E * ei * H + S * H) / 1e6:.2f} MB")
 
 
-def bench_gemm_os(only=None):
+def bench_gemm_os(only=None, ragged=False):
     """The operand-stationary kernel (weights as a fragment pack) on the prefill shapes it takes, per depth of its weight stream."""
     torch.manual_seed(0)
     shapes = [("expert gate_up (grouped, SwiGLU)", 32768, 896, 1024, 8, 1), ("expert down (grouped)", 32768, 1024, 448, 8, 0),
@@ -137,13 +137,21 @@ def bench_gemm_os(only=None):
         rs = torch.rand(M, device=dev) * 1e-3
         ws = torch.rand(G, device=dev) * 1e-2
         off = (torch.arange(G + 1, device=dev) * (M // G)).to(torch.int32) if G > 1 else None
+        if G > 1 and ragged:  # group sizes as a real chunk has them: binomial around M / G
+            cnt = torch.bincount(torch.randint(0, G, (M,), device=dev), minlength=G)
+            off = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), cnt.cumsum(0)]).to(torch.int32)
         out = torch.empty(M, N // 2 if epi else N, device=dev)
-        for grid, depth in ((256, 2), (256, 3), (256, 4), (248, 3)):
-            ops.call("i64h_set_gemm_os", grid, depth)
+        for waves, depth in ((8, 2), (8, 3), (12, 2), (12, 3)):
+            ops.call("i64h_set_gemm_os", 256, depth)
+            ops.call("i64h_set_gemm_os_waves", waves)
             med, best = timeit(lambda: ops.gemm_i8_frags(a, rs, wf, ws, N, group_offsets=off, epilogue=epi, out=out), iters=5, warm=2, inner=5)
-            print(f"gemm_i8_frags {name:34s} M={M} N={N} K={K} G={G} grid {grid} depth {depth}: {med:8.1f} us -> "
+            print(f"gemm_i8_frags {name:34s} M={M} N={N} K={K} G={G} waves {waves} depth {depth}: {med:8.1f} us -> "
                   f"{2 * M * N * K / med / 1e6:7.1f} TOP/s ({2 * M * N * K / med / 1e6 / 5000 * 100:4.1f}% of 5 POP/s)")
-        ops.call("i64h_set_gemm_os", 256, 3)
+            ok = bool(torch.equal(ops.gemm_i8(a, rs, w, ws, group_offsets=off, epilogue=epi), out))
+            if not ok:
+                print("   NOT equal to the row-major-weight kernel")
+        ops.call("i64h_set_gemm_os", 256, 2)
+        ops.call("i64h_set_gemm_os_waves", 0)
         ref = ops.gemm_i8(a, rs, w, ws, group_offsets=off, epilogue=epi)
         print("   equal to the row-major-weight kernel:", bool(torch.equal(ref, ops.gemm_i8_frags(a, rs, wf, ws, N, group_offsets=off, epilogue=epi))))
 
@@ -198,8 +206,8 @@ if __name__ == "__main__":
         ops.call("i64h_set_gemm_rowstream", int(sys.argv[2]))  # variant: 0 = LDS-tiled kernel, 2 = row-streaming kernel
         bench_gemm_prefill(sys.argv[3])
         sys.exit(0)
-    if what == "gemmos":
-        bench_gemm_os(sys.argv[2] if len(sys.argv) > 2 else None)
+    if what in ("gemmos", "gemmosr"):  # gemmosr: ragged groups
+        bench_gemm_os(sys.argv[2] if len(sys.argv) > 2 else None, ragged=what == "gemmosr")
         sys.exit(0)
     if what == "attnp":
         bench_attn_prefill()

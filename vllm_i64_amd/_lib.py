@@ -80,6 +80,10 @@ SIGNATURES: Dict[str, str] = {
     "i64h_gemm_i8_frags": "pppppiliipipippp",
     "i64h_gemm_i8_frags_ok": "iii",
     "i64h_set_gemm_os": "ii",
+    "i64h_set_gemm_os_rotation": "i",
+    "i64h_set_gemm_os_waves": "i",
+    "i64h_set_gemm_os_tall": "i",
+    "i64h_debug_set_os_stamps": "p",
 }
 _KIND = {"p": _P, "i": _I, "l": _L, "f": _F}
 

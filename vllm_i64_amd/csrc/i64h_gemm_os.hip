@@ -20,7 +20,6 @@
 #include "i64h_gemm_dev.h"
 
 #define OS_BM 128
-#define OS_NT 512
 
 typedef __attribute__((address_space(3))) void os_lds_void;
 typedef __attribute__((address_space(1))) const void os_gbl_void;
@@ -47,18 +46,164 @@ __global__ __launch_bounds__(256) void pack_frags_kernel(const int8_t* __restric
     *(v4i*)(out + f * 1024 + lane * 16) = v;
 }
 
-template <int EPI, int DB>
-__global__ __launch_bounds__(OS_NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void gemm_i8_os_kernel(GemmI8Args p, const int8_t* __restrict__ Bf, int n_items, int parts, int nblk) {
+// One block of a tile: all 128 rows x W units, a unit being two weight fragment columns (SwiGLU: 16 gate columns and their 16 up
+// partners; plain: 32 adjacent columns).  u0 = first unit; sp = this wave's stamp slots or nullptr.
+template <int EPI, int DB, int W, int MFR>
+__device__ __forceinline__ void os_block(const GemmI8Args& p, const char* Bg, const int KS, const int rk, const int u0, const int g, const int row0,
+                                         const int rows, const float ws, const bool st, const int item, const int lane, unsigned long long* sp) {
+    // the LDS regions are re-derived from the array itself: pointers handed in as arguments lose their address space
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const char* img = smem;
+    char* tail = smem + (size_t)KS * (MFR * 1024);
+    const float* s_rs = (const float*)tail;
+    const int* s_rel = (const int*)(tail + MFR * 64);
+    uint32_t* tab_lo = (uint32_t*)(tail + MFR * 128);
+    uint32_t* tab_hi = tab_lo + I64H_STAT_TAB;
+    constexpr int NJ = 2 * W;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int I = p.N / 2;
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+    int cj[NJ];
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+        if (EPI == EPI_SWIGLU) cj[jj] = jj < W ? u0 + jj : (I >> 4) + u0 + (jj - W);
+        else cj[jj] = 2 * u0 + jj;
+    }
+    uint32_t bo[NJ];  // wave-uniform byte offsets inside the group's pack
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bo[j] = (uint32_t)cj[j] * (uint32_t)KS * 1024u;
+    auto kof = [&](int k) {  // K step k of this wave's order -> step of the matrix
+        int kk = min(k, KS - 1) + rk;
+        return kk >= KS ? kk - KS : kk;
+    };
+    auto bfrag = [&](int j, int kk) { return *(const v4i*)(Bg + (bo[j] + (uint32_t)kk * 1024u) + lane16); };
+    auto afrag = [&](int i, int kk) { return *(const v4i*)(img + (uint32_t)(kk * MFR + i) * 1024u + lane16); };
+
+    v4i acc[MFR][NJ];
+#pragma unroll
+    for (int i = 0; i < MFR; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (v4i){0, 0, 0, 0};
+    v4i bq[DB][NJ], af[MFR];
+    {
+        // the weight fragments of the first DB steps, oldest first: the counted waits of the loop rely on this order
+#pragma unroll
+        for (int u = 0; u < DB; ++u) {
+            const int kk = kof(u);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bq[u][j] = bfrag(j, kk);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+            const int kk = kof(0);
+#pragma unroll
+            for (int i = 0; i < MFR; ++i) af[i] = afrag(i, kk);
+        }
+        // one K step out of register slot u; `more`: the slot is re-requested for step k + DB
+        auto step = [&](const int u, const int k, const bool more) {
+            const int kn = kof(k + 1);
+#pragma unroll
+            for (int i = 0; i < MFR; ++i) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bq[u][j], af[i], acc[i][j], 0, 0, 0);
+                af[i] = afrag(i, kn);
+            }
+            if (more) {
+                const int kb = kof(k + DB);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) bq[u][j] = bfrag(j, kb);
+                // the requests stay behind THIS step's MFMAs (left alone, the scheduler collects the requests of a whole group of
+                // steps at the group's end, right in front of their first use)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // whole groups of DB steps (no exit inside the group: the compiler can then count the loads in flight across the back
+        // edge), then the remaining steps, which request nothing more
+        int k0 = 0;
+        for (; k0 + DB <= KS; k0 += DB) {
+#pragma unroll
+            for (int u = 0; u < DB; ++u) step(u, k0 + u, true);
+        }
+#pragma unroll
+        for (int u = 0; u < DB - 1; ++u)
+            if (k0 + u < KS) step(u, k0 + u, false);
+    }
+    if (sp && lane == 0) sp[3] = __builtin_amdgcn_s_memtime();
+
+    // ---- epilogue: fragment (i, j): row 16 i + fr, columns 16 cj[j] + 4 fq + (0..3) ----
+    if (EPI == EPI_STORE) {
+#pragma unroll
+        for (int i = 0; i < MFR; ++i) {
+            const int rr = i * 16 + fr;
+            if (rr >= rows) continue;
+            const float qs = s_rs[rr];
+            const float m = qs * ws;
+            float* crow = p.C + (int64_t)(row0 + rr) * p.N;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int c0 = cj[j] * 16 + fq * 4;
+                float v[4];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    v[reg] = (float)acc[i][j][reg] * (p.col_scale ? qs * p.col_scale[(int64_t)g * p.N + c0 + reg] : m);
+                *(float4*)(crow + c0) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < MFR; ++i) {
+            const int rr = i * 16 + fr;
+            const bool rok = rr < rows;
+            const float m = rok ? s_rs[rr] * ws : 0.0f;
+            float* crow = p.C + (int64_t)(row0 + (rok ? rr : 0)) * I;
+            float a = 0.0f, bb = 0.0f;
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                const int c0 = cj[j] * 16 + fq * 4;
+                float v[4];
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const float gate = (float)acc[i][j][reg] * m;
+                    const float up = (float)acc[i][j + W][reg] * m;
+                    v[reg] = os_silu(gate) * up;
+                }
+                if (rok) {
+                    *(float4*)(crow + c0) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) { a = fminf(a, v[reg]); bb = fmaxf(bb, v[reg]); }
+                }
+            }
+            if (st) {
+                a = fminf(a, lane_xor(a, 16)); bb = fmaxf(bb, lane_xor(bb, 16));
+                a = fminf(a, lane_xor(a, 32)); bb = fmaxf(bb, lane_xor(bb, 32));
+                if (fq == 0 && rok) {
+                    const int sl = s_rel[rr];
+                    if (sl >= 0 && sl < I64H_STAT_TAB) {
+                        atomicMin(&tab_lo[sl], f32_to_ordered(a));
+                        atomicMax(&tab_hi[sl], f32_to_ordered(bb));
+                    } else {
+                        stat_update(p.stats, p.out_slot_base + sl, item, a, bb);
+                    }
+                }
+            }
+        }
+    }
+    if (sp && lane == 0) sp[4] = __builtin_amdgcn_s_memtime();
+}
+
+// The tiles of a launch: MFR row fragments (128 or 144 rows) per tile, NW waves per workgroup, blocks of at most WMAX units.
+template <int EPI, int DB, int NW, int WMAX, int MFR>
+__device__ __forceinline__ void os_run(const GemmI8Args& p, const int8_t* __restrict__ Bf, const int n_items, const int parts, const int rotk) {
+    constexpr int OS_NT = NW * 64, BM = MFR * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int K = p.K, KS = K >> 6;
-    char* img = smem;                               // [KS][8][1024]
-    char* tail = smem + (size_t)KS * 8192;
-    float* s_rs = (float*)tail;                     // [128] row scales of the tile
-    int* s_rel = (int*)(tail + 512);                // [128] relative statistics slot of the tile's rows
-    uint32_t* tab_lo = (uint32_t*)(tail + 1024);    // [I64H_STAT_TAB] x 2
+    char* img = smem;                               // [KS][MFR][1024]
+    char* tail = smem + (size_t)KS * (MFR * 1024);
+    float* s_rs = (float*)tail;                     // [BM] row scales of the tile
+    int* s_rel = (int*)(tail + MFR * 64);           // [BM] relative statistics slot of the tile's rows
+    uint32_t* tab_lo = (uint32_t*)(tail + MFR * 128);  // [I64H_STAT_TAB] x 2
     uint32_t* tab_hi = tab_lo + I64H_STAT_TAB;
-    int* s_info = (int*)(tab_hi + I64H_STAT_TAB);   // group, first row, rows, ticket
+    int* s_info = (int*)(tab_hi + I64H_STAT_TAB);   // per wave: group, first row, rows, -
 
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
@@ -67,33 +212,36 @@ void gemm_i8_os_kernel(GemmI8Args p, const int8_t* __restrict__ Bf, int n_items,
     // that stream the same group's weights meet in that XCD's L2
     const int slot = (nwg & 7) == 0 ? (w & 7) * (nwg >> 3) + (w >> 3) : w;
     const bool st = EPI == EPI_SWIGLU && p.want_stats != 0;
-    const int I = p.N / 2;
+    const int U = p.N >> 5;  // units (pairs of fragment columns) per tile
     if (st) {
         for (int i = tid; i < I64H_STAT_TAB; i += OS_NT) { tab_lo[i] = I64H_ORDERED_ZERO; tab_hi[i] = I64H_ORDERED_ZERO; }
     }
 
     for (int item = slot; item < n_items; item += nwg) {
+        // diagnostics: 8 s_memtime stamps per wave (first item of the workgroup only)
+        unsigned long long* sp = (p.stamps && item == slot) ? p.stamps + ((int64_t)w * 16 + wid) * 8 + lane : nullptr;  // per-lane address (lane 0 stores)
+        if (sp && lane == 0) sp[0] = __builtin_amdgcn_s_memtime();
         const int mt = item / parts, np = item - mt * parts;
-        const int blk_lo = (int)((int64_t)np * nblk / parts), blk_hi = (int)((int64_t)(np + 1) * nblk / parts);
-        if (wid == 0) {
-            locate_mtile<OS_BM>(p, mt, lane, s_info);
-            if (lane == 0) s_info[3] = blk_lo;
+        // every wave locates the tile itself (wave-private LDS words: no barrier in front of the loads below)
+        locate_mtile<BM>(p, mt, lane, s_info + wid * 4);
+        const int g = __builtin_amdgcn_readfirstlane(s_info[wid * 4 + 0]);
+        const int row0 = __builtin_amdgcn_readfirstlane(s_info[wid * 4 + 1]);
+        const int rows = __builtin_amdgcn_readfirstlane(s_info[wid * 4 + 2]);
+        if (sp && lane == 0) sp[1] = __builtin_amdgcn_s_memtime();
+        if (g < 0) continue;  // past the last tile (uniform over the workgroup: every wave found the same)
+        // ---- this wave's share of the tile's units: the units of the item dealt evenly over the waves (waves w, w + 4, ... share
+        // a SIMD, so the SIMDs get equal shares whenever the unit count is a multiple of 4), walked in blocks of up to WMAX units ----
+        const int ulo = (int)((int64_t)np * U / parts), uhi = (int)((int64_t)(np + 1) * U / parts);
+        const int n = uhi - ulo, base = n / NW, rem = n - base * NW;
+        int cnt = base + (wid < rem ? 1 : 0);
+        int u = ulo + wid * base + min(wid, rem);
+        // the tile's operand rows -> fragment image: the KS x MFR fragments are dealt to the waves in image order
+        for (int f = wid; f < KS * MFR; f += NW) {
+            const int ks = f / MFR, i = f - ks * MFR;
+            const int r = min(i * 16 + fr, rows - 1);  // rows past the tile's end repeat its last row (never stored)
+            os_glds16((const char*)p.A + (int64_t)(row0 + r) * K + ks * 64 + fq * 16, img + f * 1024);
         }
-        __syncthreads();
-        const int g = __builtin_amdgcn_readfirstlane(s_info[0]);
-        const int row0 = __builtin_amdgcn_readfirstlane(s_info[1]);
-        const int rows = __builtin_amdgcn_readfirstlane(s_info[2]);
-        if (g < 0) {  // the item count is an upper bound
-            __syncthreads();
-            continue;
-        }
-        // ---- the tile's operand rows -> fragment image (wave w fills row fragment w of every K step) ----
-        {
-            const int r = min(wid * 16 + fr, rows - 1);  // rows past the tile's end repeat its last row (never stored)
-            const char* src = (const char*)p.A + (int64_t)(row0 + r) * K + fq * 16;
-            for (int ks = 0; ks < KS; ++ks) os_glds16(src + ks * 64, img + (ks * 8 + wid) * 1024);
-        }
-        if (tid < OS_BM) {
+        if (tid < BM) {
             const int r = row0 + min(tid, rows - 1);
             s_rs[tid] = p.row_scale[r];
             s_rel[tid] = (EPI == EPI_SWIGLU && p.out_row_slot) ? p.out_row_slot[r] : 0;
@@ -102,129 +250,22 @@ void gemm_i8_os_kernel(GemmI8Args p, const int8_t* __restrict__ Bf, int n_items,
         const char* Bg = (const char*)Bf + (int64_t)g * p.N * K;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-
-        // ---- column blocks ----
-        int b;
-        {
-            int t = 0;
-            if (lane == 0) t = atomicAdd(&s_info[3], 1);
-            b = __builtin_amdgcn_readfirstlane(t);
+        if (sp && lane == 0) sp[2] = __builtin_amdgcn_s_memtime();
+        // Workgroups that share a group's weights would otherwise walk the same addresses in step and queue on one L2 channel
+        // after another: each wave starts at a K step of its own (integer sums are exact in any order).
+        const int rk = (int)(((unsigned)slot * (unsigned)rotk + (unsigned)wid * (unsigned)(rotk != 0)) % (unsigned)KS);
+        if (WMAX >= 2) {
+            for (; cnt >= 2; cnt -= 2, u += 2) {
+                os_block<EPI, DB, WMAX >= 2 ? 2 : 1, MFR>(p, Bg, KS, rk, u, g, row0, rows, ws, st, item, lane, sp);
+                sp = nullptr;
+            }
         }
-        while (b < blk_hi) {
-            int t = 0;
-            if (lane == 0) t = atomicAdd(&s_info[3], 1);  // the next ticket, asked for now and read after the epilogue
-            // this block's four weight fragment columns
-            int cj[4];
-            if (EPI == EPI_SWIGLU) { cj[0] = 2 * b; cj[1] = 2 * b + 1; cj[2] = (I >> 4) + 2 * b; cj[3] = (I >> 4) + 2 * b + 1; }
-            else { cj[0] = 4 * b; cj[1] = 4 * b + 1; cj[2] = 4 * b + 2; cj[3] = 4 * b + 3; }
-            const char* bp[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bp[j] = Bg + (int64_t)cj[j] * KS * 1024 + lane * 16;
-
-            v4i acc[8][4];
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = (v4i){0, 0, 0, 0};
-            v4i bq[DB][4], af[8];
-            // the weight fragments of the first DB steps, oldest first: the counted waits of the loop rely on this order
-#pragma unroll
-            for (int u = 0; u < DB; ++u) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bq[u][j] = *(const v4i*)(bp[j] + min(u, KS - 1) * 1024);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) af[i] = *(const v4i*)(img + i * 1024 + lane * 16);
-            // one K step out of register slot u; `more`: the slot is re-requested for step k + DB
-            auto step = [&](const int u, const int k, const bool more) {
-                const char* an = img + min(k + 1, KS - 1) * 8192 + lane * 16;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bq[u][j], af[i], acc[i][j], 0, 0, 0);
-                    af[i] = *(const v4i*)(an + i * 1024);
-                }
-                if (more) {
-                    const int kb = min(k + DB, KS - 1);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) bq[u][j] = *(const v4i*)(bp[j] + kb * 1024);
-                    // the requests stay behind THIS step's MFMAs (left alone, the scheduler collects the requests of a whole
-                    // group of steps at the group's end, right in front of their first use)
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            };
-            // whole groups of DB steps (no exit inside the group: the compiler can then count the loads in flight across the
-            // back edge), then the remaining steps, which request nothing more
-            int k0 = 0;
-            for (; k0 + DB <= KS; k0 += DB) {
-#pragma unroll
-                for (int u = 0; u < DB; ++u) step(u, k0 + u, true);
-            }
-#pragma unroll
-            for (int u = 0; u < DB - 1; ++u)
-                if (k0 + u < KS) step(u, k0 + u, false);
-
-            // ---- epilogue: fragment (i, j): row 16 i + fr, columns 16 cj[j] + 4 fq + (0..3) ----
-            if (EPI == EPI_STORE) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int rr = i * 16 + fr;
-                    if (rr >= rows) continue;
-                    const float qs = s_rs[rr];
-                    const float m = qs * ws;
-                    float* crow = p.C + (int64_t)(row0 + rr) * p.N;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int c0 = cj[j] * 16 + fq * 4;
-                        float v[4];
-#pragma unroll
-                        for (int reg = 0; reg < 4; ++reg)
-                            v[reg] = (float)acc[i][j][reg] * (p.col_scale ? qs * p.col_scale[(int64_t)g * p.N + c0 + reg] : m);
-                        *(float4*)(crow + c0) = make_float4(v[0], v[1], v[2], v[3]);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int rr = i * 16 + fr;
-                    const bool rok = rr < rows;
-                    const float m = rok ? s_rs[rr] * ws : 0.0f;
-                    float* crow = p.C + (int64_t)(row0 + (rok ? rr : 0)) * I;
-                    float a = 0.0f, bb = 0.0f;
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int c0 = cj[j] * 16 + fq * 4;
-                        float v[4];
-#pragma unroll
-                        for (int reg = 0; reg < 4; ++reg) {
-                            const float gate = (float)acc[i][j][reg] * m;
-                            const float up = (float)acc[i][j + 2][reg] * m;
-                            v[reg] = os_silu(gate) * up;
-                        }
-                        if (rok) {
-                            *(float4*)(crow + c0) = make_float4(v[0], v[1], v[2], v[3]);
-#pragma unroll
-                            for (int reg = 0; reg < 4; ++reg) { a = fminf(a, v[reg]); bb = fmaxf(bb, v[reg]); }
-                        }
-                    }
-                    if (st) {
-                        a = fminf(a, lane_xor(a, 16)); bb = fmaxf(bb, lane_xor(bb, 16));
-                        a = fminf(a, lane_xor(a, 32)); bb = fmaxf(bb, lane_xor(bb, 32));
-                        if (fq == 0 && rok) {
-                            const int sl = s_rel[rr];
-                            if (sl >= 0 && sl < I64H_STAT_TAB) {
-                                atomicMin(&tab_lo[sl], f32_to_ordered(a));
-                                atomicMax(&tab_hi[sl], f32_to_ordered(bb));
-                            } else {
-                                stat_update(p.stats, p.out_slot_base + sl, item, a, bb);
-                            }
-                        }
-                    }
-                }
-            }
-            b = __builtin_amdgcn_readfirstlane(t);
+        for (; cnt >= 1; --cnt, ++u) {
+            os_block<EPI, DB, 1, MFR>(p, Bg, KS, rk, u, g, row0, rows, ws, st, item, lane, sp);
+            sp = nullptr;
         }
+        sp = (p.stamps && item == slot) ? p.stamps + ((int64_t)w * 16 + wid) * 8 + lane : nullptr;
+        if (sp && lane == 0) sp[6] = __builtin_amdgcn_s_memtime();
         __syncthreads();  // every wave is done with the image, the row arrays and the statistics table
         if (st) {
             for (int i = tid; i < I64H_STAT_TAB; i += OS_NT)
@@ -236,29 +277,61 @@ void gemm_i8_os_kernel(GemmI8Args p, const int8_t* __restrict__ Bf, int n_items,
                     tab_hi[i] = I64H_ORDERED_ZERO;
                 }
         }
+        if (sp && lane == 0) sp[7] = __builtin_amdgcn_s_memtime();
     }
 }
 
+// m-tiles of BM rows over all groups (every lane ends with the sum)
+__device__ __forceinline__ int os_count_tiles(const GemmI8Args& p, const int BM, const int lane) {
+    if (p.group_off == nullptr) return (p.M_total + BM - 1) / BM;
+    int t = 0;
+    for (int g = lane; g < p.G; g += 64) t += (p.group_off[g + 1] - p.group_off[g] + BM - 1) / BM;
+    return wave_sum_i(t);
+}
+
+// The tile height is chosen per launch, on the device (the group sizes live there): 128 rows, or 144 when that needs fewer rounds
+// of the grid - e.g. 8 groups of about 4096 rows are 260 tiles of 128 rows (two rounds of 256 workgroups) but 232 tiles of 144.
+template <int EPI, int DB, int NW, int WMAX>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4)))
+void gemm_i8_os_kernel(GemmI8Args p, const int8_t* __restrict__ Bf, int parts, int rotk, int tall_ok) {
+    const int lane = threadIdx.x & 63, nwg = gridDim.x;
+    const int t8 = __builtin_amdgcn_readfirstlane(os_count_tiles(p, 128, lane));
+    bool tall = false;
+    int t9 = 0;
+    if (tall_ok) {
+        t9 = __builtin_amdgcn_readfirstlane(os_count_tiles(p, 144, lane));
+        const int r8 = (t8 * parts + nwg - 1) / nwg, r9 = (t9 * parts + nwg - 1) / nwg;
+        tall = r9 * 9 < r8 * 8;
+    }
+    if (tall) os_run<EPI, DB, NW, WMAX, 9>(p, Bf, t9 * parts, parts, rotk);
+    else os_run<EPI, DB, NW, WMAX, 8>(p, Bf, t8 * parts, parts, rotk);
+}
+
 static int g_os_grid = 256;  // tuning knob: workgroups of the persistent grid (one per CU)
-static int g_os_depth = 4;   // tuning knob: K steps of weight fragments a wave keeps in flight (2, 3 or 4)
+static int g_os_depth = 2;   // tuning knob: K steps of weight fragments a wave keeps in flight (2 or 3)
+static int g_os_waves = 0;   // tuning knob: waves per workgroup (8 with blocks of two units, 12 with blocks of one; 0 = by epilogue)
+static unsigned long long* g_os_stamps = nullptr;  // diagnostics (i64h_debug_set_os_stamps)
+static int g_os_rotk = 0;  // tuning knob: per-workgroup rotation of the K order (0 = off)
 
-static size_t os_lds_bytes(int K) { return (size_t)(K / 64) * 8192 + 1024 + 2 * I64H_STAT_TAB * 4 + 16; }
+static int g_os_tall = 1;  // tuning knob: 0 = tiles of 128 rows only
+static size_t os_lds_bytes(int K, int mfr) { return (size_t)(K / 64) * mfr * 1024 + mfr * 128 + 2 * I64H_STAT_TAB * 4 + 16 * 16; }
 
-template <int EPI, int DB>
-static int launch_os(const GemmI8Args& p, const int8_t* Bf, int n_items, int parts, int nblk, hipStream_t st) {
-    const size_t lds = os_lds_bytes(p.K);
+template <int EPI, int DB, int NW, int WMAX>
+static int launch_os(const GemmI8Args& p, const int8_t* Bf, int n_items, int parts, hipStream_t st) {
+    const bool tall = g_os_tall && os_lds_bytes(p.K, 9) <= 160 * 1024;
+    const size_t lds = os_lds_bytes(p.K, tall ? 9 : 8);
     if (lds > 64 * 1024) {
         static bool raised[64] = {};  // per instantiation and device
         int device = 0;
         I64H_CHECK_HIP(hipGetDevice(&device));
         if (device < 0 || device >= 64 || !raised[device]) {
-            I64H_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_i8_os_kernel<EPI, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            I64H_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_i8_os_kernel<EPI, DB, NW, WMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             if (device >= 0 && device < 64) raised[device] = true;
         }
     }
     int nwg = n_items < g_os_grid ? n_items : g_os_grid;
     if (nwg >= 8) nwg &= ~7;
-    hipLaunchKernelGGL((gemm_i8_os_kernel<EPI, DB>), dim3((unsigned)nwg), dim3(OS_NT), lds, st, p, Bf, n_items, parts, nblk);
+    hipLaunchKernelGGL((gemm_i8_os_kernel<EPI, DB, NW, WMAX>), dim3((unsigned)nwg), dim3(NW * 64), lds, st, p, Bf, parts, g_os_rotk, tall ? 1 : 0);
     I64H_CHECK_LAUNCH();
     return 0;
 }
@@ -267,15 +340,37 @@ extern "C" {
 
 // 1 if i64h_gemm_i8_frags takes the shape (int8 operand rows of K bytes against N weight rows, the given epilogue)
 int i64h_gemm_i8_frags_ok(int32_t N, int32_t K, int32_t epilogue) {
-    if (K <= 0 || N <= 0 || K % 64 != 0 || os_lds_bytes(K) > 160 * 1024 || (int64_t)N * K >= (1ll << 31)) return 0;
-    if (epilogue == EPI_SWIGLU) return (N % 64 == 0) ? 1 : 0;  // 32 gate columns + 32 up columns per block
-    return (epilogue == EPI_STORE && N % 64 == 0) ? 1 : 0;
+    if (K <= 0 || N <= 0 || K % 64 != 0 || os_lds_bytes(K, 8) > 160 * 1024 || (int64_t)N * K >= (1ll << 31)) return 0;
+    return ((epilogue == EPI_SWIGLU || epilogue == EPI_STORE) && N % 32 == 0) ? 1 : 0;  // units of two fragment columns
 }
 
 int i64h_set_gemm_os(int32_t workgroups, int32_t depth) {
-    I64H_CHECK_ARG(workgroups >= 1 && (depth == 2 || depth == 3 || depth == 4), "set_gemm_os: bad values %d, %d", workgroups, depth);
+    I64H_CHECK_ARG(workgroups >= 1 && (depth == 2 || depth == 3), "set_gemm_os: bad values %d, %d", workgroups, depth);
     g_os_grid = workgroups;
     g_os_depth = depth;
+    return 0;
+}
+
+int i64h_set_gemm_os_tall(int32_t on) {
+    g_os_tall = on ? 1 : 0;
+    return 0;
+}
+
+int i64h_set_gemm_os_waves(int32_t waves) {
+    I64H_CHECK_ARG(waves == 0 || waves == 8 || waves == 12, "set_gemm_os_waves: %d not in {0, 8, 12}", waves);
+    g_os_waves = waves;
+    return 0;
+}
+
+// diagnostics: device buffer of 64 uint64 per workgroup (8 waves x 8 s_memtime stamps of the workgroup's first tile); NULL = off
+int i64h_debug_set_os_stamps(void* buffer) {
+    g_os_stamps = (unsigned long long*)buffer;
+    return 0;
+}
+
+int i64h_set_gemm_os_rotation(int32_t k_stride) {
+    I64H_CHECK_ARG(k_stride >= 0, "set_gemm_os_rotation: bad value %d", k_stride);
+    g_os_rotk = k_stride;
     return 0;
 }
 
@@ -296,7 +391,7 @@ int i64h_gemm_i8_frags(const int8_t* A, const float* row_scale, const int8_t* B_
                        int32_t slot_base, uint32_t* stats, const float* col_scale, void* stream) {
     I64H_CHECK_ARG(A && row_scale && B_frags && w_scale && C, "gemm_i8_frags: null argument");
     I64H_CHECK_ARG(M_total >= 0 && M_total < (1ll << 31) && num_groups >= 1 && num_groups <= MAX_GROUPS, "gemm_i8_frags: bad sizes");
-    I64H_CHECK_ARG(i64h_gemm_i8_frags_ok(N, K, epilogue), "gemm_i8_frags: shape N=%d K=%d epilogue=%d unsupported (K %% 64, K <= 1024, N %% 64)", N, K,
+    I64H_CHECK_ARG(i64h_gemm_i8_frags_ok(N, K, epilogue), "gemm_i8_frags: shape N=%d K=%d epilogue=%d unsupported (K %% 64, K <= 1024, N %% 32)", N, K,
                    epilogue);
     I64H_CHECK_ARG(((uintptr_t)A | (uintptr_t)B_frags | (uintptr_t)C) % 16 == 0, "gemm_i8_frags: 16-byte alignment");
     I64H_CHECK_ARG(col_scale == nullptr || epilogue == EPI_STORE, "gemm_i8_frags: a column scale needs the plain epilogue");
@@ -307,26 +402,33 @@ int i64h_gemm_i8_frags(const int8_t* A, const float* row_scale, const int8_t* B_
     p.N = N; p.K = K; p.C = C; p.out_row_slot = row_slot; p.out_slot_base = slot_base; p.stats = stats;
     p.want_stats = stats != nullptr && epilogue == EPI_SWIGLU;
     p.col_scale = col_scale;
+    p.stamps = g_os_stamps;
     const int G = group_offsets ? num_groups : 1;
     const int m_tiles = (int)((M_total + OS_BM - 1) / OS_BM) + (group_offsets ? G : 0);  // upper bound
-    const int nblk = epilogue == EPI_SWIGLU ? N / 64 : N / 64;
+    const int units = N / 32;
     // few row tiles: the columns of a tile are dealt to several workgroups (each loads the tile's rows itself)
     int parts = 1;
     if (m_tiles < (g_os_grid * 3) / 4) {
         parts = (g_os_grid + m_tiles - 1) / m_tiles;
-        const int maxp = nblk / 8 > 0 ? nblk / 8 : 1;  // at least one block per wave
+        const int maxp = units / 16 > 0 ? units / 16 : 1;  // at least two units per wave
         if (parts > maxp) parts = maxp;
     }
     const int n_items = m_tiles * parts;
     hipStream_t st = (hipStream_t)stream;
-    if (epilogue == EPI_SWIGLU) {
-        if (g_os_depth == 2) return launch_os<EPI_SWIGLU, 2>(p, B_frags, n_items, parts, nblk, st);
-        if (g_os_depth == 3) return launch_os<EPI_SWIGLU, 3>(p, B_frags, n_items, parts, nblk, st);
-        return launch_os<EPI_SWIGLU, 4>(p, B_frags, n_items, parts, nblk, st);
-    }
-    if (g_os_depth == 2) return launch_os<EPI_STORE, 2>(p, B_frags, n_items, parts, nblk, st);
-    if (g_os_depth == 3) return launch_os<EPI_STORE, 3>(p, B_frags, n_items, parts, nblk, st);
-    return launch_os<EPI_STORE, 4>(p, B_frags, n_items, parts, nblk, st);
+    // measured: the SwiGLU epilogue does best with 8 waves and blocks of 64 columns, the plain store with 12 waves and blocks of 32
+#define OS_DISPATCH(EPI)                                                                                       \
+    do {                                                                                                       \
+        const int waves = g_os_waves ? g_os_waves : (EPI == EPI_SWIGLU ? 8 : 12);                              \
+        if (waves == 8) {                                                                                      \
+            if (g_os_depth == 2) return launch_os<EPI, 2, 8, 2>(p, B_frags, n_items, parts, st);                \
+            return launch_os<EPI, 3, 8, 2>(p, B_frags, n_items, parts, st);                                     \
+        }                                                                                                      \
+        if (g_os_depth == 2) return launch_os<EPI, 2, 12, 1>(p, B_frags, n_items, parts, st);                   \
+        return launch_os<EPI, 3, 12, 1>(p, B_frags, n_items, parts, st);                                        \
+    } while (0)
+    if (epilogue == EPI_SWIGLU) OS_DISPATCH(EPI_SWIGLU);
+    OS_DISPATCH(EPI_STORE);
+#undef OS_DISPATCH
 }
 
 }  // extern "C"

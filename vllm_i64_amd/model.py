@@ -28,6 +28,14 @@ class PackedLinear:
     def __init__(self, w_q: torch.Tensor, w_s: torch.Tensor):
         self.w_q, self.w_s = w_q, w_s
         self.G, self.N, self.K = w_q.shape
+        self._frags = None
+
+    def frags(self) -> torch.Tensor:
+        """The same bytes as a fragment pack (ops.pack_weight_frags), made on first use: what the operand-stationary kernel of
+        prefill-sized calls reads."""
+        if self._frags is None:
+            self._frags = ops.pack_weight_frags(self.w_q)
+        return self._frags
 
     def __getitem__(self, groups: slice) -> "PackedLinear":
         """A contiguous range of groups (the experts one rank owns)."""
@@ -329,9 +337,19 @@ class I64MoEModel:
                                            stats=self.stats, want_stats=stats_slot is not None))
             return out
         ops.call("i64h_quantize_dynamic", ops.ptr(x), n, K, 0, 0, 0, slot, ops.ptr(self.stats), ops.ptr(xa), ops.ptr(xs), 0, ops._stream())
-        ops.gemm_i8(xa, xs, pl.w_q, pl.w_s, epilogue=epilogue, slot_base=stats_slot or 0,
-                    stats=self.stats if stats_slot is not None else None, out=out)
+        self._gemm_i8(xa, xs, pl, out, epilogue=epilogue, slot_base=stats_slot or 0, stats=self.stats if stats_slot is not None else None)
         return out
+
+    FRAGS_MIN_ROWS = 4096  # from this many operand rows on a call has enough 128-row tiles for the operand-stationary kernel
+
+    def _gemm_i8(self, a8, rs, pl: PackedLinear, out, *, epilogue=ops.EPI_STORE, group_offsets=None, row_slot=None, slot_base=0, stats=None):
+        """int8 operand rows x one packed Linear (or a stack of them, grouped): the operand-stationary kernel on the weight's
+        fragment pack for prefill-sized calls it takes, the tiled kernels otherwise; the results are bit-identical."""
+        if a8.shape[0] >= self.FRAGS_MIN_ROWS and ops.gemm_i8_frags_ok(pl.N, pl.K, epilogue):
+            return ops.gemm_i8_frags(a8, rs, pl.frags(), pl.w_s, pl.N, group_offsets=group_offsets, epilogue=epilogue, row_slot=row_slot,
+                                     slot_base=slot_base, stats=stats, out=out)
+        return ops.gemm_i8(a8, rs, pl.w_q, pl.w_s, group_offsets=group_offsets, epilogue=epilogue, row_slot=row_slot, slot_base=slot_base,
+                           stats=stats, out=out)
 
     # ---- one forward (prefill chunk or decode step) ----
     def forward(self, token_ids: torch.Tensor, positions: torch.Tensor, slot_ids: torch.Tensor, ctx_len: torch.Tensor,
@@ -588,11 +606,11 @@ class I64MoEModel:
         # every (route, expert) bucket is its own Linear call: rows gathered in bucket order, bucket statistics
         ops.call("i64h_quantize_dynamic", ops.ptr(B.normed), R, cfg.hidden_size, ops.ptr(plan.perm[l]), n, ops.ptr(plan.sorted_bucket[l]),
                  base + 3, ops.ptr(st), ops.ptr(B.ea), ops.ptr(B.es), 0, ops._stream())
-        ops.gemm_i8(B.ea, B.es, W["exp_gu"].w_q, W["exp_gu"].w_s, group_offsets=plan.expert_offsets[l], epilogue=ops.EPI_SWIGLU,
-                    row_slot=plan.sorted_bucket[l], slot_base=base + 4 + nbk, stats=st, out=B.e_inter)
+        self._gemm_i8(B.ea[:R], B.es[:R], W["exp_gu"], B.e_inter, group_offsets=plan.expert_offsets[l], epilogue=ops.EPI_SWIGLU,
+                      row_slot=plan.sorted_bucket[l], slot_base=base + 4 + nbk, stats=st)
         ops.call("i64h_quantize_dynamic", ops.ptr(B.e_inter), R, cfg.expert_inter, 0, 0, ops.ptr(plan.sorted_bucket[l]), base + 4 + nbk,
                  ops.ptr(st), ops.ptr(B.eia), ops.ptr(B.eis), 0, ops._stream())
-        ops.gemm_i8(B.eia, B.eis, W["exp_dn"].w_q, W["exp_dn"].w_s, group_offsets=plan.expert_offsets[l], out=B.e_out)
+        self._gemm_i8(B.eia[:R], B.eis[:R], W["exp_dn"], B.e_out, group_offsets=plan.expert_offsets[l])
         return plan.inv[l]
 
     def _moe_ep(self, B: _Buffers, W: dict, l: int, base: int) -> torch.Tensor:
