@@ -121,6 +121,7 @@ typedef struct i64h_gemm_desc {
     const float* col_scale;       /* epilogue 0, int8 operand, optional: per-output-channel scale [G][N] replacing w_scale[g] */
     const int32_t* c_row_map;     /* epilogue 0, optional: operand row r is stored as output row c_row_map[r] (e.g. expert outputs straight back in (route, token) order) */
     int32_t a_group_slots;        /* fp32 operand, optional promise (0 = none): a_row_slot[r] of every row of group g lies in [g * S, g * S + S), S = this value; lets the decode-sized kernel request the statistics without waiting for the row's slot index */
+    int32_t b_frags;              /* decode-sized (fp32-operand) problems only: 1 = B points to the fragment pack of the weights (i64h_pack_weight_frags; N % 16 == 0, SwiGLU: N % 32 == 0, K % 64 == 0): every weight load of a wave is then 1 KB of consecutive bytes */
 } i64h_gemm_desc;
 int i64h_gemm_i8_pair(const i64h_gemm_desc* a, const i64h_gemm_desc* b, void* stream);
 /* Decode-sized fused form (fp32 operand quantized in the kernel from its stat slot, one group, <= 512 rows, K % 64 == 0,

@@ -146,3 +146,53 @@ def test_gemm_i8_frags_refuses_unsupported_shapes(dev):
     assert not ops.gemm_i8_frags_ok(100, 256, ops.EPI_STORE)
     assert not ops.gemm_i8_frags_ok(128, 96, ops.EPI_SWIGLU)
     assert not ops.gemm_i8_frags_ok(48, 128, ops.EPI_SWIGLU)
+
+
+@pytest.mark.parametrize("M_,N_,K_,G_,epi", [(62, 320, 192, 1, 0), (62, 96, 64, 1, 0), (62, 160, 192, 1, 1), (124, 32, 64, 8, 1), (64, 1536, 1024, 1, 0),
+                                              (186, 128, 192, 6, 1), (128, 1024, 448, 8, 0), (64, 3584, 1024, 1, 1), (5, 48, 128, 1, 0)])
+def test_decode_sized_kernel_reads_fragment_packs(dev, M_, N_, K_, G_, epi):
+    """The decode-sized kernel (fp32 operand quantized in the kernel) with the weights given as a fragment pack: bit-identical to
+    the row-major weights, grouped and ungrouped, both epilogues, column counts that leave waves and workgroups partly empty."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M_ + N_ + K_)
+    x = torch.randn(M_, K_, generator=g).to(dev)
+    w = torch.randint(-128, 128, (G_, N_, K_), generator=g, dtype=torch.int8).to(dev)
+    ws = ((torch.rand(G_, generator=g) + 0.5) * 1e-2).to(dev)
+    off = None
+    if G_ > 1:
+        cuts = sorted(torch.randint(0, M_ + 1, (G_ - 1,), generator=g).tolist())
+        off = torch.tensor([0] + cuts + [M_], dtype=torch.int32, device=dev)
+    outs = []
+    for frags in (None, ops.pack_weight_frags(w)):
+        stats = ops.stats_alloc(4, dev)
+        ops.stats_reset(stats)
+        ops.rows_minmax(x, stats, slot_base=0)
+        out = torch.zeros(M_, N_ // 2 if epi else N_, device=dev)
+        d = ops.gemm_desc(x, w, ws, out, a_slot_base=0, group_offsets=off, epilogue=epi, stats=stats, out_slot_base=1, want_stats=bool(epi),
+                          w_frags=frags)
+        ops.gemm_i8_pair(d)
+        outs.append((out, ops.qparams(stats, 4)[2]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+
+
+def test_fragment_pack_is_refused_where_no_kernel_reads_it(dev):
+    """A launch whose problems do not both fit the decode-sized kernel runs on the tiled kernels, which read row-major weights: a
+    pack there is an error, not a wrong result."""
+    ops = _ops()
+    from vllm_i64_amd._lib import I64HError
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(40, 64, generator=g).to(dev)
+    x2 = torch.randn(40, 80, generator=g).to(dev)
+    w = torch.randint(-128, 128, (1, 64, 64), generator=g, dtype=torch.int8).to(dev)
+    w2 = torch.randint(-128, 128, (1, 64, 80), generator=g, dtype=torch.int8).to(dev)
+    ws = torch.ones(1, device=dev)
+    stats = ops.stats_alloc(2, dev)
+    ops.stats_reset(stats)
+    ops.rows_minmax(x, stats, slot_base=0)
+    ops.rows_minmax(x2, stats, slot_base=1)
+    d1 = ops.gemm_desc(x, w, ws, torch.empty(40, 64, device=dev), a_slot_base=0, stats=stats, w_frags=ops.pack_weight_frags(w))
+    d2 = ops.gemm_desc(x2, w2, ws, torch.empty(40, 64, device=dev), a_slot_base=1, stats=stats)  # K = 80: not a multiple of 64
+    with pytest.raises(I64HError):
+        ops.gemm_i8_pair(d1, d2)
+    ops.gemm_i8_pair(d1)  # alone it is fine

@@ -104,7 +104,7 @@ class GemmDesc(ctypes.Structure):
     _fields_ = [("A", _P), ("a_fp32", _I), ("a_src_row", _P), ("a_src_mod", _I), ("row_scale", _P), ("a_row_slot", _P),
                 ("a_slot_base", _I), ("B", _P), ("w_scale", _P), ("group_offsets", _P), ("num_groups", _I), ("M_total", _L),
                 ("N", _I), ("K", _I), ("C", _P), ("epilogue", _I), ("out_row_slot", _P), ("out_slot_base", _I), ("stats", _P),
-                ("want_stats", _I), ("col_scale", _P), ("c_row_map", _P), ("a_group_slots", _I)]
+                ("want_stats", _I), ("col_scale", _P), ("c_row_map", _P), ("a_group_slots", _I), ("b_frags", _I)]
 
 
 class Fp8RowsDesc(ctypes.Structure):

@@ -679,8 +679,19 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
     const int col = nt * BNB + wid * 16 + fr;
     const bool col_ok = col < nout;
     const int8_t* bp[NF];
-    bp[0] = Bg + (int64_t)(col_ok ? col : 0) * K + fq * 16;
-    if (NF == 2) bp[1] = Bg + (int64_t)(I + (col_ok ? col : 0)) * K + fq * 16;
+    int bstep = 64;  // bytes from one K step of a lane's weight stream to the next
+    if (p.b_frags) {
+        // weights as a fragment pack: fragment (column fragment c, step s) is the 1 KB at (c * K / 64 + s) * 1024 with this lane's
+        // 16 bytes at lane * 16 - a wave's load is 8 whole cache lines instead of 16 rows x 64 bytes
+        const int c16 = nt * NW + wid;
+        const int c_ok = c16 * 16 < nout ? c16 : 0;
+        bp[0] = Bg + (int64_t)c_ok * K * 16 + lane * 16;
+        if (NF == 2) bp[1] = Bg + (int64_t)((I >> 4) + c_ok) * K * 16 + lane * 16;
+        bstep = 1024;
+    } else {
+        bp[0] = Bg + (int64_t)(col_ok ? col : 0) * K + fq * 16;
+        if (NF == 2) bp[1] = Bg + (int64_t)(I + (col_ok ? col : 0)) * K + fq * 16;
+    }
 
     // the statistics of the rows' Linear calls are requested first: vector loads retire in order, so everything that is
     // requested before them would have to land before the parameters can be derived
@@ -732,7 +743,7 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
         for (int s = 0; s < SK_STEPS; ++s) {
             const int st = min(s0 + s, nsteps - 1);  // clamped: always a valid address, surplus fragments are not used
 #pragma unroll
-            for (int f = 0; f < NF; ++f) bq[f][s] = *(const v4i*)(bp[f] + st * 64);
+            for (int f = 0; f < NF; ++f) bq[f][s] = *(const v4i*)(bp[f] + st * bstep);
         }
     };
 
@@ -1114,6 +1125,7 @@ struct i64h_gemm_desc {
     const float* col_scale;
     const int32_t* c_row_map;
     int32_t a_group_slots;
+    int32_t b_frags;
 };
 
 static int check_desc(const i64h_gemm_desc* d, const char* who) {
@@ -1125,6 +1137,8 @@ static int check_desc(const i64h_gemm_desc* d, const char* who) {
     I64H_CHECK_ARG(!d->a_fp32 || d->stats != nullptr, "%s: fp32 operand needs the stat slots", who);
     I64H_CHECK_ARG(d->a_fp32 || d->row_scale != nullptr, "%s: int8 operand needs row_scale", who);
     I64H_CHECK_ARG(!d->want_stats || (d->stats != nullptr && d->epilogue == EPI_SWIGLU), "%s: statistics need the SwiGLU epilogue and stat slots", who);
+    I64H_CHECK_ARG(!d->b_frags || (d->a_fp32 && d->K % 64 == 0 && d->N % (d->epilogue == EPI_SWIGLU ? 32 : 16) == 0),
+                   "%s: a weight fragment pack needs the fp32 operand form, K %% 64 == 0 and whole fragment columns", who);
     return 0;
 }
 
@@ -1140,6 +1154,7 @@ static GemmI8Args to_args(const i64h_gemm_desc* d) {
     p.col_scale = d->col_scale;
     p.c_row_map = d->c_row_map;
     p.a_group_slots = d->a_group_slots;
+    p.b_frags = d->b_frags;
     return p;
 }
 
@@ -1322,6 +1337,9 @@ int i64h_gemm_i8_pair(const i64h_gemm_desc* a, const i64h_gemm_desc* b, void* st
         I64H_CHECK_ARG(a->epilogue == b->epilogue && a->a_fp32 == b->a_fp32, "gemm_i8_pair: problems must share epilogue and operand kind");
     }
     hipStream_t st = (hipStream_t)stream;
+    I64H_CHECK_ARG(!(a->b_frags || (b && b->b_frags)) || (skinny_ok(a) && (!b || skinny_ok(b))),
+                   "gemm_i8_pair: a weight fragment pack is read by the decode-sized kernel only (every problem of the launch: fp32 operand, at most %d rows, K %% 64 == 0, K <= %d)",
+                   SK_MAX_ROWS, SK_MAX_K);
     const bool mapped = a->c_row_map != nullptr || (b && b->c_row_map != nullptr);
     I64H_CHECK_ARG(!mapped || a->epilogue == EPI_STORE, "gemm_i8_pair: an output row map needs the plain epilogue");
     if (skinny_ok(a) && (!b || skinny_ok(b)))

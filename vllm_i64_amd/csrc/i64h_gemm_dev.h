@@ -26,6 +26,7 @@ struct GemmI8Args {
     const float* w_scale;      // [G]
     const float* col_scale;    // EPI_STORE, optional: per-output-channel scale [G][N] used instead of w_scale[g]
     const int32_t* c_row_map;  // EPI_STORE, optional: operand row r is stored as output row c_row_map[r] (not in the row-streaming kernel)
+    int b_frags;               // decode-sized kernel: B is the fragment pack of the weights
     int a_group_slots;         // a_fp32, optional promise: a_row_slot[r] of a row of group g lies in [g * S, g * S + S) (S = this value)
     const int32_t* group_off;  // [G+1] device, or nullptr => one group [0, M_total)
     int G, M_total, N, K;

@@ -334,11 +334,22 @@ class I64MoEModel:
         n, K = x.shape
         if n <= self.FUSE_MAX_ROWS:
             ops.gemm_i8_pair(ops.gemm_desc(x, pl.w_q, pl.w_s, out, a_slot_base=slot, epilogue=epilogue, out_slot_base=stats_slot or 0,
-                                           stats=self.stats, want_stats=stats_slot is not None))
+                                           stats=self.stats, want_stats=stats_slot is not None, w_frags=self._wf(pl, epilogue)))
             return out
         ops.call("i64h_quantize_dynamic", ops.ptr(x), n, K, 0, 0, 0, slot, ops.ptr(self.stats), ops.ptr(xa), ops.ptr(xs), 0, ops._stream())
         self._gemm_i8(xa, xs, pl, out, epilogue=epilogue, slot_base=stats_slot or 0, stats=self.stats if stats_slot is not None else None)
         return out
+
+    DECODE_FRAGS = os.environ.get("I64H_DECODE_FRAGS", "1") != "0"  # decode-sized calls read the weights' fragment packs
+
+    def _wf(self, pl: PackedLinear, epilogue=ops.EPI_STORE, partner: Optional[PackedLinear] = None):
+        """The fragment pack of a weight for a decode-sized call (None: the kernel reads the row-major weights).  partner: the
+        other problem of the launch - only the decode-sized kernel reads packs, and a launch uses it when BOTH problems fit it."""
+        if partner is not None and (partner.K % 64 != 0 or partner.K > 8192):
+            return None
+        if self.DECODE_FRAGS and pl.K % 64 == 0 and pl.K <= 8192 and pl.N % (32 if epilogue == ops.EPI_SWIGLU else 16) == 0:
+            return pl.frags()
+        return None
 
     FRAGS_MIN_ROWS = 4096  # from this many operand rows on a call has enough 128-row tiles for the operand-stationary kernel
 
@@ -402,7 +413,7 @@ class I64MoEModel:
             base = l * spl
             if tails is not None:
                 if l == 0:
-                    ops.gemm_i8_qkv_rope_kv(ops.gemm_desc(B.normed, W["qkv"].w_q, W["qkv"].w_s, B.qkv, a_slot_base=0, stats=st),
+                    ops.gemm_i8_qkv_rope_kv(ops.gemm_desc(B.normed, W["qkv"].w_q, W["qkv"].w_s, B.qkv, a_slot_base=0, stats=st, w_frags=self._wf(W["qkv"])),
                                             W["q_norm"], W["k_norm"], 1e-6, self.rope, positions, slot_ids, kvc.block_table, kvc.k[0], kvc.v[0],
                                             B.q, cfg.num_heads, cfg.num_kv_heads, cfg.head_dim)
                 ops.paged_attn(B.q, kvc.k[l], kvc.v[l], kvc.block_table, ctx_len, slot_ids=None if rows_are_slots else slot_ids,
@@ -421,7 +432,7 @@ class I64MoEModel:
             # the library's own conditions for the fused form (i64h_gemm_i8_qkv_rope_kv): other shapes take the two-kernel path
             if fuse_rows and self.fuse_qkr and cfg.head_dim == 64 and 256 <= H <= 2048 and H % 64 == 0:
                 # decode-sized step: projection, QK norm, RoPE and cache write in one launch (a 64-column tile is one head)
-                ops.gemm_i8_qkv_rope_kv(ops.gemm_desc(B.normed, W["qkv"].w_q, W["qkv"].w_s, B.qkv, a_slot_base=base + 0, stats=st),
+                ops.gemm_i8_qkv_rope_kv(ops.gemm_desc(B.normed, W["qkv"].w_q, W["qkv"].w_s, B.qkv, a_slot_base=base + 0, stats=st, w_frags=self._wf(W["qkv"])),
                                         W["q_norm"], W["k_norm"], 1e-6, self.rope, positions, slot_ids, kvc.block_table, kvc.k[l], kvc.v[l],
                                         B.q, cfg.num_heads, cfg.num_kv_heads, cfg.head_dim)
             else:
@@ -586,16 +597,19 @@ class I64MoEModel:
             e_gu = ops.gemm_desc(B.normed, W["exp_gu"].w_q, W["exp_gu"].w_s, B.e_inter, a_src_row=plan.perm[l], a_src_mod=n,
                                  a_row_slot=plan.sorted_bucket[l], a_slot_base=base + 3, group_offsets=plan.expert_offsets[l],
                                  epilogue=ops.EPI_SWIGLU, out_row_slot=plan.sorted_bucket[l], out_slot_base=base + 4 + nbk, stats=st,
-                                 want_stats=True, m_total=R, a_group_slots=cfg.top_k)  # bucket = expert * top_k + route
+                                 want_stats=True, m_total=R, a_group_slots=cfg.top_k,  # bucket = expert * top_k + route
+                                 w_frags=self._wf(W["exp_gu"], ops.EPI_SWIGLU, W["sh_gu"] if shared else None))
             s_gu = ops.gemm_desc(B.normed, W["sh_gu"].w_q, W["sh_gu"].w_s, B.sh_inter, a_slot_base=base + 2, epilogue=ops.EPI_SWIGLU,
-                                 out_slot_base=base + 3 + nbk, stats=st, want_stats=True) if shared else None
+                                 out_slot_base=base + 3 + nbk, stats=st, want_stats=True,
+                                 w_frags=self._wf(W["sh_gu"], ops.EPI_SWIGLU, W["exp_gu"])) if shared else None
             ops.gemm_i8_pair(e_gu, s_gu)
             # the down projection stores its rows straight back in (route, token) order (plan.perm: sorted row -> k * n + t), so
             # the combine needs no index lookup in front of its row reads
             e_dn = ops.gemm_desc(B.e_inter, W["exp_dn"].w_q, W["exp_dn"].w_s, B.e_out, a_row_slot=plan.sorted_bucket[l],
                                  a_slot_base=base + 4 + nbk, group_offsets=plan.expert_offsets[l], stats=st, m_total=R,
-                                 c_row_map=plan.perm[l], a_group_slots=cfg.top_k)
-            s_dn = ops.gemm_desc(B.sh_inter, W["sh_dn"].w_q, W["sh_dn"].w_s, B.sh_out, a_slot_base=base + 3 + nbk, stats=st) if shared else None
+                                 c_row_map=plan.perm[l], a_group_slots=cfg.top_k, w_frags=self._wf(W["exp_dn"], partner=W["sh_dn"] if shared else None))
+            s_dn = ops.gemm_desc(B.sh_inter, W["sh_dn"].w_q, W["sh_dn"].w_s, B.sh_out, a_slot_base=base + 3 + nbk, stats=st,
+                                 w_frags=self._wf(W["sh_dn"], partner=W["exp_dn"])) if shared else None
             ops.gemm_i8_pair(e_dn, s_dn)
             return None
         if shared:

@@ -246,8 +246,9 @@ def gemm_i8_frags(a: torch.Tensor, row_scale: torch.Tensor, w_frags: torch.Tenso
 def gemm_desc(a: torch.Tensor, w: torch.Tensor, w_scale: torch.Tensor, out: torch.Tensor, *, row_scale=None, a_src_row=None,
               a_src_mod: int = 0, a_row_slot=None, a_slot_base: int = 0, group_offsets=None, epilogue: int = EPI_STORE,
               out_row_slot=None, out_slot_base: int = 0, stats=None, want_stats: bool = False, m_total: Optional[int] = None,
-              c_row_map=None, a_group_slots: int = 0):
-    """Build an i64h_gemm_desc.  a is int8 [M, K] (with row_scale) or fp32 [*, K] (quantized on the fly from the stat slots)."""
+              c_row_map=None, a_group_slots: int = 0, w_frags: Optional[torch.Tensor] = None):
+    """Build an i64h_gemm_desc.  a is int8 [M, K] (with row_scale) or fp32 [*, K] (quantized on the fly from the stat slots).
+    w_frags: the fragment pack of w (pack_weight_frags), read instead of w by the decode-sized kernel."""
     if w.dim() == 2:
         w = w.unsqueeze(0)
     G, N, K = w.shape
@@ -255,7 +256,8 @@ def gemm_desc(a: torch.Tensor, w: torch.Tensor, w_scale: torch.Tensor, out: torc
     d.A, d.a_fp32 = ptr(a), int(a.dtype == torch.float32)
     d.a_src_row, d.a_src_mod, d.row_scale = ptr(a_src_row), a_src_mod, ptr(row_scale)
     d.a_row_slot, d.a_slot_base = ptr(a_row_slot), a_slot_base
-    d.B, d.w_scale, d.group_offsets, d.num_groups = ptr(w), ptr(w_scale), ptr(group_offsets), G
+    d.B, d.w_scale, d.group_offsets, d.num_groups = ptr(w if w_frags is None else w_frags), ptr(w_scale), ptr(group_offsets), G
+    d.b_frags = int(w_frags is not None)
     d.M_total = m_total if m_total is not None else a.shape[0]
     d.N, d.K, d.C, d.epilogue = N, K, ptr(out), epilogue
     d.out_row_slot, d.out_slot_base, d.stats, d.want_stats = ptr(out_row_slot), out_slot_base, ptr(stats), int(want_stats)
