@@ -223,6 +223,7 @@ typedef struct i64h_fp8_rows_desc {
     int32_t N, K;
     float* C;                       /* [M, N] or [M, N / 2] (epilogue 1) */
     const int32_t* c_row_map;       /* output row r stored at row c_row_map[r] (NULL: r) */
+    int32_t b_frags;                /* 1 = B points to the fragment pack of the e4m3 bytes (i64h_pack_weight_frags; N % 16 == 0, epilogue 1: N % 32 == 0) */
 } i64h_fp8_rows_desc;
 int i64h_gemm_fp8_rows_pair(const i64h_fp8_rows_desc* a, const i64h_fp8_rows_desc* b, int32_t epilogue, void* stream);
 

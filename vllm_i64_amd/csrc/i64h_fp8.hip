@@ -200,6 +200,7 @@ struct Fp8RowsArgs {
     int G, M, N, K;
     float* C;
     const int32_t* c_row_map;
+    int b_frags;  // B is the fragment pack of the weights (i64h_pack_weight_frags on the e4m3 bytes)
 };
 struct Fp8RowsPair {
     Fp8RowsArgs p[2];
@@ -274,8 +275,19 @@ __global__ __launch_bounds__(256) void gemm_fp8_skinny_kernel(Fp8RowsPair pp) {
     const bool col_ok = col < nout;
     const uint8_t* Bg = B + (int64_t)g * N * K;
     const uint8_t* bp[NF];
-    bp[0] = Bg + (int64_t)(col_ok ? col : 0) * K + fq * 16;
-    if constexpr (NF == 2) bp[1] = Bg + (int64_t)(I + (col_ok ? col : 0)) * K + fq * 16;
+    int bstep = 64;  // bytes from one 64-byte K block of a lane's weight stream to the next
+    if (p.b_frags) {
+        // fragment (column fragment c, K block t) = the 1 KB at (c * K / 64 + t) * 1024, this lane's 16 bytes at lane * 16: a wave's
+        // load is 8 whole cache lines instead of 16 rows x 64 bytes
+        const int c16 = nt * 4 + wid;
+        const int c_ok = c16 * 16 < nout ? c16 : 0;
+        bp[0] = Bg + (int64_t)c_ok * K * 16 + lane * 16;
+        if constexpr (NF == 2) bp[1] = Bg + (int64_t)((I >> 4) + c_ok) * K * 16 + lane * 16;
+        bstep = 1024;
+    } else {
+        bp[0] = Bg + (int64_t)(col_ok ? col : 0) * K + fq * 16;
+        if constexpr (NF == 2) bp[1] = Bg + (int64_t)(I + (col_ok ? col : 0)) * K + fq * 16;
+    }
     float m = 0.0f;
     const bool in_regs = nv <= 16 * F8S_MAXV;
     float4 v[F8S_MAXV];
@@ -287,7 +299,7 @@ __global__ __launch_bounds__(256) void gemm_fp8_skinny_kernel(Fp8RowsPair pp) {
         for (int t = 0; t < BATCH; ++t) {
             const int tt = min(t0 + t, nblk - 1);  // clamped: always a valid address, surplus fragments are not used
 #pragma unroll
-            for (int f = 0; f < NF; ++f) bq[f][t] = *(const uint4*)(bp[f] + tt * 64);
+            for (int f = 0; f < NF; ++f) bq[f][t] = *(const uint4*)(bp[f] + tt * bstep);
         }
     };
     if (in_regs) {
@@ -429,12 +441,14 @@ static int fp8_rows_check(const i64h_fp8_rows_desc* d, int epilogue, const char*
     I64H_CHECK_ARG(d->num_groups >= 1 && d->num_groups <= 4096 && (d->group_offsets != nullptr || d->num_groups == 1), "%s: bad grouping", who);
     I64H_CHECK_ARG(epilogue == 0 || (epilogue == 1 && d->N % 2 == 0), "%s: bad epilogue %d / N=%d", who, epilogue, d->N);
     I64H_CHECK_ARG(d->a_src_row == nullptr || d->a_src_mod > 0, "%s: a_src_row needs a_src_mod > 0", who);
+    I64H_CHECK_ARG(!d->b_frags || d->N % (epilogue ? 32 : 16) == 0, "%s: a weight fragment pack needs whole fragment columns (N=%d)", who, d->N);
     return 0;
 }
 static Fp8RowsArgs fp8_rows_args(const i64h_fp8_rows_desc* d) {
     Fp8RowsArgs p;
     p.A = d->A; p.a_src_row = d->a_src_row; p.a_src_mod = d->a_src_mod; p.B = d->B; p.b_scale = d->b_scale; p.group_off = d->group_offsets;
     p.G = d->group_offsets ? d->num_groups : 1; p.M = (int)d->M; p.N = d->N; p.K = d->K; p.C = d->C; p.c_row_map = d->c_row_map;
+    p.b_frags = d->b_frags;
     return p;
 }
 static int64_t fp8_rows_blocks(const i64h_fp8_rows_desc* d, int epilogue) {
@@ -476,6 +490,7 @@ int i64h_gemm_fp8_rows(const float* A, const int32_t* a_src_row, int32_t a_src_m
     i64h_fp8_rows_desc d;
     d.A = A; d.a_src_row = a_src_row; d.a_src_mod = a_src_mod; d.B = B; d.b_scale = b_scale; d.group_offsets = group_offsets;
     d.num_groups = num_groups; d.M = M; d.N = N; d.K = K; d.C = C; d.c_row_map = c_row_map;
+    d.b_frags = 0;
     return i64h_gemm_fp8_rows_pair(&d, nullptr, epilogue, stream);
 }
 

@@ -73,6 +73,17 @@ class PackedFp8:
 
     def __init__(self, w_q: torch.Tensor, w_s: torch.Tensor):
         self.w_q, self.w_s, self.G = w_q, w_s, w_q.shape[0]
+        self._frags = None
+
+    def frags(self, swiglu: bool = False):
+        """The e4m3 bytes as a fragment pack (ops.pack_weight_frags) for the decode-sized kernel, made on first use; None when
+        the shape has no whole fragment columns."""
+        G, N, K = self.w_q.shape
+        if not I64MoEModel.DECODE_FRAGS or K % 64 != 0 or N % (32 if swiglu else 16) != 0:
+            return None
+        if self._frags is None:
+            self._frags = ops.pack_weight_frags(self.w_q)
+        return self._frags
 
 
 def pack_fp8(w: torch.Tensor, device) -> PackedFp8:
@@ -520,7 +531,7 @@ class I64MoEModel:
             quantized once (xq / xs: where to, or already there when x is None) and the tiled GEMM runs on the codes."""
             K = Wp.w_q.shape[-1]
             if small and x is not None and ops.fp8_rows_ok(K):
-                return ops.gemm_fp8_rows(x, Wp.w_q, Wp.w_s, out, **kw)
+                return ops.gemm_fp8_rows(x, Wp.w_q, Wp.w_s, out, w_frags=Wp.frags(kw.get("epilogue", ops.EPI_STORE) == ops.EPI_SWIGLU), **kw)
             if x is not None:
                 ops.quantize_fp8_rows(x, xq, xs)
             return ops.gemm_fp8(xq, xs, Wp.w_q, Wp.w_s, out, **kw)
@@ -554,12 +565,13 @@ class I64MoEModel:
                     # expert, results scattered back into (route, token) order) and the shared expert as its second problem
                     ops.gemm_fp8_rows_pair(
                         ops.fp8_rows_desc(B.normed, W["exp_gu"].w_q, W["exp_gu"].w_s, B.e_inter, m=R, a_src_row=plan.perm[l], a_src_mod=n,
-                                          group_offsets=plan.expert_offsets[l]),
-                        ops.fp8_rows_desc(B.normed, W["sh_gu"].w_q, W["sh_gu"].w_s, B.sh_inter), epilogue=ops.EPI_SWIGLU)
+                                          group_offsets=plan.expert_offsets[l], w_frags=W["exp_gu"].frags(True)),
+                        ops.fp8_rows_desc(B.normed, W["sh_gu"].w_q, W["sh_gu"].w_s, B.sh_inter, w_frags=W["sh_gu"].frags(True)),
+                        epilogue=ops.EPI_SWIGLU)
                     ops.gemm_fp8_rows_pair(
                         ops.fp8_rows_desc(B.e_inter, W["exp_dn"].w_q, W["exp_dn"].w_s, B.e_out, group_offsets=plan.expert_offsets[l],
-                                          c_row_map=plan.perm[l]),
-                        ops.fp8_rows_desc(B.sh_inter, W["sh_dn"].w_q, W["sh_dn"].w_s, B.sh_out))
+                                          c_row_map=plan.perm[l], w_frags=W["exp_dn"].frags()),
+                        ops.fp8_rows_desc(B.sh_inter, W["sh_dn"].w_q, W["sh_dn"].w_s, B.sh_out, w_frags=W["sh_dn"].frags()))
                 else:
                     if R:
                         # rows in bucket order are grouped by expert; the gather out of the token rows and the scatter back into

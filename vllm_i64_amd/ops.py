@@ -212,7 +212,9 @@ def gemm_i8(a: torch.Tensor, row_scale: torch.Tensor, w: torch.Tensor, w_scale: 
 
 def pack_weight_frags(w: torch.Tensor) -> torch.Tensor:
     """int8 weights [G, N, K] (or [N, K]) -> the fragment pack of i64h_gemm_i8_frags (same bytes, [G, N/16, K/64, 1024])."""
-    _chk(w, torch.int8, "w")
+    if w.dtype != torch.int8:  # one byte per element of any kind (e4m3 weights): the pack moves bytes
+        assert w.element_size() == 1
+        return pack_weight_frags(w.contiguous().view(torch.int8)).view(w.dtype)
     if w.dim() == 2:
         w = w.unsqueeze(0)
     G, N, K = w.shape
@@ -295,21 +297,18 @@ def gemm_fp8(a: torch.Tensor, a_scale: torch.Tensor, w: torch.Tensor, w_scale: t
 
 
 def gemm_fp8_rows(a: torch.Tensor, w: torch.Tensor, w_scale: torch.Tensor, out: torch.Tensor, *, m: Optional[int] = None, a_src_row=None,
-                  a_src_mod: int = 0, group_offsets=None, c_row_map=None, epilogue: int = EPI_STORE) -> torch.Tensor:
+                  a_src_mod: int = 0, group_offsets=None, c_row_map=None, epilogue: int = EPI_STORE, w_frags=None) -> torch.Tensor:
     """Decode-sized fp8_linear in one launch: fp32 rows `a`, per-token e4m3fn quantization inside the kernel (bit for bit
-    quantize_fp8_rows), then the product of gemm_fp8.  K a multiple of 64 up to 8192."""
-    _chk(a, torch.float32, "a")
-    if w.dim() == 2:
-        w, w_scale = w.unsqueeze(0), w_scale.reshape(1, -1)
-    G, N, K = w.shape
-    assert a.shape[1] == K and epilogue in (EPI_STORE, EPI_SWIGLU)
-    call("i64h_gemm_fp8_rows", ptr(a), ptr(a_src_row), a_src_mod, ptr(w), ptr(w_scale), ptr(group_offsets), G,
-         m if m is not None else a.shape[0], N, K, ptr(out), ptr(c_row_map), epilogue, _stream())
+    quantize_fp8_rows), then the product of gemm_fp8.  K a multiple of 64 up to 8192.  w_frags: the fragment pack of w, read
+    instead of it."""
+    assert epilogue in (EPI_STORE, EPI_SWIGLU)
+    gemm_fp8_rows_pair(fp8_rows_desc(a, w, w_scale, out, m=m, a_src_row=a_src_row, a_src_mod=a_src_mod, group_offsets=group_offsets,
+                                     c_row_map=c_row_map, w_frags=w_frags), None, epilogue)
     return out
 
 
 def fp8_rows_desc(a: torch.Tensor, w: torch.Tensor, w_scale: torch.Tensor, out: torch.Tensor, *, m: Optional[int] = None, a_src_row=None,
-                  a_src_mod: int = 0, group_offsets=None, c_row_map=None):
+                  a_src_mod: int = 0, group_offsets=None, c_row_map=None, w_frags=None):
     """One problem of gemm_fp8_rows_pair (arguments as gemm_fp8_rows)."""
     _chk(a, torch.float32, "a")
     if w.dim() == 2:
@@ -317,7 +316,8 @@ def fp8_rows_desc(a: torch.Tensor, w: torch.Tensor, w_scale: torch.Tensor, out: 
     G, N, K = w.shape
     assert a.shape[1] == K
     d = _lib.Fp8RowsDesc()
-    d.A, d.a_src_row, d.a_src_mod, d.B, d.b_scale = ptr(a), ptr(a_src_row), a_src_mod, ptr(w), ptr(w_scale)
+    d.A, d.a_src_row, d.a_src_mod, d.B, d.b_scale = ptr(a), ptr(a_src_row), a_src_mod, ptr(w if w_frags is None else w_frags), ptr(w_scale)
+    d.b_frags = int(w_frags is not None)
     d.group_offsets, d.num_groups, d.M, d.N, d.K = ptr(group_offsets), G, m if m is not None else a.shape[0], N, K
     d.C, d.c_row_map = ptr(out), ptr(c_row_map)
     return d
