@@ -661,13 +661,17 @@ class I64MoEModel:
             # two launches, each with this rank's experts and its shared expert as the second problem
             e_gu = ops.gemm_desc(x_all, W["exp_gu"].w_q, W["exp_gu"].w_s, B.e_inter, a_src_row=plan.perm[l], a_src_mod=n_all,
                                  a_row_slot=plan.sorted_bucket[l], a_slot_base=base + 3, group_offsets=eo, epilogue=ops.EPI_SWIGLU,
-                                 out_row_slot=plan.sorted_bucket[l], out_slot_base=base + 4 + nbk, stats=st, want_stats=True, m_total=R)
+                                 out_row_slot=plan.sorted_bucket[l], out_slot_base=base + 4 + nbk, stats=st, want_stats=True, m_total=R,
+                                 w_frags=self._wf(W["exp_gu"], ops.EPI_SWIGLU, W["sh_gu"] if shared else None))
             s_gu = ops.gemm_desc(B.normed, W["sh_gu"].w_q, W["sh_gu"].w_s, B.sh_inter, a_slot_base=base + spl - 1, epilogue=ops.EPI_SWIGLU,
-                                 out_slot_base=base + 3 + nbk, stats=st, want_stats=True) if shared else None
+                                 out_slot_base=base + 3 + nbk, stats=st, want_stats=True,
+                                 w_frags=self._wf(W["sh_gu"], ops.EPI_SWIGLU, W["exp_gu"])) if shared else None
             ops.gemm_i8_pair(e_gu, s_gu)
             e_dn = ops.gemm_desc(B.e_inter, W["exp_dn"].w_q, W["exp_dn"].w_s, out_buf, a_row_slot=plan.sorted_bucket[l],
-                                 a_slot_base=base + 4 + nbk, group_offsets=eo, stats=st, m_total=R, c_row_map=c_map)
-            s_dn = ops.gemm_desc(B.sh_inter, W["sh_dn"].w_q, W["sh_dn"].w_s, B.sh_out, a_slot_base=base + 3 + nbk, stats=st) if shared else None
+                                 a_slot_base=base + 4 + nbk, group_offsets=eo, stats=st, m_total=R, c_row_map=c_map,
+                                 w_frags=self._wf(W["exp_dn"], partner=W["sh_dn"] if shared else None))
+            s_dn = ops.gemm_desc(B.sh_inter, W["sh_dn"].w_q, W["sh_dn"].w_s, B.sh_out, a_slot_base=base + 3 + nbk, stats=st,
+                                 w_frags=self._wf(W["sh_dn"], partner=W["exp_dn"])) if shared else None
             ops.gemm_i8_pair(e_dn, s_dn)
             return ep.exchange(B.xsend, recv=B.xrecv).view(-1, H), B.recv_map[l]
         if shared:
