@@ -1,0 +1,88 @@
+"""GPU tests of the many-row forms of the element-wise kernels of a prefill chunk (a wave per few rows / 16 lanes per head): each
+must give, bit for bit, what the few-row form of the same entry point gives on the same rows.  -m gpu."""
+import warnings
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+warnings.filterwarnings("ignore")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from vllm_i64_amd import _lib
+    lib = _lib.load()
+    assert lib.i64h_device_check() == 0, lib.i64h_last_error().decode()
+    return torch.device("cuda:0")
+
+
+def _ops():
+    from vllm_i64_amd import ops
+    return ops
+
+
+@pytest.mark.parametrize("K_", [1024, 448, 1792, 64])
+def test_rows_minmax_and_quantize_dynamic_many_rows_equal_the_few_row_form(dev, K_):
+    ops = _ops()
+    g = torch.Generator().manual_seed(K_)
+    rows, n_slots = 5003, 9
+    x = (torch.randn(rows, K_, generator=g) * torch.rand(rows, 1, generator=g) * 3).to(dev)
+    slots = torch.sort(torch.randint(0, n_slots, (rows,), generator=g))[0].to(torch.int32).to(dev)
+    two = torch.stack([slots, (slots + 3) % n_slots], dim=1).contiguous()  # two slots per row
+    st_many, st_few = ops.stats_alloc(n_slots + 1, dev), ops.stats_alloc(n_slots + 1, dev)
+    ops.stats_reset(st_many)
+    ops.stats_reset(st_few)
+    ops.rows_minmax(x, st_many, slots=two, slot_base=1)               # > 2048 rows: the wave-per-rows kernel
+    for s in range(0, rows, 1000):                                    # <= 2048 rows a call: the workgroup-per-row kernel
+        ops.rows_minmax(x[s:s + 1000], st_few, slots=two[s:s + 1000].contiguous(), slot_base=1)
+    assert torch.equal(ops.qparams(st_many, n_slots + 1)[2], ops.qparams(st_few, n_slots + 1)[2])
+    # quantization: plain rows, and gathered rows (every row twice, in a permuted order) with their slots
+    a_many, s_many, z_many = ops.quantize_dynamic(x, st_many, slot_base=1, row_slot=slots, want_zp=True)
+    outs = [ops.quantize_dynamic(x[s:s + 1000], st_many, slot_base=1, row_slot=slots[s:s + 1000].contiguous(), want_zp=True)
+            for s in range(0, rows, 1000)]
+    assert torch.equal(a_many, torch.cat([o[0] for o in outs])) and torch.equal(s_many, torch.cat([o[1] for o in outs]))
+    assert torch.equal(z_many, torch.cat([o[2] for o in outs]))
+    perm = torch.randperm(2 * rows, generator=g).to(torch.int32).to(dev)
+    pslot = slots[(perm % rows).long()].contiguous()
+    a_g, s_g = ops.quantize_dynamic(x, st_many, slot_base=1, src_row=perm, src_mod=rows, row_slot=pslot)
+    a_ref, s_ref = ops.quantize_dynamic(x[(perm % rows).long()].contiguous()[:1500], st_many, slot_base=1, row_slot=pslot[:1500].contiguous())
+    assert torch.equal(a_g[:1500], a_ref) and torch.equal(s_g[:1500], s_ref)
+    assert torch.equal(a_g, a_many[(perm % rows).long()])
+
+
+@pytest.mark.parametrize("kv_dtype", [torch.float32, torch.bfloat16, torch.float16, torch.float8_e4m3fn])
+@pytest.mark.parametrize("with_norm", [True, False])
+def test_qk_norm_rope_kv_many_tokens_equals_the_per_token_form(dev, kv_dtype, with_norm):
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    n, nh, kvh, hd, block, seqs = 1500, 5, 3, 64, 16, 6
+    qkv = torch.randn(n, (nh + 2 * kvh) * hd, generator=g).to(dev)
+    qw = (torch.rand(hd, generator=g) + 0.5).to(dev) if with_norm else None
+    kw = (torch.rand(hd, generator=g) + 0.5).to(dev) if with_norm else None
+    max_pos = 512
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    fr = torch.outer(torch.arange(max_pos).float(), inv)
+    rope = torch.cat([fr.cos(), fr.sin()], dim=-1).contiguous().to(dev)
+    slot_ids = torch.randint(0, seqs, (n,), generator=g, dtype=torch.int32)
+    positions = torch.zeros(n, dtype=torch.int32)
+    for s in range(seqs):  # distinct positions inside a sequence
+        idx = (slot_ids == s).nonzero().flatten()
+        positions[idx] = torch.randperm(max_pos, generator=g)[: idx.numel()].to(torch.int32)
+    mb = max_pos // block
+    bt = torch.randperm(seqs * mb, generator=g).to(torch.int32).view(seqs, mb).contiguous()
+    bt[2, 5] = -1  # a block that is not there: its rows are not written
+    outs = []
+    for chunks in (1, 3):  # 1500 tokens in one call: 16 lanes per head; 500 a call: one wave per head
+        k = torch.zeros(seqs * mb, block, kvh, hd, device=dev).to(kv_dtype)
+        v = torch.zeros(seqs * mb, block, kvh, hd, device=dev).to(kv_dtype)
+        q = torch.zeros(n, nh, hd, device=dev)
+        step = n // chunks
+        for s in range(0, n, step):
+            ops.qk_norm_rope_kv(qkv[s:s + step], qw, kw, 1e-6, rope, positions[s:s + step].to(dev), slot_ids[s:s + step].to(dev), bt.to(dev), k, v,
+                                nh, kvh, hd, q_out=q[s:s + step])
+        outs.append((q, k.view(torch.uint8) if k.element_size() == 1 else k, v.view(torch.uint8) if v.element_size() == 1 else v))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)

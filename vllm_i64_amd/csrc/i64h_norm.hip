@@ -235,6 +235,89 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kv_kernel(const float* __res
     }
 }
 
+// The same for many tokens and head_dim 64 (prefill): 16 lanes per (token, head), four dims per lane (dims 4 l .. 4 l + 3), so a
+// wave reads 1 KB of consecutive bytes per load instead of 256.  The sum of squares is formed in the one-dim-per-lane kernel's
+// butterfly order (dim ^ 32, ^ 16, ^ 8, ^ 4, ^ 2, ^ 1; additions commute, so every dim ends with the same bits as there): dim ^ 32 is
+// lane ^ 8 of the 16, dim ^ 16 lane ^ 4, dim ^ 8 lane ^ 2, dim ^ 4 lane ^ 1 (DPP moves inside the row of 16), dim ^ 2 and ^ 1 are the
+// lane's own components.  The rotation partner dim +- 32 is lane ^ 8 again.
+template <typename KV>
+__device__ __forceinline__ void kv_store4(KV* dst, const float (&o)[4]) {
+    if constexpr (sizeof(KV) == 4) {
+        *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
+    } else if constexpr (sizeof(KV) == 2) {
+        unsigned short h[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const KV t = to_kv<KV>(o[c]); h[c] = __builtin_bit_cast(unsigned short, t); }
+        *(uint2*)dst = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
+    } else {
+        uint32_t w = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const KV t = to_kv<KV>(o[c]); w |= (uint32_t)__builtin_bit_cast(unsigned char, t) << (8 * c); }
+        *(uint32_t*)dst = w;
+    }
+}
+
+template <typename KV>
+__global__ __launch_bounds__(256) void qk_norm_rope_kv_vec_kernel(const float* __restrict__ qkv, const float* __restrict__ qw,
+                                                                  const float* __restrict__ kw, float qk_eps, const float* __restrict__ rope_tab,
+                                                                  const int32_t* __restrict__ positions, const int32_t* __restrict__ slot_ids,
+                                                                  const int32_t* __restrict__ block_table, int max_blocks_per_seq,
+                                                                  float* __restrict__ q_out, KV* __restrict__ k_cache, KV* __restrict__ v_cache,
+                                                                  int64_t n, int nh, int kvh, int block) {
+    constexpr int hd = 64;
+    const int heads = nh + 2 * kvh;
+    const int64_t gid = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);  // (token, head)
+    if (gid >= n * heads) return;
+    const int64_t t = gid / heads;
+    const int head = (int)(gid - t * heads);
+    const int l = threadIdx.x & 15;
+    const int pos = positions[t];
+    const int pb = block_table[(int64_t)slot_ids[t] * max_blocks_per_seq + pos / block];
+    const int64_t cache_row = ((int64_t)pb * block + pos % block) * kvh;  // in heads
+    const float4 xv = *(const float4*)(qkv + gid * hd + 4 * l);
+    float x[4] = {xv.x, xv.y, xv.z, xv.w};
+    if (head >= nh + kvh) {  // V: raw copy into the cache
+        if (pb >= 0) kv_store4<KV>(v_cache + (cache_row + (head - nh - kvh)) * hd + 4 * l, x);
+        return;
+    }
+    const bool is_q = head < nh;
+    const float* w = is_q ? qw : kw;
+    float self[4];
+    if (w) {
+        float s[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s[c] = __builtin_fmaf(x[c], x[c], 0.0f);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s[c] += I64H_DPPF(s[c], 0x128);  // row_ror:8 = lane ^ 8 (dim ^ 32)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s[c] += I64H_DPPF(s[c], 0x124);  // row_ror:4: the values have period 8 now = lane ^ 4 (dim ^ 16)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s[c] += I64H_DPPF(s[c], 0x4E);   // lane ^ 2 (dim ^ 8)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s[c] += I64H_DPPF(s[c], 0xB1);   // lane ^ 1 (dim ^ 4)
+        const float a0 = s[0] + s[2], a1 = s[1] + s[3];              // dim ^ 2 (both partners form the same sum)
+        const float ss = a0 + a1;                                    // dim ^ 1
+        const float rr = rsqrtf(ss / (float)hd + qk_eps);
+        const float4 wv = *(const float4*)(w + 4 * l);
+        self[0] = x[0] * rr * wv.x; self[1] = x[1] * rr * wv.y; self[2] = x[2] * rr * wv.z; self[3] = x[3] * rr * wv.w;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) self[c] = x[c];
+    }
+    const float* cs = rope_tab + (int64_t)pos * hd;
+    const float4 cv = *(const float4*)(cs + 4 * (l & 7)), sv = *(const float4*)(cs + 32 + 4 * (l & 7));
+    const float cc[4] = {cv.x, cv.y, cv.z, cv.w}, sn[4] = {sv.x, sv.y, sv.z, sv.w};
+    float o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float partner = I64H_DPPF(self[c], 0x128);  // dim +- 32
+        const float other = l < 8 ? -partner : partner;
+        o[c] = self[c] * cc[c] + other * sn[c];
+    }
+    if (is_q) *(float4*)(q_out + (t * nh + head) * hd + 4 * l) = make_float4(o[0], o[1], o[2], o[3]);
+    else if (pb >= 0) kv_store4<KV>(k_cache + (cache_row + (head - nh)) * hd + 4 * l, o);
+}
+
 // ---- RoPE operator (x [n, heads, hd], cos/sin [n, hd], first half used) --------------------------------------
 __global__ void rope_kernel(const float* __restrict__ x, const float* __restrict__ cos_, const float* __restrict__ sin_, float* __restrict__ out,
                             int64_t total, int heads, int hd) {
@@ -447,6 +530,25 @@ int i64h_qk_norm_rope_kv(const float* qkv, const float* q_norm_w, const float* k
     hipStream_t st = (hipStream_t)stream;
     // few tokens (decode): one wave per head, heads spread over the grid; many tokens: one workgroup walks a token's heads
     const int heads = num_heads + 2 * num_kv_heads;
+    if (n > 1024 && head_dim == 64 && ((uintptr_t)qkv | (uintptr_t)q_out | (uintptr_t)k_cache | (uintptr_t)v_cache | (uintptr_t)rope_tab) % 16 == 0 &&
+        (uintptr_t)q_norm_w % 16 == 0 && (uintptr_t)k_norm_w % 16 == 0 && (q_norm_w == nullptr) == (k_norm_w == nullptr)) {
+        // many tokens, 64-dim heads: 16 lanes per (token, head), whole cache lines per load
+        const int64_t groups = n * heads;
+        dim3 vgrid((unsigned)((groups + 15) / 16)), vblk(256);
+#define LAUNCH_QKRV(T)                                                                                                                 \
+    hipLaunchKernelGGL(qk_norm_rope_kv_vec_kernel<T>, vgrid, vblk, 0, st, qkv, q_norm_w, k_norm_w, qk_eps, rope_tab, positions, slot_ids, \
+                       block_table, (int)max_blocks_per_seq, q_out, (T*)k_cache, (T*)v_cache, n, (int)num_heads, (int)num_kv_heads,      \
+                       (int)block_size)
+        if (kv_dtype == 0) LAUNCH_QKRV(float);
+        else if (kv_dtype == 1) LAUNCH_QKRV(__half);
+        else if (kv_dtype == 2) LAUNCH_QKRV(__hip_bfloat16);
+        else if (kv_dtype == 3) LAUNCH_QKRV(F8E4);
+        else if (kv_dtype == 4) LAUNCH_QKRV(F8E5);
+        else I64H_CHECK_ARG(false, "qk_norm_rope_kv: unknown kv dtype %d", kv_dtype);
+#undef LAUNCH_QKRV
+        I64H_CHECK_LAUNCH();
+        return 0;
+    }
     dim3 grid((unsigned)n, n <= 1024 ? (unsigned)((heads + 3) / 4) : 1u), blk(256);
 #define LAUNCH_QKR(T)                                                                                                             \
     hipLaunchKernelGGL(qk_norm_rope_kv_kernel<T>, grid, blk, 0, st, qkv, q_norm_w, k_norm_w, qk_eps, rope_tab, positions, slot_ids, \

@@ -92,6 +92,99 @@ __global__ __launch_bounds__(256) void quantize_dynamic_kernel(const float* __re
     }
 }
 
+// min/max of many rows (prefill): a wave owns RM_RPW consecutive rows, all loads of a row in flight together, no barrier per
+// row; per-workgroup table of ordered (min, max) per relative slot through LDS atomics, flushed once.
+#define RM_RPW 8
+__global__ __launch_bounds__(256) void rows_minmax_rows_kernel(const float* __restrict__ x, int64_t rows, int K,
+                                                               const int32_t* __restrict__ slots, int slots_per_row, int slot_base,
+                                                               uint32_t* __restrict__ stats) {
+    __shared__ uint32_t tab_lo[I64H_STAT_TAB], tab_hi[I64H_STAT_TAB];
+    for (int i = threadIdx.x; i < I64H_STAT_TAB; i += 256) { tab_lo[i] = I64H_ORDERED_ZERO; tab_hi[i] = I64H_ORDERED_ZERO; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RM_RPW;
+    const int nv = K >> 2;
+    for (int64_t r = r0; r < r0 + RM_RPW && r < rows; ++r) {
+        const float4* xr = (const float4*)(x + r * K);
+        float lo = 0.0f, hi = 0.0f;
+        for (int i = lane; i < nv; i += 64) {
+            const float4 v = xr[i];
+            lo = fminf(lo, fminf(fminf(v.x, v.y), fminf(v.z, v.w)));
+            hi = fmaxf(hi, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+        }
+        lo = wave_min(lo);
+        hi = wave_max(hi);
+        const int ns = slots ? slots_per_row : 1;
+        if (lane < ns) {
+            const int rel = slots ? slots[r * slots_per_row + lane] : 0;
+            if (rel >= 0 && rel < I64H_STAT_TAB) {
+                atomicMin(&tab_lo[rel], f32_to_ordered(lo));
+                atomicMax(&tab_hi[rel], f32_to_ordered(hi));
+            } else {
+                stat_update(stats, slot_base + rel, blockIdx.x, lo, hi);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < I64H_STAT_TAB; i += 256)
+        if (tab_lo[i] != I64H_ORDERED_ZERO || tab_hi[i] != I64H_ORDERED_ZERO) {
+            uint32_t* q = stats + (int64_t)(slot_base + i) * I64H_SLOT_WORDS + 2 * (blockIdx.x & (I64H_NSHARD - 1));
+            atomicMin(q, tab_lo[i]);
+            atomicMax(q + 1, tab_hi[i]);
+        }
+}
+
+// The same for many rows (prefill): a wave owns QD_RPW consecutive rows and keeps a row's K / 256 float4 loads in flight
+// together; the parameters of a slot are derived by the wave itself (lane l reads word l of the slot's 64, a wave-wide
+// min / max folds the 32 shards) and kept while consecutive rows report to the same slot (rows arrive sorted by bucket).
+// One workgroup per row with one thread deriving the parameters in front of everybody's single load ran at half this rate.
+#define QD_RPW 8
+#define QD_MAXV 8  // float4 per lane and row: K <= 2048
+__global__ __launch_bounds__(256) void quantize_dynamic_rows_kernel(const float* __restrict__ x, int K, int64_t out_rows,
+                                                                    const int32_t* __restrict__ src_row, int src_mod,
+                                                                    const int32_t* __restrict__ row_slot, int slot_base,
+                                                                    const uint32_t* __restrict__ stats, int8_t* __restrict__ a,
+                                                                    float* __restrict__ row_scale, int32_t* __restrict__ row_zp) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * QD_RPW;
+    const int nv = K >> 2;  // K % 4 == 0 (launcher)
+    int prev_slot = -1;
+    QParams q;
+    q.scale = 0.0f; q.inv_scale = 0.0f; q.zp = 0;
+    for (int64_t r = r0; r < r0 + QD_RPW && r < out_rows; ++r) {
+        const int64_t sr = src_row ? (int64_t)(src_row[r] % src_mod) : r;
+        const int slot = slot_base + (row_slot ? row_slot[r] : 0);
+        const float4* xr = (const float4*)(x + sr * K);
+        float4 v[QD_MAXV];
+#pragma unroll
+        for (int j = 0; j < QD_MAXV; ++j) {
+            const int i = lane + 64 * j;
+            v[j] = i < nv ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (slot != prev_slot) {  // wave-uniform
+            const uint32_t wd = stats[(int64_t)slot * I64H_SLOT_WORDS + lane];  // words alternate (min, max) over the shards
+            uint32_t mn = (lane & 1) ? 0xffffffffu : wd, mx = (lane & 1) ? wd : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
+                mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+            }
+            q = choose_qparams_u7(ordered_to_f32(mn), ordered_to_f32(mx));
+            prev_slot = slot;
+        }
+        if (lane == 0) {
+            row_scale[r] = q.scale;
+            if (row_zp) row_zp[r] = q.zp;
+        }
+        uint32_t* ar = (uint32_t*)(a + r * K);
+#pragma unroll
+        for (int j = 0; j < QD_MAXV; ++j) {
+            const int i = lane + 64 * j;
+            if (i < nv) ar[i] = quantize4_u7_signed(v[j], q);
+        }
+    }
+}
+
 // Read back the parameters of a range of slots (tests / debugging).
 __global__ void qparams_kernel(const uint32_t* __restrict__ stats, int n_slots, float* __restrict__ scale, int32_t* __restrict__ zp,
                                float* __restrict__ lo_hi) {
@@ -176,6 +269,13 @@ int i64h_rows_minmax(const float* x, int64_t rows, int32_t K, const int32_t* slo
                      uint32_t* stats, void* stream) {
     I64H_CHECK_ARG(rows >= 0 && K > 0, "rows_minmax: bad sizes");
     if (rows == 0) return 0;
+    if (rows > 2048 && K % 4 == 0 && (uintptr_t)x % 16 == 0 && slots_per_row <= 64) {  // many rows: a wave per RM_RPW rows
+        const int64_t waves = (rows + RM_RPW - 1) / RM_RPW;
+        hipLaunchKernelGGL(rows_minmax_rows_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, rows, (int)K, slots,
+                           (int)slots_per_row, (int)slot_base, stats);
+        I64H_CHECK_LAUNCH();
+        return 0;
+    }
     const int rpb = rows > 2048 ? 16 : 1;  // many rows: fold 16 rows per workgroup before touching the global slots
     hipLaunchKernelGGL(rows_minmax_kernel, dim3((unsigned)i64h_cdiv(rows, rpb)), dim3(256), 0, (hipStream_t)stream, x, rows, (int)K, rpb,
                        slots, (int)slots_per_row, (int)slot_base, stats);
@@ -189,6 +289,13 @@ int i64h_quantize_dynamic(const float* x, int64_t out_rows, int32_t K, const int
     I64H_CHECK_ARG(out_rows >= 0 && K > 0, "quantize_dynamic: bad sizes");
     I64H_CHECK_ARG(src_row == nullptr || src_mod > 0, "quantize_dynamic: src_mod must be > 0 with src_row");
     if (out_rows == 0) return 0;
+    if (out_rows >= 2048 && K % 4 == 0 && K <= 256 * QD_MAXV && ((uintptr_t)x | (uintptr_t)a) % 16 == 0) {  // many rows: a wave per QD_RPW rows
+        const int64_t waves = (out_rows + QD_RPW - 1) / QD_RPW;
+        hipLaunchKernelGGL(quantize_dynamic_rows_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (int)K,
+                           out_rows, src_row, (int)src_mod, row_slot, (int)slot_base, stats, a, row_scale, row_zp);
+        I64H_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(quantize_dynamic_kernel, dim3((unsigned)out_rows), dim3(256), 0, (hipStream_t)stream, x, (int)K, src_row,
                        (int)src_mod, row_slot, (int)slot_base, stats, a, row_scale, row_zp);
     I64H_CHECK_LAUNCH();
