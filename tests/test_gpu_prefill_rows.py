@@ -86,3 +86,42 @@ def test_qk_norm_rope_kv_many_tokens_equals_the_per_token_form(dev, kv_dtype, wi
         outs.append((q, k.view(torch.uint8) if k.element_size() == 1 else k, v.view(torch.uint8) if v.element_size() == 1 else v))
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("H_,mode", [(1024, "add"), (1024, "moe"), (448, "moe_noshared"), (64, "add"), (1024, "moe_identity")])
+def test_fused_residual_norm_many_rows_equals_the_few_row_form(dev, H_, mode):
+    """More than 2048 rows take the wave-per-rows kernel; its sum of squares is formed in the workgroup-per-row kernel's order, so
+    the residual stream, the normalised rows and the call statistics are the same bits."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(H_ + len(mode))
+    n, top_k, n_slots = 2600, 2, 7
+    h = torch.randn(n, H_, generator=g).to(dev)
+    add = torch.randn(n, H_, generator=g).to(dev) if mode == "add" else None
+    w = (torch.rand(H_, generator=g) + 0.5).to(dev)
+    rows = inv = shared = None
+    rw = ()
+    if mode.startswith("moe"):
+        rows = torch.randn(top_k * n, H_, generator=g).to(dev)
+        inv = None if mode == "moe_identity" else torch.randperm(top_k * n, generator=g).to(torch.int32).to(dev)
+        shared = None if mode == "moe_noshared" else torch.randn(n, H_, generator=g).to(dev)
+        rw = (0.6, 0.4)
+    slots = torch.randint(0, n_slots, (n, 3), generator=g, dtype=torch.int32).to(dev)
+    st_many, st_few = ops.stats_alloc(n_slots + 2, dev), ops.stats_alloc(n_slots + 2, dev)
+    ops.stats_reset(st_many)
+    ops.stats_reset(st_few)
+    kw = dict(route_weights=rw, routed_scale=1.5, shared_scale=0.75, slot_base=2)
+    ho, no = ops.fused_residual_norm(h, w, 1e-6, add=add, moe_rows=rows, moe_inv=inv, moe_shared=shared, slots=slots, stats=st_many, **kw)
+    hs, ns = [], []
+    step = 650
+    for s in range(0, n, step):
+        e = s + step
+        c_rows, c_inv = rows, None
+        if rows is not None:  # the chunk's (route, token) rows: route k of token s + t is row k * step + t of the chunk's own list
+            src = torch.cat([(inv[k * n + s: k * n + e].long() if inv is not None else torch.arange(k * n + s, k * n + e, device=dev)) for k in range(top_k)])
+            c_rows = rows[src].contiguous()
+        a, b = ops.fused_residual_norm(h[s:e], w, 1e-6, add=None if add is None else add[s:e], moe_rows=c_rows, moe_inv=c_inv,
+                                       moe_shared=None if shared is None else shared[s:e], slots=slots[s:e].contiguous(), stats=st_few, **kw)
+        hs.append(a)
+        ns.append(b)
+    assert torch.equal(ho, torch.cat(hs)) and torch.equal(no, torch.cat(ns))
+    assert torch.equal(ops.qparams(st_many, n_slots + 2)[2], ops.qparams(st_few, n_slots + 2)[2])

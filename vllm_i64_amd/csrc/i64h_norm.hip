@@ -174,6 +174,122 @@ __global__ __launch_bounds__(256) void fused_residual_norm_kernel(const float* _
     if (use_tab && normed) stat_tab_flush(tab_lo, tab_hi, stats, slot_base, blockIdx.x);
 }
 
+// The same for many rows (prefill) and H <= 1024: a wave owns FRR_RPW consecutive rows, no barrier per row, every operand load
+// of a row in flight together.  Lane l stands for threads l, l + 64, l + 128, l + 192 of the workgroup-per-row kernel (float4
+// l + 64 v of the row, v = 0..3): the sum of squares is formed per v exactly as there (fma chain over the four components, the
+// wave butterfly) and the four results are added in that kernel's order, so every value of the row has the same bits.
+#define FRR_RPW 4
+__global__ __launch_bounds__(256) void fused_residual_norm_rows_kernel(const float* __restrict__ h, const float* __restrict__ add,
+                                                                       MoeCombine mc, int64_t n, float* __restrict__ h_out,
+                                                                       const float* __restrict__ w, float eps, float* __restrict__ normed,
+                                                                       int H, const int32_t* __restrict__ slots, int spr, int slot_base,
+                                                                       uint32_t* __restrict__ stats) {
+    __shared__ uint32_t tab_lo[I64H_STAT_TAB], tab_hi[I64H_STAT_TAB];
+    if (stats) {
+        for (int i = threadIdx.x; i < I64H_STAT_TAB; i += 256) { tab_lo[i] = I64H_ORDERED_ZERO; tab_hi[i] = I64H_ORDERED_ZERO; }
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    const int nv = H / 4;  // <= 256 (launcher)
+    const int64_t t0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * FRR_RPW;
+    float4 gw[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int i = lane + 64 * v;
+        gw[v] = (normed && i < nv) ? ((const float4*)w)[i] : make_float4(0, 0, 0, 0);
+    }
+    for (int64_t t = t0; t < t0 + FRR_RPW && t < n; ++t) {
+        float4 a[4];
+        float ssv[4];
+        int64_t rrow[8];
+        if (mc.rows) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k < mc.top_k) rrow[k] = mc.inv ? (int64_t)mc.inv[(int64_t)k * n + t] : (int64_t)k * n + t;
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int i = lane + 64 * v;
+            float4 x = make_float4(0, 0, 0, 0);
+            if (i < nv) {
+                if (h) x = ((const float4*)(h + t * H))[i];
+                if (add) {
+                    const float4 b = ((const float4*)(add + t * H))[i];
+                    x.x = x.x + b.x; x.y = x.y + b.y; x.z = x.z + b.z; x.w = x.w + b.w;
+                }
+                if (mc.rows) {
+                    const float4 r0 = ((const float4*)(mc.rows + rrow[0] * H))[i];
+                    float4 o = make_float4(mc.wk[0] * r0.x, mc.wk[0] * r0.y, mc.wk[0] * r0.z, mc.wk[0] * r0.w);
+#pragma unroll
+                    for (int k = 1; k < 8; ++k) {
+                        if (k < mc.top_k) {
+                            const float4 rk = ((const float4*)(mc.rows + rrow[k] * H))[i];
+                            o.x = o.x + mc.wk[k] * rk.x; o.y = o.y + mc.wk[k] * rk.y;
+                            o.z = o.z + mc.wk[k] * rk.z; o.w = o.w + mc.wk[k] * rk.w;
+                        }
+                    }
+                    if (mc.shared) {
+                        const float4 sh = ((const float4*)(mc.shared + t * H))[i];
+                        o.x = mc.routed_scale * o.x + mc.shared_scale * sh.x; o.y = mc.routed_scale * o.y + mc.shared_scale * sh.y;
+                        o.z = mc.routed_scale * o.z + mc.shared_scale * sh.z; o.w = mc.routed_scale * o.w + mc.shared_scale * sh.w;
+                    } else {
+                        o.x = mc.routed_scale * o.x; o.y = mc.routed_scale * o.y; o.z = mc.routed_scale * o.z; o.w = mc.routed_scale * o.w;
+                    }
+                    if (h || add) { x.x = x.x + o.x; x.y = x.y + o.y; x.z = x.z + o.z; x.w = x.w + o.w; }
+                    else x = o;
+                }
+                if (h_out) ((float4*)(h_out + t * H))[i] = x;
+            }
+            a[v] = x;
+            float ss = 0.0f;
+            if (i < nv) {
+                ss = __builtin_fmaf(x.x, x.x, ss); ss = __builtin_fmaf(x.y, x.y, ss);
+                ss = __builtin_fmaf(x.z, x.z, ss); ss = __builtin_fmaf(x.w, x.w, ss);
+            }
+            ssv[v] = ss;
+        }
+        if (!normed) continue;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) ssv[v] = wave_sum(ssv[v]);
+        const float rr = rsqrtf((ssv[0] + ssv[1] + ssv[2] + ssv[3]) / (float)H + eps);
+        float lo = 0.0f, hi = 0.0f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int i = lane + 64 * v;
+            if (i < nv) {
+                const float4 g = gw[v];
+                float4 y = a[v];
+                y.x = y.x * rr * g.x; y.y = y.y * rr * g.y; y.z = y.z * rr * g.z; y.w = y.w * rr * g.w;
+                ((float4*)(normed + t * H))[i] = y;
+                lo = fminf(lo, fminf(fminf(y.x, y.y), fminf(y.z, y.w)));
+                hi = fmaxf(hi, fmaxf(fmaxf(y.x, y.y), fmaxf(y.z, y.w)));
+            }
+        }
+        if (!stats) continue;
+        lo = wave_min(lo);
+        hi = wave_max(hi);
+        const int ns = slots ? spr : 1;
+        if (lane < ns) {
+            const int rel = slots ? slots[t * spr + lane] : 0;
+            if (rel >= 0 && rel < I64H_STAT_TAB) {
+                atomicMin(&tab_lo[rel], f32_to_ordered(lo));
+                atomicMax(&tab_hi[rel], f32_to_ordered(hi));
+            } else {
+                stat_update(stats, slot_base + rel, blockIdx.x, lo, hi);
+            }
+        }
+    }
+    if (stats && normed) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < I64H_STAT_TAB; i += 256)
+            if (tab_lo[i] != I64H_ORDERED_ZERO || tab_hi[i] != I64H_ORDERED_ZERO) {
+                uint32_t* q = stats + (int64_t)(slot_base + i) * I64H_SLOT_WORDS + 2 * (blockIdx.x & (I64H_NSHARD - 1));
+                atomicMin(q, tab_lo[i]);
+                atomicMax(q + 1, tab_hi[i]);
+            }
+    }
+}
+
 // ---- per-head QK RMSNorm + rotate-half RoPE + paged KV write ----------------------------------------------
 // qkv [n, (nh + 2*kvh) * hd] fp32 from the fused projection.  One wave per head; heads of a token are spread
 // over the workgroup's waves.  q_out [n, nh, hd] fp32.  K (normed, rotated) and V (raw) go to the paged cache
@@ -513,6 +629,15 @@ int i64h_fused_residual_norm(const float* h, const float* add, const float* moe_
     for (int k = 0; k < 8; ++k) mc.wk[k] = (moe_rows && k < top_k) ? route_weights[k] : 0.0f;
     mc.routed_scale = routed_scale;
     mc.shared_scale = shared_scale;
+    const bool al16 = (((uintptr_t)h | (uintptr_t)add | (uintptr_t)moe_rows | (uintptr_t)moe_shared | (uintptr_t)h_out | (uintptr_t)normed |
+                        (uintptr_t)norm_weight) % 16) == 0;
+    if (n > 2048 && H <= 1024 && slots_per_row <= 64 && al16) {  // many rows: a wave per FRR_RPW rows (same bits)
+        const int64_t waves = (n + FRR_RPW - 1) / FRR_RPW;
+        hipLaunchKernelGGL(fused_residual_norm_rows_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, h, add, mc, n,
+                           h_out, norm_weight, eps, normed, (int)H, slots, (int)slots_per_row, (int)slot_base, stats);
+        I64H_CHECK_LAUNCH();
+        return 0;
+    }
     const int rpb = n > 2048 ? 8 : 1;  // many rows: fold 8 rows per workgroup before touching the global stat slots
     hipLaunchKernelGGL(fused_residual_norm_kernel, dim3((unsigned)i64h_cdiv(n, rpb)), dim3(256), 0, (hipStream_t)stream, h, add, mc,
                        (int)n, rpb, h_out, norm_weight, eps, normed, (int)H, slots, (int)slots_per_row, (int)slot_base, stats);
