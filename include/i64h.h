@@ -138,7 +138,7 @@ int i64h_gemm_i8_qkv_rope_kv(const i64h_gemm_desc* d, const float* q_norm_w, con
 int i64h_gemm_i8_colscale(const int8_t* A, const float* row_scale, const int8_t* B, const float* col_scale, int64_t M, int32_t N, int32_t K,
                           float* C, void* stream);
 /* Operand-stationary form of i64h_gemm_i8 for prefill-sized problems with a short K (K % 64 == 0, 128 rows x K bytes must fit
- * LDS: K <= 1024; N % 32 == 0): a workgroup keeps 128 operand rows in LDS for all output columns, the weights are read as a
+ * LDS: K <= 1024, or 64 rows for K <= 2432; N % 32 == 0): a workgroup keeps 128 operand rows in LDS for all output columns, the weights are read as a
  * fragment pack made once by i64h_pack_weight_frags ([G][N/16][K/64] pieces of 1 KB in matrix-core lane order).  Results are
  * bit-identical to i64h_gemm_i8.  Same reference counterpart as i64h_gemm_i8 (csrc/i64_expert_dispatch.cu:144-233,
  * token_routed_mlp.py:135-144); the pack replaces nothing in the reference (its weights stay in the nn.Linear layout). */

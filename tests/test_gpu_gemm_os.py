@@ -44,7 +44,7 @@ def _offsets(M_, G_, g):
 
 @pytest.mark.parametrize("depth", [2, 3])
 @pytest.mark.parametrize("M_,N_,K_,G_", [(1, 64, 64, 1), (77, 192, 448, 1), (4133, 160, 256, 3), (9000, 1024, 448, 8), (2500, 1536, 1024, 1),
-                                          (40000, 32, 128, 5), (300, 1120, 192, 2)])
+                                          (40000, 32, 128, 5), (300, 1120, 192, 2), (3000, 256, 1792, 2), (700, 64, 2432, 1)])
 def test_gemm_i8_frags_exact(dev, M_, N_, K_, G_, depth):
     ops = _ops()
     g = torch.Generator().manual_seed(M_ * 3 + N_ + depth)
@@ -69,7 +69,7 @@ def test_gemm_i8_frags_exact(dev, M_, N_, K_, G_, depth):
 
 
 @pytest.mark.parametrize("grid", [256, 40])
-@pytest.mark.parametrize("I_,K_", [(448, 1024), (64, 128), (1792, 1024), (96, 320), (16, 64), (272, 512)])
+@pytest.mark.parametrize("I_,K_", [(448, 1024), (64, 128), (1792, 1024), (96, 320), (16, 64), (272, 512), (64, 1792)])
 def test_gemm_i8_frags_swiglu_and_stats_match_the_row_major_kernels(dev, I_, K_, grid):
     ops = _ops()
     g = torch.Generator().manual_seed(13 + I_)
@@ -142,7 +142,8 @@ def test_gemm_i8_frags_column_scale(dev):
 
 def test_gemm_i8_frags_refuses_unsupported_shapes(dev):
     ops = _ops()
-    assert not ops.gemm_i8_frags_ok(1024, 1792, ops.EPI_STORE)  # 128 rows x K bytes beyond LDS
+    assert ops.gemm_i8_frags_ok(1024, 1792, ops.EPI_STORE)      # long K: tiles of 64 rows
+    assert not ops.gemm_i8_frags_ok(1024, 4096, ops.EPI_STORE)  # 64 rows x K bytes beyond LDS
     assert not ops.gemm_i8_frags_ok(100, 256, ops.EPI_STORE)
     assert not ops.gemm_i8_frags_ok(128, 96, ops.EPI_SWIGLU)
     assert not ops.gemm_i8_frags_ok(48, 128, ops.EPI_SWIGLU)

@@ -127,7 +127,8 @@ def bench_gemm_os(only=None, ragged=False):
     """The operand-stationary kernel (weights as a fragment pack) on the prefill shapes it takes, per depth of its weight stream."""
     torch.manual_seed(0)
     shapes = [("expert gate_up (grouped, SwiGLU)", 32768, 896, 1024, 8, 1), ("expert down (grouped)", 32768, 1024, 448, 8, 0),
-              ("shared gate_up (SwiGLU)", 16384, 3584, 1024, 1, 1), ("qkv", 16384, 1536, 1024, 1, 0), ("o", 16384, 1024, 1024, 1, 0)]
+              ("shared gate_up (SwiGLU)", 16384, 3584, 1024, 1, 1), ("qkv", 16384, 1536, 1024, 1, 0), ("o", 16384, 1024, 1024, 1, 0),
+              ("shared down", 16384, 1024, 1792, 1, 0)]
     for name, M, N, K, G, epi in shapes:
         if only and only not in name:
             continue

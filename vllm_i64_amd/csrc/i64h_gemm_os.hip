@@ -295,6 +295,11 @@ template <int EPI, int DB, int NW, int WMAX>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4)))
 void gemm_i8_os_kernel(GemmI8Args p, const int8_t* __restrict__ Bf, int parts, int rotk, int tall_ok) {
     const int lane = threadIdx.x & 63, nwg = gridDim.x;
+    if (tall_ok < 0) {  // long K (up to 2432): only 64 operand rows x K fit LDS
+        const int t4 = __builtin_amdgcn_readfirstlane(os_count_tiles(p, 64, lane));
+        os_run<EPI, DB, NW, WMAX, 4>(p, Bf, t4 * parts, parts, rotk);
+        return;
+    }
     const int t8 = __builtin_amdgcn_readfirstlane(os_count_tiles(p, 128, lane));
     bool tall = false;
     int t9 = 0;
@@ -318,8 +323,9 @@ static size_t os_lds_bytes(int K, int mfr) { return (size_t)(K / 64) * mfr * 102
 
 template <int EPI, int DB, int NW, int WMAX>
 static int launch_os(const GemmI8Args& p, const int8_t* Bf, int n_items, int parts, hipStream_t st) {
-    const bool tall = g_os_tall && os_lds_bytes(p.K, 9) <= 160 * 1024;
-    const size_t lds = os_lds_bytes(p.K, tall ? 9 : 8);
+    const bool shortt = os_lds_bytes(p.K, 8) > 160 * 1024;  // long K: tiles of 64 rows
+    const bool tall = !shortt && g_os_tall && os_lds_bytes(p.K, 9) <= 160 * 1024;
+    const size_t lds = os_lds_bytes(p.K, shortt ? 4 : tall ? 9 : 8);
     if (lds > 64 * 1024) {
         static bool raised[64] = {};  // per instantiation and device
         int device = 0;
@@ -331,7 +337,7 @@ static int launch_os(const GemmI8Args& p, const int8_t* Bf, int n_items, int par
     }
     int nwg = n_items < g_os_grid ? n_items : g_os_grid;
     if (nwg >= 8) nwg &= ~7;
-    hipLaunchKernelGGL((gemm_i8_os_kernel<EPI, DB, NW, WMAX>), dim3((unsigned)nwg), dim3(NW * 64), lds, st, p, Bf, parts, g_os_rotk, tall ? 1 : 0);
+    hipLaunchKernelGGL((gemm_i8_os_kernel<EPI, DB, NW, WMAX>), dim3((unsigned)nwg), dim3(NW * 64), lds, st, p, Bf, parts, g_os_rotk, shortt ? -1 : tall ? 1 : 0);
     I64H_CHECK_LAUNCH();
     return 0;
 }
@@ -340,7 +346,7 @@ extern "C" {
 
 // 1 if i64h_gemm_i8_frags takes the shape (int8 operand rows of K bytes against N weight rows, the given epilogue)
 int i64h_gemm_i8_frags_ok(int32_t N, int32_t K, int32_t epilogue) {
-    if (K <= 0 || N <= 0 || K % 64 != 0 || os_lds_bytes(K, 8) > 160 * 1024 || (int64_t)N * K >= (1ll << 31)) return 0;
+    if (K <= 0 || N <= 0 || K % 64 != 0 || os_lds_bytes(K, 4) > 160 * 1024 || (int64_t)N * K >= (1ll << 31)) return 0;
     return ((epilogue == EPI_SWIGLU || epilogue == EPI_STORE) && N % 32 == 0) ? 1 : 0;  // units of two fragment columns
 }
 
@@ -404,7 +410,8 @@ int i64h_gemm_i8_frags(const int8_t* A, const float* row_scale, const int8_t* B_
     p.col_scale = col_scale;
     p.stamps = g_os_stamps;
     const int G = group_offsets ? num_groups : 1;
-    const int m_tiles = (int)((M_total + OS_BM - 1) / OS_BM) + (group_offsets ? G : 0);  // upper bound
+    const int tile_rows = os_lds_bytes(K, 8) > 160 * 1024 ? 64 : OS_BM;
+    const int m_tiles = (int)((M_total + tile_rows - 1) / tile_rows) + (group_offsets ? G : 0);  // upper bound
     const int units = N / 32;
     // few row tiles: the columns of a tile are dealt to several workgroups (each loads the tile's rows itself)
     int parts = 1;
@@ -415,10 +422,11 @@ int i64h_gemm_i8_frags(const int8_t* A, const float* row_scale, const int8_t* B_
     }
     const int n_items = m_tiles * parts;
     hipStream_t st = (hipStream_t)stream;
-    // measured: the SwiGLU epilogue does best with 8 waves and blocks of 64 columns, the plain store with 12 waves and blocks of 32
+    // measured: the SwiGLU epilogue and the 64-row tiles of a long K do best with 8 waves and blocks of 64 columns, the plain store
+    // on 128-row tiles with 12 waves and blocks of 32
 #define OS_DISPATCH(EPI)                                                                                       \
     do {                                                                                                       \
-        const int waves = g_os_waves ? g_os_waves : (EPI == EPI_SWIGLU ? 8 : 12);                              \
+        const int waves = g_os_waves ? g_os_waves : ((EPI == EPI_SWIGLU || tile_rows == 64) ? 8 : 12);          \
         if (waves == 8) {                                                                                      \
             if (g_os_depth == 2) return launch_os<EPI, 2, 8, 2>(p, B_frags, n_items, parts, st);                \
             return launch_os<EPI, 3, 8, 2>(p, B_frags, n_items, parts, st);                                     \
