@@ -125,3 +125,39 @@ def test_fused_residual_norm_many_rows_equals_the_few_row_form(dev, H_, mode):
         ns.append(b)
     assert torch.equal(ho, torch.cat(hs)) and torch.equal(no, torch.cat(ns))
     assert torch.equal(ops.qparams(st_many, n_slots + 2)[2], ops.qparams(st_few, n_slots + 2)[2])
+
+
+@pytest.mark.parametrize("rows_,splits,kv_dtype,mode", [(700, 1, torch.bfloat16, 1), (700, 1, torch.float32, 1), (700, 1, torch.bfloat16, 0),
+                                                       (40, 1, torch.bfloat16, 1), (40, 4, torch.bfloat16, 1), (300, 3, torch.float32, 1)])
+def test_attention_folds_the_range_of_its_output_whichever_kernel_runs(dev, rows_, splits, kv_dtype, mode):
+    """stats != NULL: the o projection's slot receives min / max (with zero) of the output from the many-row kernels' epilogue, the
+    split merge, or a pass behind the unsplit row kernel - the same words a rows_minmax over the output leaves."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(rows_ + splits)
+    nh, kvh, hd, seq = 16, 4, 64, 5
+    per = (rows_ + seq - 1) // seq
+    nblk = seq * ((per + 15) // 16) + 1
+    kc = torch.randn(nblk, 16, kvh, hd, generator=g).to(kv_dtype).to(dev)
+    vc = (torch.randn(nblk, 16, kvh, hd, generator=g) * 2 + 0.3).to(kv_dtype).to(dev)
+    bt = torch.randperm(nblk - 1, generator=g).to(torch.int32).view(seq, -1).contiguous().to(dev)
+    slot = (torch.arange(rows_) // per).to(torch.int32).to(dev)
+    ctx = (torch.arange(rows_) % per + 1).to(torch.int32)
+    ctx[rows_ // 2] = 0  # a row that attends to nothing stores zeros
+    ctx = ctx.to(dev)
+    q = torch.randn(rows_, nh, hd, generator=g).to(dev)
+    st, st_ref = ops.stats_alloc(3, dev), ops.stats_alloc(3, dev)
+    ops.stats_reset(st)
+    ops.stats_reset(st_ref)
+    ops.call("i64h_set_prefill_attn", mode)
+    try:
+        out = ops.paged_attn(q, kc, vc, bt, ctx, slot_ids=slot, splits=splits, stats=st, stat_slot=1)
+        plain = ops.paged_attn(q, kc, vc, bt, ctx, slot_ids=slot, splits=splits)
+    finally:
+        ops.call("i64h_set_prefill_attn", 1)
+    assert torch.equal(out, plain)
+    ops.rows_minmax(out.view(rows_, nh * hd), st_ref, slot_base=1)
+    got, want = ops.qparams(st, 3), ops.qparams(st_ref, 3)
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+    lo = min(float(out.min()), 0.0)
+    hi = max(float(out.max()), 0.0)
+    assert hi > 0.5 and lo < 0.0  # the slot really saw the output, not just its reset value

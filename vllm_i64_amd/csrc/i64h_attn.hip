@@ -10,6 +10,7 @@
 // ctx_len[row] = number of keys the row may see (position + 1 for a causal decode/prefill row, cache_seqlens
 // for the operator form); 0 gives an all-zero output row, as the reference does for an empty sequence.
 #include "i64h_common.h"
+#include "../../include/i64h.h"
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 #include <math.h>
@@ -233,6 +234,14 @@ __global__ __launch_bounds__(256) void paged_attn_kernel(const float* __restrict
 // be assigned to (g, step) so that each lane reads contiguous 16-byte pieces of a token row.
 // Rows are (slot, ctx) pairs like everywhere else; a tile whose rows belong to several sequences is handled in one pass per
 // distinct sequence.  fp32 math throughout (the cache may be bf16 / fp16 / fp32).
+// minimum and maximum of everything a wave of a prefill workgroup stored, folded into a call's statistics slot (one pair of
+// atomics per wave; the shard is picked by workgroup and wave so that neighbours do not meet on one word)
+__device__ __forceinline__ void pf_fold_range(uint32_t* stats, int stat_slot, float lo, float hi) {
+    if (!stats) return;
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+    if ((threadIdx.x & 63) == 0) stat_update(stats, stat_slot, (int)((blockIdx.x * gridDim.y + blockIdx.y) * (blockDim.x >> 6) + (threadIdx.x >> 6)), lo, hi);
+}
 #define PF_TOK 64            // tokens per K/V tile
 #define PF_LDK 64            // LDS row stride in floats: unpadded, so that a V row read by 16 lanes covers all 64 banks once
 // K rows are read by fragments (lane = (token row c, dim group g)); no padding makes all four ds_read_b128 lane groups
@@ -243,7 +252,7 @@ __global__ __launch_bounds__(GS * 64) void paged_attn_prefill_kernel(const float
                                                                      const KV* __restrict__ v_cache, const int32_t* __restrict__ block_table,
                                                                      int max_blocks_per_seq, const int32_t* __restrict__ slot_ids,
                                                                      const int32_t* __restrict__ ctx_len, float scale, float* __restrict__ out,
-                                                                     int n, int kvh, int block) {
+                                                                     int n, int kvh, int block, uint32_t* __restrict__ stats, int stat_slot) {
     constexpr int HD = 64, NT = GS * 64, CPT = (PF_TOK * 8 + NT - 1) / NT;  // 8-element chunks per thread and tensor
     constexpr float LOG2E = 1.4426950408889634f;
     __shared__ __attribute__((aligned(16))) float Ks[PF_TOK][PF_LDK];
@@ -258,6 +267,7 @@ __global__ __launch_bounds__(GS * 64) void paged_attn_prefill_kernel(const float
     const int my_slot = valid ? (slot_ids ? slot_ids[r] : r) : -1;
     const int my_ctx = valid ? ctx_len[r] : 0;
     bool done = !valid;
+    float olo = 0.0f, ohi = 0.0f;  // range of the rows this lane stores (with zero, as the quantizer's range has it)
 
     // Q^T operand: dims 16g..16g+15 of query row c, pre-multiplied by scale * log2(e) (scores live in log2 units)
     float qv[16];
@@ -401,10 +411,13 @@ __global__ __launch_bounds__(GS * 64) void paged_attn_prefill_kernel(const float
                 float4 o = make_float4(0, 0, 0, 0);
                 if (lsum > 0.0f) o = make_float4(acc[0][e] / lsum, acc[1][e] / lsum, acc[2][e] / lsum, acc[3][e] / lsum);
                 *(float4*)(op + 4 * e) = o;
+                olo = fminf(olo, fminf(fminf(o.x, o.y), fminf(o.z, o.w)));
+                ohi = fmaxf(ohi, fmaxf(fmaxf(o.x, o.y), fmaxf(o.z, o.w)));
             }
             done = true;
         }
     }
+    pf_fold_range(stats, stat_slot, olo, ohi);
 }
 
 // ---- prefill form for bf16 and 8-bit float caches: the same tiling on the bf16 matrix cores, at fp32 accuracy -------------------------------
@@ -458,7 +471,8 @@ __global__ __launch_bounds__(GS * 64) void paged_attn_prefill_bf16_kernel(const 
                                                                           const KV* __restrict__ v_cache,
                                                                           const int32_t* __restrict__ block_table, int max_blocks_per_seq,
                                                                           const int32_t* __restrict__ slot_ids, const int32_t* __restrict__ ctx_len,
-                                                                          float scale, float* __restrict__ out, int n, int kvh, int block) {
+                                                                          float scale, float* __restrict__ out, int n, int kvh, int block,
+                                                                          uint32_t* __restrict__ stats, int stat_slot) {
     constexpr int HD = 64, NT = GS * 64, CPT = (PF_TOK * 8 + NT - 1) / NT;  // 16-byte chunks per thread and tensor
     constexpr float LOG2E = 1.4426950408889634f;
     __shared__ __attribute__((aligned(16))) unsigned short Kb[PF_TOK * 64];
@@ -472,6 +486,7 @@ __global__ __launch_bounds__(GS * 64) void paged_attn_prefill_bf16_kernel(const 
     const int my_slot = valid ? (slot_ids ? slot_ids[r] : r) : -1;
     const int my_ctx = valid ? ctx_len[r] : 0;
     bool done = !valid;
+    float olo = 0.0f, ohi = 0.0f;  // range of the rows this lane stores (with zero, as the quantizer's range has it)
     const int bshift = (block & (block - 1)) == 0 ? __builtin_ctz(block) : -1;  // power-of-two blocks (the reference's 16): no division
 
     // Q^T operand of depth step s: dims 32 s + 8 g .. + 7 of query row c, pre-multiplied by scale * log2(e), in three terms
@@ -637,10 +652,13 @@ __global__ __launch_bounds__(GS * 64) void paged_attn_prefill_bf16_kernel(const 
                 float4 o = make_float4(0, 0, 0, 0);
                 if (lsum > 0.0f) o = make_float4(acc[j][0] / lsum, acc[j][1] / lsum, acc[j][2] / lsum, acc[j][3] / lsum);
                 *(float4*)(op + 16 * j) = o;
+                olo = fminf(olo, fminf(fminf(o.x, o.y), fminf(o.z, o.w)));
+                ohi = fmaxf(ohi, fmaxf(fmaxf(o.x, o.y), fmaxf(o.z, o.w)));
             }
             done = true;
         }
     }
+    pf_fold_range(stats, stat_slot, olo, ohi);
 }
 
 // merge the splits of one query row (all heads) with one workgroup: one float4 of one head per thread and pass;
@@ -1057,7 +1075,6 @@ int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, in
                     float* workspace, int64_t rows, int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, int32_t block_size,
                     int32_t splits, uint32_t* stats, int32_t stat_slot, void* stream) {
     I64H_CHECK_ARG(rows >= 0 && rows < (1ll << 31), "paged_attn: bad row count");
-    I64H_CHECK_ARG(stats == nullptr || splits > 1, "paged_attn: output statistics are produced by the split merge (splits > 1)");
     I64H_CHECK_ARG(num_kv_heads > 0 && num_heads % num_kv_heads == 0, "paged_attn: heads %d not a multiple of kv heads %d", num_heads, num_kv_heads);
     I64H_CHECK_ARG(kv_dtype >= 0 && kv_dtype <= 4, "paged_attn: unknown kv dtype %d", kv_dtype);
     I64H_CHECK_ARG(splits >= 1 && splits <= 64, "paged_attn: splits=%d out of range", splits);
@@ -1075,10 +1092,10 @@ int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, in
         dim3 grid((unsigned)((rows + 15) / 16), (unsigned)num_kv_heads);
 #define PF(G, T)                                                                                                                     \
     hipLaunchKernelGGL((paged_attn_prefill_kernel<G, T>), grid, dim3(G * 64), 0, st, q, (const T*)k_cache, (const T*)v_cache, block_table, \
-                       (int)max_blocks_per_seq, slot_ids, ctx_len, softmax_scale, out, (int)rows, (int)num_kv_heads, (int)block_size)
+                       (int)max_blocks_per_seq, slot_ids, ctx_len, softmax_scale, out, (int)rows, (int)num_kv_heads, (int)block_size, stats, (int)stat_slot)
 #define PFB(G, T)                                                                                                                          \
     hipLaunchKernelGGL((paged_attn_prefill_bf16_kernel<G, T>), grid, dim3(G * 64), 0, st, q, (const T*)k_cache, (const T*)v_cache, block_table, \
-                       (int)max_blocks_per_seq, slot_ids, ctx_len, softmax_scale, out, (int)rows, (int)num_kv_heads, (int)block_size)
+                       (int)max_blocks_per_seq, slot_ids, ctx_len, softmax_scale, out, (int)rows, (int)num_kv_heads, (int)block_size, stats, (int)stat_slot)
 #define PFG(G)                                                  \
     do {                                                        \
         if (kv_dtype == 0) PF(G, float);                        \
@@ -1148,6 +1165,9 @@ int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, in
         hipLaunchKernelGGL(attn_merge_kernel, dim3((unsigned)rows), dim3(256), 0, st, part_o, part_ml, out, (int)num_heads, (int)head_dim,
                            (int)splits, stats, (int)stat_slot, done ? 1 : 0);
         I64H_CHECK_LAUNCH();
+    } else if (splits == 1 && stats) {
+        // the unsplit row-per-workgroup kernel has no merge to fold the range into: one pass over the rows it wrote
+        return i64h_rows_minmax(out, rows, num_heads * head_dim, nullptr, 0, stat_slot, stats, stream);
     }
     return 0;
 }

@@ -429,9 +429,7 @@ class I64MoEModel:
                                             B.q, cfg.num_heads, cfg.num_kv_heads, cfg.head_dim)
                 ops.paged_attn(B.q, kvc.k[l], kvc.v[l], kvc.block_table, ctx_len, slot_ids=None if rows_are_slots else slot_ids,
                                softmax_scale=1.0 / math.sqrt(cfg.head_dim), splits=splits, out=B.attn, workspace=B.attn_ws,
-                               stats=st if splits > 1 else None, stat_slot=base + 1)
-                if splits == 1:
-                    ops.rows_minmax(B.attn.view(n, H), st, slot_base=base + 1)
+                               stats=st, stat_slot=base + 1)
                 tails[l].run()  # o projection ... combine + next norm (+ the next layer's qkv projection, RoPE, cache write)
                 continue
             if inject is not None and l in inject:
@@ -452,12 +450,10 @@ class I64MoEModel:
                                     kvc.k[l], kvc.v[l], cfg.num_heads, cfg.num_kv_heads, cfg.head_dim, q_out=B.q)
             ops.paged_attn(B.q, kvc.k[l], kvc.v[l], kvc.block_table, ctx_len, slot_ids=None if rows_are_slots else slot_ids,
                            softmax_scale=1.0 / math.sqrt(cfg.head_dim), splits=splits, out=B.attn, workspace=B.attn_ws,
-                           stats=st if splits > 1 else None, stat_slot=base + 1)
+                           stats=st, stat_slot=base + 1)  # the range of the output is folded into the o projection's slot
             attn2d = B.attn.view(n, H)
             if record is not None:
                 record[f"l{l}.attn_out"] = attn2d.clone()
-            if splits == 1:
-                ops.rows_minmax(attn2d, st, slot_base=base + 1)
             # h += o_proj(attn) ; normed = ln2(h) ; statistics of the Linear call(s) that read normed
             ln2_base = base + 2
             if self.ep is not None:
