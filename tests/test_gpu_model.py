@@ -407,3 +407,35 @@ def test_engine_model_refuses_a_prefix_caching_cache(dev):
     cache.prefix_cache_enabled = lambda: True
     with pytest.raises(RuntimeError, match="copy-on-write"):
         EngineModel(model)(M.make_token_ids(ocfg, 3, seed=1), torch.arange(3), cache, [0], [3])
+
+
+@pytest.mark.parametrize("name", ["tiny-moe", "tiny-dense"])
+def test_prefill_with_norm_and_quantization_in_one_launch_gives_the_same_bits(dev, name):
+    """A prefill chunk of several hundred rows: the runner's one-launch residual + norm + quantization against its two-kernel
+    form - logits and KV cache bit for bit."""
+    from vllm_i64_amd.model import I64MoEModel
+    ocfg, w, model = _model(name, dev, max_seqs=4)
+    lens = [200, 130, 77]
+    n = sum(lens)
+    assert n > I64MoEModel.FUSE_MAX_ROWS
+    ids = M.make_token_ids(ocfg, n, seed=5).to(dev)
+    pos = torch.cat([torch.arange(t) for t in lens]).to(torch.int32).to(dev)
+    slots = torch.cat([torch.full((t,), s, dtype=torch.int32) for s, t in enumerate(lens)]).to(dev)
+    outs = []
+    for s in range(4):
+        model.kv.free(s)
+    for s, t in enumerate(lens):
+        model.kv.reserve(s, t)
+    for fused in (True, False):
+        for kc in model.kv.k + model.kv.v:
+            kc.zero_()
+        model.FUSE_NORM_QUANT = fused
+        try:
+            logits = model.forward(ids, pos, slots, (pos + 1).contiguous()).clone()
+        finally:
+            model.FUSE_NORM_QUANT = I64MoEModel.FUSE_NORM_QUANT
+        outs.append((logits, [k.clone() for k in model.kv.k], [v.clone() for v in model.kv.v], model.kv.block_table.clone()))
+    assert torch.equal(outs[0][3], outs[1][3])
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1] + outs[0][2], outs[1][1] + outs[1][2]):
+        assert torch.equal(a, b)

@@ -161,3 +161,56 @@ def test_attention_folds_the_range_of_its_output_whichever_kernel_runs(dev, rows
     lo = min(float(out.min()), 0.0)
     hi = max(float(out.max()), 0.0)
     assert hi > 0.5 and lo < 0.0  # the slot really saw the output, not just its reset value
+
+
+@pytest.mark.parametrize("mode,n,H", [("plain", 5003, 1024), ("add_gather", 5003, 1024), ("combine", 3001, 1024), ("add_gather", 16384, 1024),
+                                      ("add_gather", 2500, 512), ("plain", 77, 256)])
+def test_fused_residual_norm_quant_equals_norm_then_quantize(dev, mode, n, H):
+    """The one-launch residual + norm + per-call quantization (grid barrier between the ranges and the rows) against the two
+    kernels it replaces: same residual stream, same int8 rows and scales for the call over all rows and for every gathered
+    (route, expert) bucket call, same statistics words; twice in a row on the same sync words."""
+    ops = _ops()
+    if n > ops.fused_residual_norm_quant_rows():
+        pytest.skip("more rows than one resident grid takes on this device")
+    g = torch.Generator().manual_seed(n + H)
+    top_k, nb = 2, 16
+    h = torch.randn(n, H, generator=g).to(dev)
+    w = (torch.rand(H, generator=g) + 0.5).to(dev)
+    kw = {}
+    slots = inv = None
+    if mode in ("add_gather", "combine"):
+        bucket = torch.randint(0, nb, (top_k, n), generator=g)
+        slots = torch.cat([torch.zeros(n, 1, dtype=torch.int64), 1 + bucket.t()], dim=1).to(torch.int32).contiguous().to(dev)
+        order = torch.sort(bucket.reshape(-1), stable=True)[1]                # sorted row -> k * n + t
+        inv = torch.empty(top_k * n, dtype=torch.int64)
+        inv[order] = torch.arange(top_k * n)
+        inv = inv.to(torch.int32).to(dev)
+        perm = order.to(torch.int32).to(dev)
+        sorted_bucket = bucket.reshape(-1)[order].to(torch.int32).to(dev)
+    if mode == "add_gather":
+        kw["add"] = (torch.randn(n, H, generator=g) * 0.3).to(dev)
+    if mode == "combine":
+        kw.update(moe_rows=torch.randn(top_k * n, H, generator=g).to(dev), moe_inv=inv, moe_shared=torch.randn(n, H, generator=g).to(dev),
+                  route_weights=(0.6, 0.4), routed_scale=1.5, shared_scale=0.7)
+    n_slots = 2 + nb * top_k + 1
+    sync = ops.decode_sync_alloc(dev)
+    for rep in range(2):
+        st_a, st_b = ops.stats_alloc(n_slots, dev), ops.stats_alloc(n_slots, dev)
+        ops.stats_reset(st_a), ops.stats_reset(st_b)
+        ho, normed = ops.fused_residual_norm(h, w, 1e-6, slots=slots, slot_base=1, stats=st_a, **kw)
+        qa, qs = ops.quantize_dynamic(normed, st_a, slot_base=1)
+        q2 = torch.empty(n, H, dtype=torch.int8, device=dev)
+        s2 = torch.empty(n, dtype=torch.float32, device=dev)
+        gk = {}
+        if mode == "add_gather":
+            ga, gs = ops.quantize_dynamic(normed, st_a, slot_base=2, src_row=perm, src_mod=n, row_slot=sorted_bucket)
+            g2 = torch.empty(top_k * n, H, dtype=torch.int8, device=dev)
+            gs2 = torch.empty(top_k * n, dtype=torch.float32, device=dev)
+            gk = dict(gather_inv=inv, gather_k=top_k, g_rows=g2, g_scale=gs2)
+        ho2 = ops.fused_residual_norm_quant(h, w, 1e-6, st_b, sync, q2, s2, slots=slots, slot_base=1, **kw, **gk)
+        assert torch.equal(ho, ho2)
+        assert all(torch.equal(a, b) for a, b in zip(ops.qparams(st_a, n_slots), ops.qparams(st_b, n_slots)))
+        assert torch.equal(qs, s2) and torch.equal(qa, q2)
+        if mode == "add_gather":
+            assert torch.equal(gs, gs2) and torch.equal(ga, g2)
+        assert int(sync.abs().sum()) == 0   # the launch leaves its sync words zero (and its wait budget was not exceeded)

@@ -47,6 +47,7 @@ SIGNATURES: Dict[str, str] = {
     "i64h_embedding_stats_reset": "pppli" + "lplp",
     "i64h_rmsnorm": "ppplifp",
     "i64h_fused_residual_norm": "ppppppiffppfplipiipp",
+    "i64h_fused_residual_norm_quant": "ppppppiffppflipiippppipppp",
     "i64h_qk_norm_rope_kv": "pppfppppipppiliiiip",
     "i64h_rope": "ppppliip",
     "i64h_rope_q14": "ppppliip",
@@ -96,7 +97,7 @@ class I64HError(RuntimeError):
 
 def exported_symbols():
     return ["i64h_last_error", "i64h_version", "i64h_device_check", "i64h_bucketize_workspace_bytes",
-            "i64h_paged_attn_workspace_floats", "i64h_stats_words_per_slot", "i64h_moe_forward_workspace_bytes", "i64h_moe_forward_static_max_bytes", "i64h_decode_sync_words", "i64h_decode_tail_args_bytes", "i64h_debug_stamp_cursor", *SIGNATURES.keys()]
+            "i64h_paged_attn_workspace_floats", "i64h_stats_words_per_slot", "i64h_moe_forward_workspace_bytes", "i64h_moe_forward_static_max_bytes", "i64h_decode_sync_words", "i64h_decode_tail_args_bytes", "i64h_debug_stamp_cursor", "i64h_fused_residual_norm_quant_rows", *SIGNATURES.keys()]
 
 
 class GemmDesc(ctypes.Structure):
@@ -160,7 +161,7 @@ def load() -> ctypes.CDLL:
     lib.i64h_debug_stamp_cursor.restype = _L
     lib.i64h_debug_stamp_cursor.argtypes = []
     lib.i64h_moe_forward_static_max_bytes.restype = _L
-    for name in ("i64h_decode_sync_words", "i64h_decode_tail_args_bytes"):
+    for name in ("i64h_decode_sync_words", "i64h_decode_tail_args_bytes", "i64h_fused_residual_norm_quant_rows"):
         getattr(lib, name).restype = _L
         getattr(lib, name).argtypes = []
     lib.i64h_moe_forward_static_max_bytes.argtypes = []

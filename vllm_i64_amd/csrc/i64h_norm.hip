@@ -2,6 +2,7 @@
 // the min/max statistics the next quantized Linear needs), per-head QK-norm + rotate-half RoPE + paged-KV
 // write, RoPE (float and Q14), integer softmax (Q7, exp LUT) and the Q7 SiLU*up activation.
 #include "i64h_common.h"
+#include "i64h_gridsync.h"
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 
@@ -179,10 +180,117 @@ __global__ __launch_bounds__(256) void fused_residual_norm_kernel(const float* _
 // l + 64 v of the row, v = 0..3): the sum of squares is formed per v exactly as there (fma chain over the four components, the
 // wave butterfly) and the four results are added in that kernel's order, so every value of the row has the same bits.
 #define FRR_RPW 4
-__global__ __launch_bounds__(256) void fused_residual_norm_rows_kernel(const float* __restrict__ h, const float* __restrict__ add,
-                                                                       MoeCombine mc, int64_t n, float* __restrict__ h_out,
-                                                                       const float* __restrict__ w, float eps, float* __restrict__ normed,
-                                                                       int H, const int32_t* __restrict__ slots, int spr, int slot_base,
+struct FrrArgs {
+    const float* h;
+    const float* add;
+    MoeCombine mc;
+    int64_t n;
+    float* h_out;
+    float eps;
+    int H;
+};
+// One row in one wave: the residual update (stored to h_out), the normalised row in y (lane l: float4 l + 64 v of the row), its
+// range with zero in lo / hi (per lane: fold with wave_min / wave_max).
+template <typename GW>
+__device__ __forceinline__ void frr_row(const FrrArgs& p, const int64_t t, const int lane, const int nv, const GW& gw, const bool norm,
+                                        float4 (&y)[4], float& lo, float& hi) {
+    const MoeCombine& mc = p.mc;
+    const int H = p.H;
+    const int64_t n = p.n;
+    float ssv[4];
+    int64_t rrow[8];
+    if (mc.rows) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (k < mc.top_k) rrow[k] = mc.inv ? (int64_t)mc.inv[(int64_t)k * n + t] : (int64_t)k * n + t;
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int i = lane + 64 * v;
+        float4 x = make_float4(0, 0, 0, 0);
+        if (i < nv) {
+            if (p.h) x = ((const float4*)(p.h + t * H))[i];
+            if (p.add) {
+                const float4 b = ((const float4*)(p.add + t * H))[i];
+                x.x = x.x + b.x; x.y = x.y + b.y; x.z = x.z + b.z; x.w = x.w + b.w;
+            }
+            if (mc.rows) {
+                const float4 r0 = ((const float4*)(mc.rows + rrow[0] * H))[i];
+                float4 o = make_float4(mc.wk[0] * r0.x, mc.wk[0] * r0.y, mc.wk[0] * r0.z, mc.wk[0] * r0.w);
+#pragma unroll
+                for (int k = 1; k < 8; ++k) {
+                    if (k < mc.top_k) {
+                        const float4 rk = ((const float4*)(mc.rows + rrow[k] * H))[i];
+                        o.x = o.x + mc.wk[k] * rk.x; o.y = o.y + mc.wk[k] * rk.y;
+                        o.z = o.z + mc.wk[k] * rk.z; o.w = o.w + mc.wk[k] * rk.w;
+                    }
+                }
+                if (mc.shared) {
+                    const float4 sh = ((const float4*)(mc.shared + t * H))[i];
+                    o.x = mc.routed_scale * o.x + mc.shared_scale * sh.x; o.y = mc.routed_scale * o.y + mc.shared_scale * sh.y;
+                    o.z = mc.routed_scale * o.z + mc.shared_scale * sh.z; o.w = mc.routed_scale * o.w + mc.shared_scale * sh.w;
+                } else {
+                    o.x = mc.routed_scale * o.x; o.y = mc.routed_scale * o.y; o.z = mc.routed_scale * o.z; o.w = mc.routed_scale * o.w;
+                }
+                if (p.h || p.add) { x.x = x.x + o.x; x.y = x.y + o.y; x.z = x.z + o.z; x.w = x.w + o.w; }
+                else x = o;
+            }
+            if (p.h_out) ((float4*)(p.h_out + t * H))[i] = x;
+        }
+        y[v] = x;
+        float ss = 0.0f;
+        if (i < nv) {
+            ss = __builtin_fmaf(x.x, x.x, ss); ss = __builtin_fmaf(x.y, x.y, ss);
+            ss = __builtin_fmaf(x.z, x.z, ss); ss = __builtin_fmaf(x.w, x.w, ss);
+        }
+        ssv[v] = ss;
+    }
+    lo = 0.0f;
+    hi = 0.0f;
+    if (!norm) return;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) ssv[v] = wave_sum(ssv[v]);
+    const float rr = rsqrtf((ssv[0] + ssv[1] + ssv[2] + ssv[3]) / (float)H + p.eps);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int i = lane + 64 * v;
+        if (i < nv) {
+            const float4 g = gw(v);
+            float4 a = y[v];
+            a.x = a.x * rr * g.x; a.y = a.y * rr * g.y; a.z = a.z * rr * g.z; a.w = a.w * rr * g.w;
+            y[v] = a;
+            lo = fminf(lo, fminf(fminf(a.x, a.y), fminf(a.z, a.w)));
+            hi = fmaxf(hi, fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)));
+        }
+    }
+}
+// a row's range into the workgroup's table of relative slots (lanes < number of slots of the row)
+__device__ __forceinline__ void frr_fold(uint32_t* tab_lo, uint32_t* tab_hi, const int32_t* slots, int spr, int64_t t, int lane, float lo, float hi,
+                                         uint32_t* stats, int slot_base) {
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+    const int ns = slots ? spr : 1;
+    if (lane < ns) {
+        const int rel = slots ? slots[t * spr + lane] : 0;
+        if (rel >= 0 && rel < I64H_STAT_TAB) {
+            atomicMin(&tab_lo[rel], f32_to_ordered(lo));
+            atomicMax(&tab_hi[rel], f32_to_ordered(hi));
+        } else {
+            stat_update(stats, slot_base + rel, blockIdx.x, lo, hi);
+        }
+    }
+}
+__device__ __forceinline__ void frr_flush(const uint32_t* tab_lo, const uint32_t* tab_hi, uint32_t* stats, int slot_base) {
+    for (int i = threadIdx.x; i < I64H_STAT_TAB; i += blockDim.x)
+        if (tab_lo[i] != I64H_ORDERED_ZERO || tab_hi[i] != I64H_ORDERED_ZERO) {
+            uint32_t* q = stats + (int64_t)(slot_base + i) * I64H_SLOT_WORDS + 2 * (blockIdx.x & (I64H_NSHARD - 1));
+            atomicMin(q, tab_lo[i]);
+            atomicMax(q + 1, tab_hi[i]);
+        }
+}
+
+__global__ __launch_bounds__(256) void fused_residual_norm_rows_kernel(FrrArgs p, const float* __restrict__ w, float* __restrict__ normed,
+                                                                       const int32_t* __restrict__ slots, int spr, int slot_base,
                                                                        uint32_t* __restrict__ stats) {
     __shared__ uint32_t tab_lo[I64H_STAT_TAB], tab_hi[I64H_STAT_TAB];
     if (stats) {
@@ -190,7 +298,7 @@ __global__ __launch_bounds__(256) void fused_residual_norm_rows_kernel(const flo
         __syncthreads();
     }
     const int lane = threadIdx.x & 63;
-    const int nv = H / 4;  // <= 256 (launcher)
+    const int nv = p.H / 4;  // <= 256 (launcher)
     const int64_t t0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * FRR_RPW;
     float4 gw[4];
 #pragma unroll
@@ -198,96 +306,115 @@ __global__ __launch_bounds__(256) void fused_residual_norm_rows_kernel(const flo
         const int i = lane + 64 * v;
         gw[v] = (normed && i < nv) ? ((const float4*)w)[i] : make_float4(0, 0, 0, 0);
     }
-    for (int64_t t = t0; t < t0 + FRR_RPW && t < n; ++t) {
-        float4 a[4];
-        float ssv[4];
-        int64_t rrow[8];
-        if (mc.rows) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if (k < mc.top_k) rrow[k] = mc.inv ? (int64_t)mc.inv[(int64_t)k * n + t] : (int64_t)k * n + t;
-        }
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const int i = lane + 64 * v;
-            float4 x = make_float4(0, 0, 0, 0);
-            if (i < nv) {
-                if (h) x = ((const float4*)(h + t * H))[i];
-                if (add) {
-                    const float4 b = ((const float4*)(add + t * H))[i];
-                    x.x = x.x + b.x; x.y = x.y + b.y; x.z = x.z + b.z; x.w = x.w + b.w;
-                }
-                if (mc.rows) {
-                    const float4 r0 = ((const float4*)(mc.rows + rrow[0] * H))[i];
-                    float4 o = make_float4(mc.wk[0] * r0.x, mc.wk[0] * r0.y, mc.wk[0] * r0.z, mc.wk[0] * r0.w);
-#pragma unroll
-                    for (int k = 1; k < 8; ++k) {
-                        if (k < mc.top_k) {
-                            const float4 rk = ((const float4*)(mc.rows + rrow[k] * H))[i];
-                            o.x = o.x + mc.wk[k] * rk.x; o.y = o.y + mc.wk[k] * rk.y;
-                            o.z = o.z + mc.wk[k] * rk.z; o.w = o.w + mc.wk[k] * rk.w;
-                        }
-                    }
-                    if (mc.shared) {
-                        const float4 sh = ((const float4*)(mc.shared + t * H))[i];
-                        o.x = mc.routed_scale * o.x + mc.shared_scale * sh.x; o.y = mc.routed_scale * o.y + mc.shared_scale * sh.y;
-                        o.z = mc.routed_scale * o.z + mc.shared_scale * sh.z; o.w = mc.routed_scale * o.w + mc.shared_scale * sh.w;
-                    } else {
-                        o.x = mc.routed_scale * o.x; o.y = mc.routed_scale * o.y; o.z = mc.routed_scale * o.z; o.w = mc.routed_scale * o.w;
-                    }
-                    if (h || add) { x.x = x.x + o.x; x.y = x.y + o.y; x.z = x.z + o.z; x.w = x.w + o.w; }
-                    else x = o;
-                }
-                if (h_out) ((float4*)(h_out + t * H))[i] = x;
-            }
-            a[v] = x;
-            float ss = 0.0f;
-            if (i < nv) {
-                ss = __builtin_fmaf(x.x, x.x, ss); ss = __builtin_fmaf(x.y, x.y, ss);
-                ss = __builtin_fmaf(x.z, x.z, ss); ss = __builtin_fmaf(x.w, x.w, ss);
-            }
-            ssv[v] = ss;
-        }
+    for (int64_t t = t0; t < t0 + FRR_RPW && t < p.n; ++t) {
+        float4 y[4];
+        float lo, hi;
+        frr_row(p, t, lane, nv, [&](int v) { return gw[v]; }, normed != nullptr, y, lo, hi);
         if (!normed) continue;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) ssv[v] = wave_sum(ssv[v]);
-        const float rr = rsqrtf((ssv[0] + ssv[1] + ssv[2] + ssv[3]) / (float)H + eps);
-        float lo = 0.0f, hi = 0.0f;
-#pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int i = lane + 64 * v;
-            if (i < nv) {
-                const float4 g = gw[v];
-                float4 y = a[v];
-                y.x = y.x * rr * g.x; y.y = y.y * rr * g.y; y.z = y.z * rr * g.z; y.w = y.w * rr * g.w;
-                ((float4*)(normed + t * H))[i] = y;
-                lo = fminf(lo, fminf(fminf(y.x, y.y), fminf(y.z, y.w)));
-                hi = fmaxf(hi, fmaxf(fmaxf(y.x, y.y), fmaxf(y.z, y.w)));
-            }
+            if (i < nv) ((float4*)(normed + t * p.H))[i] = y[v];
         }
-        if (!stats) continue;
-        lo = wave_min(lo);
-        hi = wave_max(hi);
-        const int ns = slots ? spr : 1;
-        if (lane < ns) {
-            const int rel = slots ? slots[t * spr + lane] : 0;
-            if (rel >= 0 && rel < I64H_STAT_TAB) {
-                atomicMin(&tab_lo[rel], f32_to_ordered(lo));
-                atomicMax(&tab_hi[rel], f32_to_ordered(hi));
-            } else {
-                stat_update(stats, slot_base + rel, blockIdx.x, lo, hi);
-            }
-        }
+        if (stats) frr_fold(tab_lo, tab_hi, slots, spr, t, lane, lo, hi, stats, slot_base);
     }
     if (stats && normed) {
         __syncthreads();
-        for (int i = threadIdx.x; i < I64H_STAT_TAB; i += 256)
-            if (tab_lo[i] != I64H_ORDERED_ZERO || tab_hi[i] != I64H_ORDERED_ZERO) {
-                uint32_t* q = stats + (int64_t)(slot_base + i) * I64H_SLOT_WORDS + 2 * (blockIdx.x & (I64H_NSHARD - 1));
-                atomicMin(q, tab_lo[i]);
-                atomicMax(q + 1, tab_hi[i]);
-            }
+        frr_flush(tab_lo, tab_hi, stats, slot_base);
     }
+}
+
+// Residual update + RMSNorm + the per-call quantization of the Linear calls that read the normalised rows, in ONE launch: the
+// normalised rows never go to memory as fp32.  A quantized Linear call needs the range of its WHOLE input (one range per
+// call, vllm_i64/core/loader.py:57-76), so the launch has two phases around a grid barrier: every workgroup (16 waves x
+// FRR_RPW rows, all workgroups resident at once) normalises its 64 rows into registers and folds their ranges into the calls'
+// slots; behind the barrier every wave derives the parameters of its rows' slots from the now complete statistics and stores
+// the signed int8 rows and their scales:
+//   plain call      qa[t], qs[t]                      slot = slot_base + slots[t][0]         (slots == NULL: slot_base)
+//   gathered calls  ga[g_inv[k n + t]], gs[...]       slot = slot_base + slots[t][1 + k]     (k < g_k routes; ga == NULL: none)
+// The arithmetic is that of fused_residual_norm_rows_kernel followed by quantize_dynamic_rows_kernel (same expressions, same
+// order; min / max are order-free), so the bytes are the same.
+#define FRQ_WAVES 16
+__device__ __forceinline__ QParams frq_params(const uint32_t* stats, int slot, int lane) {
+    // lane l reads word l of the slot's 64 (device-coherent: other workgroups' atomics of this launch); words alternate (min, max)
+    const uint32_t wd = __hip_atomic_load(stats + (int64_t)slot * I64H_SLOT_WORDS + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t mn = (lane & 1) ? 0xffffffffu : wd, mx = (lane & 1) ? wd : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
+        mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+    }
+    return choose_qparams_u7(ordered_to_f32(mn), ordered_to_f32(mx));
+}
+__global__ __launch_bounds__(FRQ_WAVES * 64) void fused_residual_norm_quant_kernel(FrrArgs p, const float* __restrict__ w,
+                                                                                    const int32_t* __restrict__ slots, int spr, int slot_base,
+                                                                                    uint32_t* __restrict__ stats, int8_t* __restrict__ qa,
+                                                                                    float* __restrict__ qs, const int32_t* __restrict__ g_inv,
+                                                                                    int g_k, int8_t* __restrict__ ga, float* __restrict__ gs,
+                                                                                    uint32_t* sync) {
+    __shared__ uint32_t tab_lo[I64H_STAT_TAB], tab_hi[I64H_STAT_TAB];
+    for (int i = threadIdx.x; i < I64H_STAT_TAB; i += FRQ_WAVES * 64) { tab_lo[i] = I64H_ORDERED_ZERO; tab_hi[i] = I64H_ORDERED_ZERO; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int nv = p.H / 4;
+    const int H = p.H;
+    const int64_t t0 = ((int64_t)blockIdx.x * FRQ_WAVES + (threadIdx.x >> 6)) * FRR_RPW;
+    __shared__ float4 s_w[256];  // the norm weights stay in LDS: the registers hold the rows
+    for (int i = threadIdx.x; i < 256; i += FRQ_WAVES * 64) s_w[i] = i < nv ? ((const float4*)w)[i] : make_float4(0, 0, 0, 0);
+    __syncthreads();
+    float4 y[FRR_RPW][4];
+#pragma unroll
+    for (int r = 0; r < FRR_RPW; ++r) {
+        const int64_t t = t0 + r;
+        if (t < p.n) {
+            float lo, hi;
+            frr_row(p, t, lane, nv, [&](int v) { return s_w[lane + 64 * v]; }, true, y[r], lo, hi);
+            frr_fold(tab_lo, tab_hi, slots, spr, t, lane, lo, hi, stats, slot_base);
+        }
+    }
+    __syncthreads();
+    frr_flush(tab_lo, tab_hi, stats, slot_base);
+    drain();  // this wave's atomics and h_out stores have left the CU before the workgroup's arrival is counted
+    GridSync gsy;
+    gsy.w = sync;
+    gsy.nwg = gridDim.x;
+    gsy.epoch = 0;
+    grid_barrier(gsy);
+    int prev_slot = -1;
+    QParams q;
+    q.scale = 0.0f; q.inv_scale = 0.0f; q.zp = 0;
+#pragma unroll
+    for (int r = 0; r < FRR_RPW; ++r) {
+        const int64_t t = t0 + r;
+        if (t >= p.n) break;
+        const int slot = slot_base + (slots ? slots[t * spr] : 0);
+        if (slot != prev_slot) {  // wave-uniform
+            q = frq_params(stats, slot, lane);
+            prev_slot = slot;
+        }
+        if (lane == 0) qs[t] = q.scale;
+        uint32_t* ar = (uint32_t*)(qa + t * H);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int i = lane + 64 * v;
+            if (i < nv) ar[i] = quantize4_u7_signed(y[r][v], q);
+        }
+        if (ga) {
+            for (int k = 0; k < g_k; ++k) {
+                const int gslot = slot_base + slots[t * spr + 1 + k];
+                const int64_t dst = g_inv[(int64_t)k * p.n + t];
+                const QParams gq = frq_params(stats, gslot, lane);
+                if (lane == 0) gs[dst] = gq.scale;
+                uint32_t* gr = (uint32_t*)(ga + dst * H);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int i = lane + 64 * v;
+                    if (i < nv) gr[i] = quantize4_u7_signed(y[r][v], gq);
+                }
+            }
+        }
+    }
+    grid_exit(gsy);
 }
 
 // ---- per-head QK RMSNorm + rotate-half RoPE + paged KV write ----------------------------------------------
@@ -633,14 +760,55 @@ int i64h_fused_residual_norm(const float* h, const float* add, const float* moe_
                         (uintptr_t)norm_weight) % 16) == 0;
     if (n > 2048 && H <= 1024 && slots_per_row <= 64 && al16) {  // many rows: a wave per FRR_RPW rows (same bits)
         const int64_t waves = (n + FRR_RPW - 1) / FRR_RPW;
-        hipLaunchKernelGGL(fused_residual_norm_rows_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, h, add, mc, n,
-                           h_out, norm_weight, eps, normed, (int)H, slots, (int)slots_per_row, (int)slot_base, stats);
+        FrrArgs fa;
+        fa.h = h; fa.add = add; fa.mc = mc; fa.n = n; fa.h_out = h_out; fa.eps = eps; fa.H = (int)H;
+        hipLaunchKernelGGL(fused_residual_norm_rows_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, fa, norm_weight,
+                           normed, slots, (int)slots_per_row, (int)slot_base, stats);
         I64H_CHECK_LAUNCH();
         return 0;
     }
     const int rpb = n > 2048 ? 8 : 1;  // many rows: fold 8 rows per workgroup before touching the global stat slots
     hipLaunchKernelGGL(fused_residual_norm_kernel, dim3((unsigned)i64h_cdiv(n, rpb)), dim3(256), 0, (hipStream_t)stream, h, add, mc,
                        (int)n, rpb, h_out, norm_weight, eps, normed, (int)H, slots, (int)slots_per_row, (int)slot_base, stats);
+    I64H_CHECK_LAUNCH();
+    return 0;
+}
+
+// rows one launch of the fused residual + norm + quantize kernel takes on this device: 64 per workgroup, one workgroup per CU
+int64_t i64h_fused_residual_norm_quant_rows(void) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (cus > DEC_MAX_WGS) cus = DEC_MAX_WGS;
+    return (int64_t)cus * FRQ_WAVES * FRR_RPW;
+}
+
+int i64h_fused_residual_norm_quant(const float* h, const float* add, const float* moe_rows, const int32_t* moe_inv, const float* moe_shared,
+                                   const float* route_weights, int32_t top_k, float routed_scale, float shared_scale, float* h_out,
+                                   const float* norm_weight, float eps, int64_t n, int32_t H, const int32_t* slots, int32_t slots_per_row,
+                                   int32_t slot_base, uint32_t* stats, int8_t* q_rows, float* q_scale, const int32_t* gather_inv,
+                                   int32_t gather_k, int8_t* g_rows, float* g_scale, uint32_t* sync, void* stream) {
+    I64H_CHECK_ARG(n >= 0 && H > 0 && H % 4 == 0 && H <= 1024, "fused_residual_norm_quant: H=%d unsupported (multiple of 4, <= 1024)", H);
+    I64H_CHECK_ARG(n <= i64h_fused_residual_norm_quant_rows(), "fused_residual_norm_quant: %lld rows exceed one resident grid (%lld)", (long long)n,
+                   (long long)i64h_fused_residual_norm_quant_rows());
+    I64H_CHECK_ARG(top_k >= 0 && top_k <= 8, "fused_residual_norm_quant: top_k=%d unsupported", top_k);
+    I64H_CHECK_ARG(moe_rows == nullptr || (route_weights != nullptr && top_k > 0), "fused_residual_norm_quant: moe args");
+    I64H_CHECK_ARG(norm_weight && stats && q_rows && q_scale && sync, "fused_residual_norm_quant: null norm weight, stats, output or sync words");
+    I64H_CHECK_ARG(slots == nullptr || (slots_per_row >= 1 && slots_per_row <= 64), "fused_residual_norm_quant: slots_per_row=%d", slots_per_row);
+    I64H_CHECK_ARG(g_rows == nullptr || (gather_inv && g_scale && slots && gather_k >= 1 && gather_k + 1 <= slots_per_row),
+                   "fused_residual_norm_quant: gathered output needs the inverse map, scales and 1 + gather_k slots per row");
+    I64H_CHECK_ARG((((uintptr_t)h | (uintptr_t)add | (uintptr_t)moe_rows | (uintptr_t)moe_shared | (uintptr_t)h_out | (uintptr_t)norm_weight) % 16) == 0 &&
+                       (((uintptr_t)q_rows | (uintptr_t)g_rows) % 4) == 0,
+                   "fused_residual_norm_quant: operands must be 16-byte aligned");
+    if (n == 0) return 0;
+    FrrArgs fa;
+    fa.h = h; fa.add = add; fa.n = n; fa.h_out = h_out; fa.eps = eps; fa.H = (int)H;
+    fa.mc.rows = moe_rows; fa.mc.inv = moe_inv; fa.mc.shared = moe_shared; fa.mc.top_k = top_k;
+    for (int k = 0; k < 8; ++k) fa.mc.wk[k] = (moe_rows && k < top_k) ? route_weights[k] : 0.0f;
+    fa.mc.routed_scale = routed_scale; fa.mc.shared_scale = shared_scale;
+    const int rows_per_wg = FRQ_WAVES * FRR_RPW;
+    hipLaunchKernelGGL(fused_residual_norm_quant_kernel, dim3((unsigned)((n + rows_per_wg - 1) / rows_per_wg)), dim3(FRQ_WAVES * 64), 0,
+                       (hipStream_t)stream, fa, norm_weight, slots, (int)slots_per_row, (int)slot_base, stats, q_rows, q_scale, gather_inv,
+                       (int)gather_k, g_rows, g_scale, sync);
     I64H_CHECK_LAUNCH();
     return 0;
 }

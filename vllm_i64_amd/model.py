@@ -262,6 +262,13 @@ class I64MoEModel:
             self._bufs[key] = _Buffers(self.cfg, n, n_logit_rows, self.device, ep_world=self.ep.world if self.ep is not None else 0)
         return self._bufs[key]
 
+    FUSE_NORM_QUANT = os.environ.get("I64H_FUSE_NORM_QUANT", "1") != "0"  # prefill chunks: residual + norm + quantization in one launch
+
+    def _fq_rows(self) -> int:
+        if not hasattr(self, "_fq_rows_cached"):
+            self._fq_rows_cached = ops.fused_residual_norm_quant_rows()
+        return self._fq_rows_cached
+
     FUSE_MAX_ROWS = 256  # up to this many operand rows the quantizer runs inside the GEMM (one launch per Linear call)
     EP_FUSE_MAX_ROWS = 1024  # the same for the pooled expert rows of the expert-parallel runner (8 ranks x 64 sequences x top-2)
     fuse_qkr = True   # decode-sized steps: QK norm / RoPE / cache write inside the qkv GEMM
@@ -416,7 +423,14 @@ class I64MoEModel:
         if splits > 1 and (B.attn_ws is None or B.attn_splits != splits):
             B.attn_ws = ops.attn_workspace(n, cfg.num_heads, cfg.head_dim, splits, self.device)
             B.attn_splits = splits
-        ops.fused_residual_norm(B.h, self.layers[0]["ln1"], eps, h_out=B.h, normed=B.normed, slot_base=0, stats=st)
+        # prefill-sized chunks that fit one resident grid: residual + norm + the quantization of the calls that read the normalised
+        # rows are one launch (the fp32 normalised rows are never stored); record / inject / expert-parallel runs keep the two-kernel form
+        fq = (self.FUSE_NORM_QUANT and n > self.FUSE_MAX_ROWS and n <= self._fq_rows() and record is None and inject is None
+              and self.ep is None and H <= 1024 and H % 4 == 0)
+        if fq:
+            ops.fused_residual_norm_quant(B.h, self.layers[0]["ln1"], eps, st, self.dec_sync, B.xa, B.xs, h_out=B.h, slot_base=0)
+        else:
+            ops.fused_residual_norm(B.h, self.layers[0]["ln1"], eps, h_out=B.h, normed=B.normed, slot_base=0, stats=st)
         tails = None
         if fuse_rows and record is None and inject is None and self._tail_supported(n):
             tails = self._tails(B, kvc, positions, slot_ids)
@@ -445,7 +459,10 @@ class I64MoEModel:
                                         W["q_norm"], W["k_norm"], 1e-6, self.rope, positions, slot_ids, kvc.block_table, kvc.k[l], kvc.v[l],
                                         B.q, cfg.num_heads, cfg.num_kv_heads, cfg.head_dim)
             else:
-                self._linear(B.normed, W["qkv"], base + 0, B.xa, B.xs, B.qkv)
+                if fq:
+                    self._gemm_i8(B.xa, B.xs, W["qkv"], B.qkv)
+                else:
+                    self._linear(B.normed, W["qkv"], base + 0, B.xa, B.xs, B.qkv)
                 ops.qk_norm_rope_kv(B.qkv, W["q_norm"], W["k_norm"], 1e-6, self.rope, positions, slot_ids, kvc.block_table,
                                     kvc.k[l], kvc.v[l], cfg.num_heads, cfg.num_kv_heads, cfg.head_dim, q_out=B.q)
             ops.paged_attn(B.q, kvc.k[l], kvc.v[l], kvc.block_table, ctx_len, slot_ids=None if rows_are_slots else slot_ids,
@@ -465,32 +482,47 @@ class I64MoEModel:
             # (folding this residual + norm into the o projection through a last-arriving workgroup per row block was built and
             # measured: the tail's device-coherent round trip costs more than the kernel boundary it removes)
             self._linear(attn2d, W["o"], base + 1, B.xa, B.xs, B.o)
-            ops.fused_residual_norm(B.h, W["ln2"], eps, add=B.o, h_out=B.h, normed=B.normed, slots=ln2_slots, slot_base=ln2_base,
-                                    stats=ln2_stats)
+            if fq:
+                gk = {}
+                if cfg.is_moe and B.plan.rows > 0:  # the (route, expert) bucket calls' rows, gathered into bucket order
+                    gk = dict(gather_inv=B.plan.inv[l], gather_k=cfg.top_k, g_rows=B.ea, g_scale=B.es)
+                ops.fused_residual_norm_quant(B.h, W["ln2"], eps, st, self.dec_sync, B.xa, B.xs, add=B.o, h_out=B.h, slots=ln2_slots,
+                                              slot_base=ln2_base, **gk)
+            else:
+                ops.fused_residual_norm(B.h, W["ln2"], eps, add=B.o, h_out=B.h, normed=B.normed, slots=ln2_slots, slot_base=ln2_base,
+                                        stats=ln2_stats)
             if cfg.is_moe:
                 if record is not None:
                     record[f"l{l}.mlp_in"] = B.normed.clone()
                 if self.ep is not None:
                     moe_rows, moe_inv = self._moe_ep(B, W, l, base)
                 else:
-                    moe_rows, moe_inv = B.e_out, self._moe(B, W, l, base)
+                    moe_rows, moe_inv = B.e_out, self._moe(B, W, l, base, prequantized=fq)
                 nxt = self.layers[l + 1]["ln1"] if l + 1 < cfg.num_layers else self.final_norm
                 last = l + 1 == cfg.num_layers
-                ops.fused_residual_norm(B.h, nxt, eps, moe_rows=moe_rows, moe_inv=moe_inv,
-                                        moe_shared=B.sh_out if cfg.shared_intermediate_size else None, route_weights=rw,
-                                        routed_scale=W["routed_scale"], shared_scale=W["shared_scale"], h_out=B.h, normed=B.normed,
-                                        slot_base=base + spl, stats=None if last else st)
+                mk = dict(moe_rows=moe_rows, moe_inv=moe_inv, moe_shared=B.sh_out if cfg.shared_intermediate_size else None, route_weights=rw,
+                          routed_scale=W["routed_scale"], shared_scale=W["shared_scale"], h_out=B.h, slot_base=base + spl)
+                if fq and not last:
+                    ops.fused_residual_norm_quant(B.h, nxt, eps, st, self.dec_sync, B.xa, B.xs, **mk)
+                else:
+                    ops.fused_residual_norm(B.h, nxt, eps, normed=B.normed, stats=None if last else st, **mk)
                 if record is not None:
                     record[f"l{l}.out"] = B.h.clone()
             else:
                 if record is not None:
                     record[f"l{l}.mlp_in"] = B.normed.clone()
-                self._linear(B.normed, W["gu"], base + 2, B.xa, B.xs, B.d_inter, epilogue=ops.EPI_SWIGLU, stats_slot=base + 3)
+                if fq:
+                    self._gemm_i8(B.xa, B.xs, W["gu"], B.d_inter, epilogue=ops.EPI_SWIGLU, slot_base=base + 3, stats=st)
+                else:
+                    self._linear(B.normed, W["gu"], base + 2, B.xa, B.xs, B.d_inter, epilogue=ops.EPI_SWIGLU, stats_slot=base + 3)
                 self._linear(B.d_inter, W["dn"], base + 3, B.da, B.ds, B.d_out)
                 nxt = self.layers[l + 1]["ln1"] if l + 1 < cfg.num_layers else self.final_norm
                 last = l + 1 == cfg.num_layers
-                ops.fused_residual_norm(B.h, nxt, eps, add=B.d_out, h_out=B.h, normed=B.normed, slot_base=base + spl,
-                                        stats=None if last else st)
+                if fq and not last:
+                    ops.fused_residual_norm_quant(B.h, nxt, eps, st, self.dec_sync, B.xa, B.xs, add=B.d_out, h_out=B.h, slot_base=base + spl)
+                else:
+                    ops.fused_residual_norm(B.h, nxt, eps, add=B.d_out, h_out=B.h, normed=B.normed, slot_base=base + spl,
+                                            stats=None if last else st)
                 if record is not None:
                     record[f"l{l}.out"] = B.h.clone()
         ops.call("i64h_gemm_f32", ops.ptr(B.normed), ops.ptr(logit_rows), ops.ptr(self.embed), ops.ptr(B.logits), B.logits.shape[0],
@@ -591,10 +623,11 @@ class I64MoEModel:
                  cfg.vocab_size, H, ops._stream())
         return B.logits
 
-    def _moe(self, B: _Buffers, W: dict, l: int, base: int):
+    def _moe(self, B: _Buffers, W: dict, l: int, base: int, prequantized: bool = False):
         """Routed experts (grouped by expert, rows in bucket order) + shared expert; outputs stay in B.e_out / B.sh_out and
         are combined by the next fused_residual_norm (token_routed_mlp.py:154-187).  Returns the inverse map the combine has to
-        read B.e_out through (None: the rows already lie in (route, token) order)."""
+        read B.e_out through (None: the rows already lie in (route, token) order).  prequantized: the norm in front already left
+        the shared call's rows in B.xa / B.xs and the bucket calls' rows in B.ea / B.es."""
         cfg, st, nbk = self.cfg, self.stats, self.nb
         plan = B.plan
         n, R = plan.n, plan.rows
@@ -621,13 +654,17 @@ class I64MoEModel:
             ops.gemm_i8_pair(e_dn, s_dn)
             return None
         if shared:
-            self._linear(B.normed, W["sh_gu"], base + 2, B.xa, B.xs, B.sh_inter, epilogue=ops.EPI_SWIGLU, stats_slot=base + 3 + nbk)
+            if prequantized:
+                self._gemm_i8(B.xa, B.xs, W["sh_gu"], B.sh_inter, epilogue=ops.EPI_SWIGLU, slot_base=base + 3 + nbk, stats=st)
+            else:
+                self._linear(B.normed, W["sh_gu"], base + 2, B.xa, B.xs, B.sh_inter, epilogue=ops.EPI_SWIGLU, stats_slot=base + 3 + nbk)
             self._linear(B.sh_inter, W["sh_dn"], base + 3 + nbk, B.sha, B.shs, B.sh_out)
         if R == 0:
             return plan.inv[l]
         # every (route, expert) bucket is its own Linear call: rows gathered in bucket order, bucket statistics
-        ops.call("i64h_quantize_dynamic", ops.ptr(B.normed), R, cfg.hidden_size, ops.ptr(plan.perm[l]), n, ops.ptr(plan.sorted_bucket[l]),
-                 base + 3, ops.ptr(st), ops.ptr(B.ea), ops.ptr(B.es), 0, ops._stream())
+        if not prequantized:
+            ops.call("i64h_quantize_dynamic", ops.ptr(B.normed), R, cfg.hidden_size, ops.ptr(plan.perm[l]), n, ops.ptr(plan.sorted_bucket[l]),
+                     base + 3, ops.ptr(st), ops.ptr(B.ea), ops.ptr(B.es), 0, ops._stream())
         self._gemm_i8(B.ea[:R], B.es[:R], W["exp_gu"], B.e_inter, group_offsets=plan.expert_offsets[l], epilogue=ops.EPI_SWIGLU,
                       row_slot=plan.sorted_bucket[l], slot_base=base + 4 + nbk, stats=st)
         ops.call("i64h_quantize_dynamic", ops.ptr(B.e_inter), R, cfg.expert_inter, 0, 0, ops.ptr(plan.sorted_bucket[l]), base + 4 + nbk,

@@ -428,6 +428,32 @@ def fused_residual_norm(h: torch.Tensor, norm_weight: Optional[torch.Tensor], ep
     return h_out, normed
 
 
+def fused_residual_norm_quant_rows() -> int:
+    """Rows one launch of fused_residual_norm_quant takes on this device."""
+    return int(_lib.load().i64h_fused_residual_norm_quant_rows())
+
+
+def fused_residual_norm_quant(h: torch.Tensor, norm_weight: torch.Tensor, eps: float, stats: torch.Tensor, sync: torch.Tensor,
+                              q_rows: torch.Tensor, q_scale: torch.Tensor, add: Optional[torch.Tensor] = None,
+                              moe_rows: Optional[torch.Tensor] = None, moe_inv: Optional[torch.Tensor] = None,
+                              moe_shared: Optional[torch.Tensor] = None, route_weights: Sequence[float] = (), routed_scale: float = 1.0,
+                              shared_scale: float = 1.0, h_out: Optional[torch.Tensor] = None, slots: Optional[torch.Tensor] = None,
+                              slot_base: int = 0, gather_inv: Optional[torch.Tensor] = None, gather_k: int = 0,
+                              g_rows: Optional[torch.Tensor] = None, g_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fused_residual_norm + quantize_dynamic of every Linear call that reads the normalised rows, in one launch (the
+    normalised rows themselves are not stored).  Returns h_out."""
+    _chk(h, torch.float32, "h"), _chk(q_rows, torch.int8, "q_rows"), _chk(q_scale, torch.float32, "q_scale")
+    n, H = h.shape
+    if h_out is None:
+        h_out = torch.empty_like(h)
+    rw = (ctypes.c_float * 8)(*([float(w) for w in route_weights] + [0.0] * (8 - len(route_weights))))
+    spr = 1 if slots is None else (slots.shape[1] if slots.dim() == 2 else 1)
+    call("i64h_fused_residual_norm_quant", ptr(h), ptr(add), ptr(moe_rows), ptr(moe_inv), ptr(moe_shared), ctypes.addressof(rw),
+         len(route_weights), float(routed_scale), float(shared_scale), ptr(h_out), ptr(norm_weight), float(eps), n, H, ptr(slots), spr,
+         slot_base, ptr(stats), ptr(q_rows), ptr(q_scale), ptr(gather_inv), gather_k, ptr(g_rows), ptr(g_scale), ptr(sync), _stream())
+    return h_out
+
+
 def qk_norm_rope_kv(qkv, q_norm_w, k_norm_w, qk_eps, rope_tab, positions, slot_ids, block_table, k_cache, v_cache,
                     num_heads: int, num_kv_heads: int, head_dim: int, q_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk(qkv, torch.float32, "qkv"), _chk(positions, torch.int32, "positions"), _chk(slot_ids, torch.int32, "slot_ids")
