@@ -3,7 +3,7 @@
               the single-process statement exactly;
   mode "gpu": the HIP runner (I64MoEModel(expert_parallel=True)), every rank on cuda:0 (gloo stages through the host), against
               the same single-process statement within the quantization-noise bound of the model tests.
-One prefill step and two decode steps."""
+One prefill step and two decode steps (case "real64": one)."""
 import os
 import sys
 
@@ -31,23 +31,37 @@ def main():
     import dataclasses
     if big:
         ocfg = dataclasses.replace(ocfg, max_pos=512)
-    if case == "real2":   # the benchmark model's real dimensions (hidden 1024, 8 experts of width 448, shared 1792), two layers deep
+    if case in ("real2", "real64"):   # the benchmark model's real dimensions (hidden 1024, 8 experts of width 448, shared 1792), two layers deep
         ocfg = dataclasses.replace(M.named_config("trhash500m-synth"), num_layers=2, max_pos=256, name="trhash500m-cut2")
         w = M.make_weights(ocfg, seed=0)
         bank = M.LinearBank(w, "int8")
-    lens, prompts = ep_oracle.make_case(ocfg, world, big=big)
+    # "real64": 64 sequences per rank, i.e. world x 64 x top_k pooled expert rows in a decode step (the benchmark's batch)
+    lens, prompts = ep_oracle.make_case(ocfg, world, big=big, batch=64 if case == "real64" else 0)
     nseq = len(lens[0])
+    nblk = max(64, 2 * nseq)
     # the single-process statement, for all ranks (every rank computes it: tiny)
-    kvs = [M.PagedKV(ocfg, 64, nseq) for _ in range(world)]
+    kvs = [M.PagedKV(ocfg, nblk, nseq) for _ in range(world)]
     steps = []   # per step: (ids per rank, positions per rank, tokens per seq)
     ids = [torch.cat(p) for p in prompts]
     pos = [torch.cat([torch.arange(n) for n in ls]) for ls in lens]
     cur = [list(ls) for ls in lens]
     ref = []
     tps = [list(ls) for ls in lens]
-    for step in range(3):
-        lg = ep_oracle.reference_step(ocfg, bank, ids, pos, kvs, [list(range(nseq))] * world, tps)
+    n_steps = 2 if case == "real64" else 3
+    for step in range(n_steps):
+        if case == "real64":
+            # at these sizes the statement takes the host cores tens of seconds: rank 0 computes it, the others receive it
+            if rank == 0:
+                lg = ep_oracle.reference_step(ocfg, bank, ids, pos, kvs, [list(range(nseq))] * world, tps)
+            else:
+                lg = [torch.empty(len(i), ocfg.vocab_size) for i in ids]
+            for x in lg:
+                dist.broadcast(x, src=0)
+        else:
+            lg = ep_oracle.reference_step(ocfg, bank, ids, pos, kvs, [list(range(nseq))] * world, tps)
         steps.append((ids, pos, tps))
+        if rank == 0:
+            print(f"oracle statement of step {step} done", file=sys.stderr, flush=True)
         if step == 0:
             lg = [x[torch.cumsum(torch.tensor(ls), 0) - 1] for x, ls in zip(lg, lens)]
         ref.append(lg)
@@ -57,7 +71,7 @@ def main():
         tps = [[1] * nseq for _ in range(world)]
     worst, agree = 0.0, 1.0
     if mode == "cpu":
-        kv = M.PagedKV(ocfg, 64, nseq)
+        kv = M.PagedKV(ocfg, nblk, nseq)
         for step, (sids, spos, stps) in enumerate(steps):
             lg = ep_oracle.rank_step(ocfg, bank, comm, sids[rank], spos[rank], kv, list(range(nseq)), stps[rank])
             if step == 0:
@@ -67,7 +81,7 @@ def main():
         from vllm_i64_amd.config import ModelConfig
         from vllm_i64_amd.model import I64MoEModel
         dev = torch.device("cuda:0")
-        model = I64MoEModel(ModelConfig.from_any(ocfg), w, device=dev, max_seqs=nseq, num_kv_blocks=64, expert_parallel=True)
+        model = I64MoEModel(ModelConfig.from_any(ocfg), w, device=dev, max_seqs=nseq, num_kv_blocks=nblk, expert_parallel=True)
         assert model.ep.world == world and not model.ep.direct
         for s in range(nseq):
             model.kv.reserve(s, lens[rank][s] + 4)
@@ -79,6 +93,8 @@ def main():
                 rows = (torch.cumsum(torch.tensor(lens[rank]), 0) - 1).to(torch.int32).to(dev)
             lg = model.forward(sids[rank].to(dev), p32, slot, (p32 + 1).contiguous(), logit_rows=rows).cpu()
             worst = max(worst, float((lg - ref[step][rank]).abs().max()))
+            if rank == 0:
+                print(f"runner step {step} done: max diff so far {worst:.3e}", file=sys.stderr, flush=True)
             agree = min(agree, float((lg.argmax(-1) == ref[step][rank].argmax(-1)).float().mean()))
     t = torch.tensor([worst, -agree], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -92,9 +92,13 @@ def rank_step(ocfg, bank, comm, ids, positions, kv, seq_ids: Sequence[int], toke
     return F.linear(M.rmsnorm(h, bank.w["final_norm"], ocfg.rms_eps), bank.w["embed"])
 
 
-def make_case(ocfg, world: int, seed: int = 5, big: bool = False):
+def make_case(ocfg, world: int, seed: int = 5, big: bool = False, batch: int = 0):
     """Per-rank prompts with the SAME token count on every rank (the exchange has fixed shapes), ragged inside a rank.
-    big: enough pooled expert rows (world x 300 tokens x top_k) for the prefill-sized expert path."""
+    big: enough pooled expert rows (world x 300 tokens x top_k) for the prefill-sized expert path; batch: that many one-token
+    prompts per rank instead (every step has `batch` rows per rank, like a decode step of that batch size)."""
+    if batch:
+        lens = [[1] * batch for _ in range(world)]
+        return lens, [[M.make_token_ids(ocfg, n, seed=seed + 1000 * r + j) for j, n in enumerate(ls)] for r, ls in enumerate(lens)]
     lens = ([[180, 120], [75, 225], [299, 1], [150, 150]] if big else [[12, 8], [5, 15], [19, 1], [10, 10]])[:world]
     prompts = [[M.make_token_ids(ocfg, n, seed=seed + 10 * r + j) for j, n in enumerate(ls)] for r, ls in enumerate(lens)]
     return lens, prompts

@@ -13,24 +13,26 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("world,port,force,case", [(2, 29551, "0", "small"), (4, 29552, "0", "small"), (1, 29553, "1", "small"),
-                                                   (2, 29554, "0", "big"), (2, 29555, "0", "real2")])
+                                                   (2, 29554, "0", "big"), (2, 29555, "0", "real2"), (4, 29556, "0", "real64")])
 def test_expert_parallel_runner_against_single_process_oracle(world, port, force, case):
     """Prefill (ragged prompts, equal token count per rank) and two greedy decode steps.  Bound: the quantization-noise scale
     of the model tests (a flipped 7-bit activation LSB moves a logit by ~1e-2); greedy tokens identical.  world 1 with forced
     collectives walks the exchange path (gather, row maps, all-to-all, owner-indexed combine) at one rank; "big": 300 tokens per
     rank, i.e. 1200 pooled expert rows in the prefill step (the separately quantized, prefill-sized expert path); "real2": a
-    two-layer cut of the benchmark model at its real dimensions (four local experts per rank)."""
+    two-layer cut of the benchmark model at its real dimensions (four local experts per rank); "real64": the same cut with the
+    benchmark's 64 sequences per rank on 4 ranks - 512 pooled expert rows in every step (the fused expert launches between 257
+    and 1024 pooled rows)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", I64H_EP_FORCE_COLLECTIVES=force)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="8" if case == "real64" else "2", I64H_EP_FORCE_COLLECTIVES=force)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
                         "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "ep_model_worker.py"), "gpu", case],
-                       capture_output=True, text=True, env=env, timeout=600)
+                       capture_output=True, text=True, env=env, timeout=170)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     line = [l for l in r.stdout.splitlines() if l.startswith("EP_MODEL_RESULT")][0].split()
     print(line)
     assert int(line[2]) == world
-    if case == "real2":
+    if case in ("real2", "real64"):
         # the benchmark model's dimensions, two layers, end to end: isolated activation-code flips move a logit by up to ~1e-1
         # at these widths (tests/test_gpu_fullsize.py); an error in the exchange plumbing would be of the logits' own size (~3)
         assert float(line[3]) <= 1.5e-1 and float(line[4]) >= 0.9

@@ -466,8 +466,11 @@ template <typename KV> struct Stage8 {
     }
 };
 
+#ifndef I64H_PF_OCC
+#define I64H_PF_OCC 2  // waves per SIMD the register allocation aims at
+#endif
 template <int GS, typename KV>
-__global__ __launch_bounds__(GS * 64) void paged_attn_prefill_bf16_kernel(const float* __restrict__ q, const KV* __restrict__ k_cache,
+__global__ __launch_bounds__(GS * 64, I64H_PF_OCC) void paged_attn_prefill_bf16_kernel(const float* __restrict__ q, const KV* __restrict__ k_cache,
                                                                           const KV* __restrict__ v_cache,
                                                                           const int32_t* __restrict__ block_table, int max_blocks_per_seq,
                                                                           const int32_t* __restrict__ slot_ids, const int32_t* __restrict__ ctx_len,
