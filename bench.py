@@ -286,6 +286,7 @@ def main():
                 tp, timed_seqs = time.time(), B - len(seqs)
         torch.cuda.synchronize()
         rate = timed_seqs * P / (time.time() - tp)
+        model.check_sync()  # no grid barrier of the prefill's resident launches ran out of its wait budget
         dec.set_state(first, [P] * B, reserve_extra=total_len - P)
         return rate
 

@@ -435,6 +435,7 @@ def test_prefill_with_norm_and_quantization_in_one_launch_gives_the_same_bits(de
         finally:
             model.FUSE_NORM_QUANT = I64MoEModel.FUSE_NORM_QUANT
         outs.append((logits, [k.clone() for k in model.kv.k], [v.clone() for v in model.kv.v], model.kv.block_table.clone()))
+        model.check_sync()
     assert torch.equal(outs[0][3], outs[1][3])
     assert torch.equal(outs[0][0], outs[1][0])
     for a, b in zip(outs[0][1] + outs[0][2], outs[1][1] + outs[1][2]):

@@ -269,6 +269,12 @@ class I64MoEModel:
             self._fq_rows_cached = ops.fused_residual_norm_quant_rows()
         return self._fq_rows_cached
 
+    def check_sync(self):
+        """Raises if a grid barrier of a resident launch (the one-launch norm + quantization of a prefill chunk, the opt-in decode
+        tail) ever ran out of its wait budget - its results are then not to be trusted.  Synchronizes; call it off the hot path."""
+        if int(self.dec_sync[1].item()) != 0:
+            raise RuntimeError("a grid barrier of a resident launch exceeded its wait budget (workgroups not co-resident?)")
+
     FUSE_MAX_ROWS = 256  # up to this many operand rows the quantizer runs inside the GEMM (one launch per Linear call)
     EP_FUSE_MAX_ROWS = 1024  # the same for the pooled expert rows of the expert-parallel runner (8 ranks x 64 sequences x top-2)
     fuse_qkr = True   # decode-sized steps: QK norm / RoPE / cache write inside the qkv GEMM
