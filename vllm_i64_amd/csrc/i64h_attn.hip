@@ -481,7 +481,10 @@ __global__ __launch_bounds__(GS * 64, I64H_PF_OCC) void paged_attn_prefill_bf16_
     __shared__ __attribute__((aligned(16))) unsigned short Kb[PF_TOK * 64];
     __shared__ __attribute__((aligned(16))) unsigned short Vb[PF_TOK * 64];
     __shared__ int s_ok[PF_TOK];
+    __shared__ int s_plain[2];  // tile i: s_plain[i & 1] stays 1 unless some wave staged a row without a cache block behind it
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid < 2) s_plain[tid] = 1;  // (ordered before the first tile's writes by that tile's first barrier)
+    int tile_no = 0;
     const int g = lane >> 4, c = lane & 15;
     const int kh = blockIdx.y, head = kh * GS + wid, nh = kvh * GS;
     const int r = (gridDim.x - 1 - blockIdx.x) * 16 + c;  // this lane's query row (tiles are taken from the back)
@@ -566,7 +569,13 @@ __global__ __launch_bounds__(GS * 64, I64H_PF_OCC) void paged_attn_prefill_bf16_
                     if (ch == 0) s_ok[tt] = rok[u];
                 }
             }
-            const bool plain = __syncthreads_and(all_ok) && (t0 + PF_TOK <= lim_min);
+            // "every staged row is live", over the workgroup: a wave that saw a dead row clears the tile's flag (one ballot, no
+            // wave-wide reduction); the flag of the next tile is set again behind the barrier, before anybody can clear it
+            if (__ballot(!all_ok) != 0ull && lane == 0) s_plain[tile_no & 1] = 0;
+            __syncthreads();
+            const bool plain = s_plain[tile_no & 1] != 0 && (t0 + PF_TOK <= lim_min);
+            if (tid == 0) s_plain[(tile_no + 1) & 1] = 1;
+            ++tile_no;
             if (t0 + PF_TOK < kv_end) gload(t0 + PF_TOK);  // next tile in flight behind the math of this one
 
             // scores of 64 tokens: S^T tile t holds tokens t0 + 16 t + 4 g + reg of query row c; small terms first
@@ -600,8 +609,12 @@ __global__ __launch_bounds__(GS * 64, I64H_PF_OCC) void paged_attn_prefill_bf16_
                         mx = fmaxf(mx, sc[t][e]);
                     }
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            {  // over the four lanes of a query row (lane ^ 16, lane ^ 32) through register swaps, no LDS round trip
+                const PairF sr = swap_rows(mx);
+                mx = fmaxf(sr.lo, sr.hi);
+                const PairF sh = swap_halves(mx);
+                mx = fmaxf(sh.lo, sh.hi);
+            }
             const float mn = fmaxf(m, mx);
             if (__ballot(mn != m)) {  // some row's running maximum moved: rescale (rare after the first tiles)
                 const float alpha = (mn == -INFINITY) ? 1.0f : exp2f(m - mn);
