@@ -142,10 +142,20 @@ def bench_gemm_os(only=None, ragged=False):
             cnt = torch.bincount(torch.randint(0, G, (M,), device=dev), minlength=G)
             off = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), cnt.cumsum(0)]).to(torch.int32)
         out = torch.empty(M, N // 2 if epi else N, device=dev)
+        skw = {}
+        if epi:  # the SwiGLU calls of the runner also fold the range of their output: per (route, expert) bucket / one slot for the shared expert
+            st = ops.stats_alloc(2 * G + 1, dev)
+            ops.stats_reset(st)
+            skw = dict(stats=st, slot_base=0)
+            if G > 1:
+                o64 = off.long()
+                grp = torch.bucketize(torch.arange(M, device=dev), o64[1:], right=True)
+                half = (torch.arange(M, device=dev) - o64[grp]) * 2 >= (o64[grp + 1] - o64[grp])
+                skw["row_slot"] = (grp * 2 + half.long()).to(torch.int32)
         for waves, depth in ((8, 2), (8, 3), (12, 2), (12, 3)):
             ops.call("i64h_set_gemm_os", 256, depth)
             ops.call("i64h_set_gemm_os_waves", waves)
-            med, best = timeit(lambda: ops.gemm_i8_frags(a, rs, wf, ws, N, group_offsets=off, epilogue=epi, out=out), iters=5, warm=2, inner=5)
+            med, best = timeit(lambda: ops.gemm_i8_frags(a, rs, wf, ws, N, group_offsets=off, epilogue=epi, out=out, **skw), iters=5, warm=2, inner=5)
             print(f"gemm_i8_frags {name:34s} M={M} N={N} K={K} G={G} waves {waves} depth {depth}: {med:8.1f} us -> "
                   f"{2 * M * N * K / med / 1e6:7.1f} TOP/s ({2 * M * N * K / med / 1e6 / 5000 * 100:4.1f}% of 5 POP/s)")
             ok = bool(torch.equal(ops.gemm_i8(a, rs, w, ws, group_offsets=off, epilogue=epi), out))

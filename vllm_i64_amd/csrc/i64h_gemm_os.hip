@@ -50,7 +50,8 @@ __global__ __launch_bounds__(256) void pack_frags_kernel(const int8_t* __restric
 // partners; plain: 32 adjacent columns).  u0 = first unit; sp = this wave's stamp slots or nullptr.
 template <int EPI, int DB, int W, int MFR>
 __device__ __forceinline__ void os_block(const GemmI8Args& p, const char* Bg, const int KS, const int rk, const int u0, const int g, const int row0,
-                                         const int rows, const float ws, const bool st, const int item, const int lane, unsigned long long* sp) {
+                                         const int rows, const float ws, const bool st, const bool uni, const int sl0, const int sl1,
+                                         const int item, const int lane, unsigned long long* sp) {
     // the LDS regions are re-derived from the array itself: pointers handed in as arguments lose their address space
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const char* img = smem;
@@ -150,6 +151,7 @@ __device__ __forceinline__ void os_block(const GemmI8Args& p, const char* Bg, co
             }
         }
     } else {
+        float ra = 0.0f, rb = 0.0f, ra1 = 0.0f, rb1 = 0.0f;  // ranges of what this lane stored, per slot (tiles whose rows share one or two slots)
 #pragma unroll
         for (int i = 0; i < MFR; ++i) {
             const int rr = i * 16 + fr;
@@ -173,7 +175,11 @@ __device__ __forceinline__ void os_block(const GemmI8Args& p, const char* Bg, co
                     for (int reg = 0; reg < 4; ++reg) { a = fminf(a, v[reg]); bb = fmaxf(bb, v[reg]); }
                 }
             }
-            if (st) {
+            if (st && uni) {  // the tile's rows report to one or two slots: their ranges are carried over the row fragments in registers
+                const bool second = rok && s_rel[rr] != sl0;
+                ra = fminf(ra, second ? 0.0f : a); rb = fmaxf(rb, second ? 0.0f : bb);
+                ra1 = fminf(ra1, second ? a : 0.0f); rb1 = fmaxf(rb1, second ? bb : 0.0f);
+            } else if (st) {
                 a = fminf(a, lane_xor(a, 16)); bb = fmaxf(bb, lane_xor(bb, 16));
                 a = fminf(a, lane_xor(a, 32)); bb = fmaxf(bb, lane_xor(bb, 32));
                 if (fq == 0 && rok) {
@@ -184,6 +190,24 @@ __device__ __forceinline__ void os_block(const GemmI8Args& p, const char* Bg, co
                     } else {
                         stat_update(p.stats, p.out_slot_base + sl, item, a, bb);
                     }
+                }
+            }
+        }
+        if (st && uni) {  // one pair of table updates per slot and block instead of one per row (same-address LDS atomics serialise)
+            ra = wave_min(ra);
+            rb = wave_max(rb);
+            if (sl1 != sl0) {
+                ra1 = wave_min(ra1);
+                rb1 = wave_max(rb1);
+            }
+            if (lane < 2 && (lane == 0 || sl1 != sl0)) {
+                const int sl = lane == 0 ? sl0 : sl1;
+                const float lo = lane == 0 ? ra : ra1, hi = lane == 0 ? rb : rb1;
+                if (sl >= 0 && sl < I64H_STAT_TAB) {
+                    atomicMin(&tab_lo[sl], f32_to_ordered(lo));
+                    atomicMax(&tab_hi[sl], f32_to_ordered(hi));
+                } else {
+                    stat_update(p.stats, p.out_slot_base + sl, item, lo, hi);
                 }
             }
         }
@@ -251,17 +275,34 @@ __device__ __forceinline__ void os_run(const GemmI8Args& p, const int8_t* __rest
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (sp && lane == 0) sp[2] = __builtin_amdgcn_s_memtime();
+        // Do the rows of the tile report to at most two statistics slots (always without a per-row slot array; with one, the
+        // rows arrive sorted by bucket, so a tile holds one bucket or straddles one boundary)?  Then the ranges are kept in
+        // registers per slot instead of going through one table update per row.
+        bool uni = true;
+        int sl0 = 0, sl1 = 0;
+        if (st && p.out_row_slot) {
+            sl0 = s_rel[0];
+            sl1 = s_rel[rows - 1];
+            bool other = false;
+#pragma unroll
+            for (int q = 0; q < (BM + 63) / 64; ++q) {
+                const int r = lane + 64 * q;
+                const int v = s_rel[min(r, BM - 1)];
+                other |= r < rows && v != sl0 && v != sl1;
+            }
+            uni = __ballot(other) == 0ull;
+        }
         // Workgroups that share a group's weights would otherwise walk the same addresses in step and queue on one L2 channel
         // after another: each wave starts at a K step of its own (integer sums are exact in any order).
         const int rk = (int)(((unsigned)slot * (unsigned)rotk + (unsigned)wid * (unsigned)(rotk != 0)) % (unsigned)KS);
         if (WMAX >= 2) {
             for (; cnt >= 2; cnt -= 2, u += 2) {
-                os_block<EPI, DB, WMAX >= 2 ? 2 : 1, MFR>(p, Bg, KS, rk, u, g, row0, rows, ws, st, item, lane, sp);
+                os_block<EPI, DB, WMAX >= 2 ? 2 : 1, MFR>(p, Bg, KS, rk, u, g, row0, rows, ws, st, uni, sl0, sl1, item, lane, sp);
                 sp = nullptr;
             }
         }
         for (; cnt >= 1; --cnt, ++u) {
-            os_block<EPI, DB, 1, MFR>(p, Bg, KS, rk, u, g, row0, rows, ws, st, item, lane, sp);
+            os_block<EPI, DB, 1, MFR>(p, Bg, KS, rk, u, g, row0, rows, ws, st, uni, sl0, sl1, item, lane, sp);
             sp = nullptr;
         }
         sp = (p.stamps && item == slot) ? p.stamps + ((int64_t)w * 16 + wid) * 8 + lane : nullptr;
