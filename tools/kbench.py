@@ -167,6 +167,27 @@ def bench_gemm_os(only=None, ragged=False):
         print("   equal to the row-major-weight kernel:", bool(torch.equal(ref, ops.gemm_i8_frags(a, rs, wf, ws, N, group_offsets=off, epilogue=epi))))
 
 
+def bench_gemm_os_cold():
+    """The grouped gate_up shape with the weights of a different layer at every launch (48 packs, more than the Infinity Cache
+    holds), as the runner meets them, against the same launch on one pack that stays cached."""
+    torch.manual_seed(0)
+    M, N, K, G, L = 32768, 896, 1024, 8, 48
+    a = torch.randint(-127, 128, (M, K), dtype=torch.int8, device=dev)
+    packs = [ops.pack_weight_frags(torch.randint(-128, 128, (G, N, K), dtype=torch.int8, device=dev)) for _ in range(L)]
+    rs = torch.rand(M, device=dev) * 1e-3
+    ws = torch.rand(G, device=dev) * 1e-2
+    off = (torch.arange(G + 1, device=dev) * (M // G)).to(torch.int32)
+    out = torch.empty(M, N // 2, device=dev)
+    state = {"i": 0}
+
+    def cold():
+        state["i"] = (state["i"] + 1) % L
+        ops.gemm_i8_frags(a, rs, packs[state["i"]], ws, N, group_offsets=off, epilogue=1, out=out)
+    med_h, _ = timeit(lambda: ops.gemm_i8_frags(a, rs, packs[0], ws, N, group_offsets=off, epilogue=1, out=out), iters=5, warm=2, inner=6)
+    med_c, _ = timeit(cold, iters=5, warm=2, inner=6)
+    print(f"grouped gate_up, weights cached: {med_h:.1f} us; weights of another layer at every launch: {med_c:.1f} us")
+
+
 def bench_gemm_prefill(only=None):
     """Prefill-shaped int8 GEMMs (operands already quantized): achieved int8 TOP/s = 2*M*N*K / time."""
     torch.manual_seed(0)
@@ -219,6 +240,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if what in ("gemmos", "gemmosr"):  # gemmosr: ragged groups
         bench_gemm_os(sys.argv[2] if len(sys.argv) > 2 else None, ragged=what == "gemmosr")
+        sys.exit(0)
+    if what == "gemmosc":
+        bench_gemm_os_cold()
         sys.exit(0)
     if what == "attnp":
         bench_attn_prefill()

@@ -29,6 +29,13 @@ __device__ __forceinline__ void os_glds16(const void* g, void* lds_base) {
     __builtin_amdgcn_global_load_lds((os_gbl_void*)g, (os_lds_void*)lds_base, 16, 0, 0);
 }
 
+#ifndef I64H_OS_PREFETCH
+#define I64H_OS_PREFETCH 1  // weights of the tile's group requested into the XCD's L2 while the operand image is filled
+#endif
+#ifndef I64H_OS_PF_SHARES
+#define I64H_OS_PF_SHARES 8  // ... one share of this many per workgroup
+#endif
+
 __device__ __forceinline__ float os_silu(float g) {
     const float e = __builtin_amdgcn_exp2f(g * -1.44269504088896341f);
     return g * __builtin_amdgcn_rcpf(1.0f + e);
@@ -259,6 +266,25 @@ __device__ __forceinline__ void os_run(const GemmI8Args& p, const int8_t* __rest
         const int n = uhi - ulo, base = n / NW, rem = n - base * NW;
         int cnt = base + (wid < rem ? 1 : 0);
         int u = ulo + wid * base + min(wid, rem);
+#if I64H_OS_PREFETCH
+        // The weights of a launch are those of another layer than the last launch's: cold, in HBM.  The workgroups of an XCD
+        // (consecutive items) share one or two groups' weights through that XCD's L2, so each of them asks for an eighth of its
+        // group's pack now - one 16-byte piece out of every 128-byte line, dropped into a spare KB of LDS - and the weight stream
+        // of the K loops, which starts only after the operand image has arrived, finds the lines in the L2.
+        {
+            const int64_t bbytes = (int64_t)p.N * K;
+            const int64_t share = (bbytes + I64H_OS_PF_SHARES * 8192 - 1) / (I64H_OS_PF_SHARES * 8192) * 8192;
+            const int64_t lo = (int64_t)(item % I64H_OS_PF_SHARES) * share;
+            const int64_t hi = lo + share < bbytes ? lo + share : bbytes;
+            const char* bsrc = (const char*)Bf + (int64_t)g * bbytes;
+            char* junk = (char*)(s_info + 64);
+            for (int64_t o = lo + (int64_t)wid * 8192; o < hi; o += (int64_t)NW * 8192) {
+                int64_t a = o + lane * 128;
+                a = a < bbytes - 16 ? a : bbytes - 16;
+                os_glds16(bsrc + a, junk);
+            }
+        }
+#endif
         // the tile's operand rows -> fragment image: the KS x MFR fragments are dealt to the waves in image order
         for (int f = wid; f < KS * MFR; f += NW) {
             const int ks = f / MFR, i = f - ks * MFR;
@@ -360,7 +386,7 @@ static unsigned long long* g_os_stamps = nullptr;  // diagnostics (i64h_debug_se
 static int g_os_rotk = 0;  // tuning knob: per-workgroup rotation of the K order (0 = off)
 
 static int g_os_tall = 1;  // tuning knob: 0 = tiles of 128 rows only
-static size_t os_lds_bytes(int K, int mfr) { return (size_t)(K / 64) * mfr * 1024 + mfr * 128 + 2 * I64H_STAT_TAB * 4 + 16 * 16; }
+static size_t os_lds_bytes(int K, int mfr) { return (size_t)(K / 64) * mfr * 1024 + mfr * 128 + 2 * I64H_STAT_TAB * 4 + 16 * 16 + 1024; }  // image, row arrays, table, per-wave words, prefetch sink
 
 template <int EPI, int DB, int NW, int WMAX>
 static int launch_os(const GemmI8Args& p, const int8_t* Bf, int n_items, int parts, hipStream_t st) {
