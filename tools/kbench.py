@@ -179,11 +179,17 @@ def bench_gemm_os_cold():
     off = (torch.arange(G + 1, device=dev) * (M // G)).to(torch.int32)
     out = torch.empty(M, N // 2, device=dev)
     state = {"i": 0}
+    st = ops.stats_alloc(2 * G + 1, dev)
+    ops.stats_reset(st)
+    o64 = off.long()
+    grp = torch.bucketize(torch.arange(M, device=dev), o64[1:], right=True)
+    half = (torch.arange(M, device=dev) - o64[grp]) * 2 >= (o64[grp + 1] - o64[grp])
+    skw = dict(stats=st, slot_base=0, row_slot=(grp * 2 + half.long()).to(torch.int32))  # two buckets per expert, as the runner has them
 
     def cold():
         state["i"] = (state["i"] + 1) % L
-        ops.gemm_i8_frags(a, rs, packs[state["i"]], ws, N, group_offsets=off, epilogue=1, out=out)
-    med_h, _ = timeit(lambda: ops.gemm_i8_frags(a, rs, packs[0], ws, N, group_offsets=off, epilogue=1, out=out), iters=5, warm=2, inner=6)
+        ops.gemm_i8_frags(a, rs, packs[state["i"]], ws, N, group_offsets=off, epilogue=1, out=out, **skw)
+    med_h, _ = timeit(lambda: ops.gemm_i8_frags(a, rs, packs[0], ws, N, group_offsets=off, epilogue=1, out=out, **skw), iters=5, warm=2, inner=6)
     med_c, _ = timeit(cold, iters=5, warm=2, inner=6)
     print(f"grouped gate_up, weights cached: {med_h:.1f} us; weights of another layer at every launch: {med_c:.1f} us")
 
