@@ -194,6 +194,31 @@ def bench_gemm_os_cold():
     print(f"grouped gate_up, weights cached: {med_h:.1f} us; weights of another layer at every launch: {med_c:.1f} us")
 
 
+def bench_gemm_decode_cold():
+    """Decode-sized dense launches (64 rows, fp32 operand quantized in the kernel, weights as fragment packs) on ONE weight that
+    stays cached against a different weight at every launch (more weights than the Infinity Cache holds), queued back to back."""
+    torch.manual_seed(0)
+    for name, N, K, L in (("qkv", 1536, 1024, 200), ("o", 1024, 1024, 300), ("shared gate_up", 3584, 1024, 90)):
+        epi = ops.EPI_SWIGLU if "gate_up" in name else ops.EPI_STORE
+        x = torch.randn(64, K, device=dev)
+        st = ops.stats_alloc(4, dev)
+        ops.stats_reset(st)
+        ops.rows_minmax(x, st, slot_base=1)
+        ws = torch.rand(1, device=dev) * 1e-2
+        wts = [torch.randint(-128, 128, (1, N, K), dtype=torch.int8, device=dev) for _ in range(L)]
+        packs = [ops.pack_weight_frags(w) for w in wts]
+        out = torch.empty(64, N // 2 if epi else N, device=dev)
+        descs = [ops.gemm_desc(x, wts[i], ws, out, a_slot_base=1, stats=st, epilogue=epi, w_frags=packs[i]) for i in range(L)]
+        state = {"i": 0}
+
+        def cold():
+            state["i"] = (state["i"] + 1) % L
+            ops.gemm_i8_pair(descs[state["i"]])
+        med_h, _ = timeit(lambda: ops.gemm_i8_pair(descs[0]), iters=5, warm=2, inner=20)
+        med_c, _ = timeit(cold, iters=5, warm=2, inner=20)
+        print(f"decode GEMM {name:15s} N={N} K={K}: cached weights {med_h:.2f} us; another weight at every launch {med_c:.2f} us")
+
+
 def bench_gemm_prefill(only=None):
     """Prefill-shaped int8 GEMMs (operands already quantized): achieved int8 TOP/s = 2*M*N*K / time."""
     torch.manual_seed(0)
@@ -246,6 +271,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if what in ("gemmos", "gemmosr"):  # gemmosr: ragged groups
         bench_gemm_os(sys.argv[2] if len(sys.argv) > 2 else None, ragged=what == "gemmosr")
+        sys.exit(0)
+    if what == "gemmdc":
+        bench_gemm_decode_cold()
         sys.exit(0)
     if what == "gemmosc":
         bench_gemm_os_cold()
