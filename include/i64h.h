@@ -146,6 +146,15 @@ int i64h_pack_weight_frags(const int8_t* B, int8_t* out, int32_t G, int32_t N, i
 int i64h_gemm_i8_frags(const int8_t* A, const float* row_scale, const int8_t* B_frags, const float* w_scale, const int32_t* group_offsets,
                        int32_t num_groups, int64_t M_total, int32_t N, int32_t K, float* C, int32_t epilogue, const int32_t* row_slot,
                        int32_t slot_base, uint32_t* stats, const float* col_scale, void* stream);
+/* The fused qkv projection of a prefill-sized chunk: i64h_gemm_i8_frags (plain epilogue) + i64h_qk_norm_rope_kv in one launch - the
+ * linear of the attention block with q/k RMSNorm, RoPE and the cache write of model.py:203-236 in its epilogue (a 64-column block
+ * of the operand-stationary kernel is one head); the fp32 projection is never stored; same bits in q_out and in the cache.
+ * head_dim 64; N = (num_heads + 2 * num_kv_heads) * 64 must satisfy i64h_gemm_i8_frags_ok(N, K, 0). */
+int i64h_gemm_i8_frags_qkv_rope_kv(const int8_t* A, const float* row_scale, const int8_t* B_frags, const float* w_scale, int64_t M_total,
+                                   int32_t K, const float* q_norm_w, const float* k_norm_w, float qk_eps, const float* rope_tab,
+                                   const int32_t* positions, const int32_t* slot_ids, const int32_t* block_table, int32_t max_blocks_per_seq,
+                                   float* q_out, void* k_cache, void* v_cache, int32_t kv_dtype, int32_t num_heads, int32_t num_kv_heads,
+                                   int32_t head_dim, int32_t block_size, void* stream);
 int i64h_gemm_i8_frags_ok(int32_t N, int32_t K, int32_t epilogue); /* 1 if i64h_gemm_i8_frags takes the shape (returns a flag, not a status) */
 int i64h_debug_set_os_stamps(void* buffer); /* diagnostics: 64 uint64 per workgroup (8 waves x 8 s_memtime stamps of its first tile); NULL = off */
 int i64h_set_gemm_os_waves(int32_t waves); /* tuning knob of the operand-stationary kernel: waves per workgroup, 8 (blocks of 64 columns), 12 (blocks of 32 columns), 0 = chosen by epilogue (default) */

@@ -175,3 +175,39 @@ def test_other_baseline_configs_teacher_forced(dev, name, lens):
         flipped = row_err > 1e-5   # a row whose fp32 input sits on a rounding tie of the 7-bit quantizer (see the test above)
         assert int(flipped.sum()) <= max(2, n // 64), (int(flipped.sum()), row_err[flipped])
         assert row_err.max() <= 1e-1 and do.mean() <= 2e-4
+
+
+def test_prefill_chunk_of_several_thousand_rows_fused_and_unfused_launches_give_the_same_bits(dev, two_layer):
+    """A 4400-row prefill chunk at the benchmark model's dimensions takes the operand-stationary GEMMs, the one-launch residual +
+    norm + quantization and the qkv projection with QK norm / RoPE / cache write in its epilogue; with those fusions switched off
+    the same chunk runs as separate launches.  Logits and both caches: bit for bit."""
+    from vllm_i64_amd.model import I64MoEModel
+    ocfg, w, model = two_layer
+    lens = [1200, 1100, 1000, 1100]
+    n = sum(lens)
+    assert n >= I64MoEModel.FRAGS_MIN_ROWS
+    ids = M.make_token_ids(ocfg, n, seed=21).to(dev)
+    pos = torch.cat([torch.arange(t) for t in lens]).to(torch.int32).to(dev)
+    slots = torch.cat([torch.full((t,), s, dtype=torch.int32) for s, t in enumerate(lens)]).to(dev)
+    last = (torch.cumsum(torch.tensor(lens), 0) - 1).to(torch.int32).to(dev)
+    for s in range(4):
+        model.kv.free(s)
+    for s, t in enumerate(lens):
+        model.kv.reserve(s, t)
+    outs = []
+    for fused in (True, False):
+        for c in model.kv.k + model.kv.v:
+            c.zero_()
+        model.FUSE_NORM_QUANT, model.FUSE_QKV_PREFILL = fused, fused
+        try:
+            logits = model.forward(ids, pos, slots, (pos + 1).contiguous(), logit_rows=last).clone()
+        finally:
+            model.FUSE_NORM_QUANT, model.FUSE_QKV_PREFILL = I64MoEModel.FUSE_NORM_QUANT, I64MoEModel.FUSE_QKV_PREFILL
+        model.check_sync()
+        outs.append((logits, [k.clone() for k in model.kv.k], [v.clone() for v in model.kv.v]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1] + outs[0][2], outs[1][1] + outs[1][2]):
+        assert torch.equal(a, b)
+    assert float(outs[0][1][1].abs().max()) > 0
+    for s in range(4):
+        model.kv.free(s)

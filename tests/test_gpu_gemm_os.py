@@ -197,3 +197,44 @@ def test_fragment_pack_is_refused_where_no_kernel_reads_it(dev):
     with pytest.raises(I64HError):
         ops.gemm_i8_pair(d1, d2)
     ops.gemm_i8_pair(d1)  # alone it is fine
+
+
+@pytest.mark.parametrize("kv_dtype", [torch.bfloat16, torch.float32, torch.float16, torch.float8_e4m3fn])
+@pytest.mark.parametrize("with_norm,rows_", [(True, 5003), (False, 300)])
+def test_fused_qkv_projection_with_norm_rope_and_cache_write_in_the_epilogue(dev, kv_dtype, with_norm, rows_):
+    """The prefill-sized qkv projection with per-head RMSNorm, RoPE and the paged-cache write in the epilogue of the
+    operand-stationary kernel against the two launches it replaces (plain projection, then qk_norm_rope_kv): q_out and both caches
+    bit for bit; rows without a cache block behind them leave the cache alone."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(rows_ + int(with_norm))
+    nh, kvh, hd, K, block = 16, 4, 64, 1024, 16
+    N = (nh + 2 * kvh) * hd
+    a8 = torch.randint(-127, 128, (rows_, K), dtype=torch.int8, generator=g).to(dev)
+    rs = (torch.rand(rows_, generator=g) * 1e-2 + 1e-3).to(dev)
+    w = torch.randint(-128, 128, (1, N, K), dtype=torch.int8, generator=g).to(dev)
+    ws = torch.tensor([3e-3], device=dev)
+    wf = ops.pack_weight_frags(w)
+    seqs = 7
+    per = (rows_ + seqs - 1) // seqs
+    nb_seq = (per + block - 1) // block
+    nblk = seqs * nb_seq + 2
+    bt = torch.randperm(nblk - 1, generator=g)[:seqs * nb_seq].to(torch.int32).view(seqs, nb_seq).contiguous()
+    bt[seqs - 1, nb_seq - 1] = -1   # a hole: the rows of that block must not be written
+    bt = bt.to(dev)
+    slot = (torch.arange(rows_) // per).to(torch.int32).to(dev)
+    pos = (torch.arange(rows_) % per).to(torch.int32).to(dev)
+    rope = torch.randn(per + 1, hd, generator=g).to(dev)
+    qw = (torch.rand(hd, generator=g) + 0.5).to(dev) if with_norm else None
+    kw = (torch.rand(hd, generator=g) + 0.5).to(dev) if with_norm else None
+
+    def caches():
+        z = torch.zeros(nblk, block, kvh, hd, device=dev)
+        return (z + 7.0).to(kv_dtype), (z - 3.0).to(kv_dtype)
+    kc1, vc1 = caches()
+    kc2, vc2 = caches()
+    qkv = ops.gemm_i8_frags(a8, rs, wf, ws, N)
+    q1 = ops.qk_norm_rope_kv(qkv, qw, kw, 1e-6, rope, pos, slot, bt, kc1, vc1, nh, kvh, hd)
+    q2 = ops.gemm_i8_frags_qkv_rope_kv(a8, rs, wf, ws, qw, kw, 1e-6, rope, pos, slot, bt, kc2, vc2, nh, kvh, hd)
+    assert torch.equal(q1, q2)
+    assert torch.equal(kc1.view(torch.uint8), kc2.view(torch.uint8)) and torch.equal(vc1.view(torch.uint8), vc2.view(torch.uint8))
+    assert not torch.equal(kc1.view(torch.uint8), caches()[0].view(torch.uint8))  # the cache really was written

@@ -18,6 +18,7 @@
 // one output row and stores them as one 16-byte word.  Integer accumulation is exact in any order, and the rescale /
 // SwiGLU expressions are those of the row-streaming kernel (i64h_gemm.hip), so the results are bit-identical to it.
 #include "i64h_gemm_dev.h"
+#include "i64h_kv_dev.h"
 
 #define OS_BM 128
 
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void pack_frags_kernel(const int8_t* __restric
 template <int EPI, int DB, int W, int MFR>
 __device__ __forceinline__ void os_block(const GemmI8Args& p, const char* Bg, const int KS, const int rk, const int u0, const int g, const int row0,
                                          const int rows, const float ws, const bool st, const bool uni, const int sl0, const int sl1,
-                                         const int item, const int lane, unsigned long long* sp) {
+                                         const int item, const int lane, unsigned long long* sp, const RowTailArgs* ta = nullptr) {
     // the LDS regions are re-derived from the array itself: pointers handed in as arguments lose their address space
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const char* img = smem;
@@ -139,7 +140,111 @@ __device__ __forceinline__ void os_block(const GemmI8Args& p, const char* Bg, co
     if (sp && lane == 0) sp[3] = __builtin_amdgcn_s_memtime();
 
     // ---- epilogue: fragment (i, j): row 16 i + fr, columns 16 cj[j] + 4 fq + (0..3) ----
-    if (EPI == EPI_STORE) {
+    if constexpr (EPI == EPI_QKR) {
+        // The block is one 64-wide head of the fused qkv projection: per-head RMSNorm, rotate-half RoPE, q to q_out, K / V into the
+        // paged cache - the arithmetic of qk_norm_rope_kv_vec_kernel on the values the plain epilogue would have stored.  A lane
+        // holds dims d = 16 j + 4 fq + reg of its rows; the sum of squares follows that kernel's butterfly (dim ^ 32, ^ 16, ^ 8,
+        // ^ 4, ^ 2, ^ 1): ^ 32 and ^ 16 pair the lane's own fragments j ^ 2 and j ^ 1, ^ 8 and ^ 4 are lane ^ 32 and lane ^ 16,
+        // ^ 2 and ^ 1 the lane's own registers; the rotation partner d +- 32 is fragment j ^ 2.
+        static_assert(EPI != EPI_QKR || NJ == 4, "a head is four fragment columns");
+        const int head = u0 >> 1;
+        const int nh = ta->nh, kvh = ta->kvh;
+        const int* s_pos = s_rel;                 // per tile row: position, cache token row (or -1)
+        const int* s_crow = (const int*)tab_lo;
+        if (head >= nh + kvh) {  // V: the projection itself goes into the cache
+#pragma unroll
+            for (int i = 0; i < MFR; ++i) {
+                const int rr = i * 16 + fr;
+                const bool rok = rr < rows;
+                const int rc = rok ? rr : 0;
+                const float m = s_rs[rc] * ws;
+                const int crow = s_crow[rc];
+                if (rok && crow >= 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float x[4] = {(float)acc[i][j][0] * m, (float)acc[i][j][1] * m, (float)acc[i][j][2] * m, (float)acc[i][j][3] * m};
+                        kv_store4_rt(ta->v_cache, ((int64_t)crow * kvh + (head - nh - kvh)) * 64 + 16 * j + 4 * fq, x, ta->kv_dtype);
+                    }
+                }
+            }
+        } else {
+            const bool is_q = head < nh;
+            const float* nw = is_q ? ta->qw : ta->kw;
+            float4 wv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wv[j] = nw ? *(const float4*)(nw + 16 * j + 4 * fq) : make_float4(1, 1, 1, 1);
+            // the rotation table rows of a row fragment are requested one fragment ahead (the weight and operand fragment
+            // registers of the K loop are free now): without that every fragment waits for its own table loads
+            float4 cv[2][2], sv[2][2];  // [buffer][jj]
+            auto rope_load = [&](int i, int b) {
+                const int rr = min(i * 16 + fr, rows - 1);
+                const float* cs = ta->rope_tab + (int64_t)s_pos[rr] * 64 + 4 * fq;
+                cv[b][0] = *(const float4*)cs; cv[b][1] = *(const float4*)(cs + 16);
+                sv[b][0] = *(const float4*)(cs + 32); sv[b][1] = *(const float4*)(cs + 48);
+            };
+            rope_load(0, 0);
+#pragma unroll
+            for (int i = 0; i < MFR; ++i) {
+                const int b = i & 1;
+                if (i + 1 < MFR) rope_load(i + 1, b ^ 1);
+                const int rr = i * 16 + fr;
+                const bool rok = rr < rows;
+                const int rc = rok ? rr : 0;
+                const float m = s_rs[rc] * ws;
+                const int crow = s_crow[rc];
+                float x[4][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) x[j][reg] = (float)acc[i][j][reg] * m;
+                if (nw) {
+                    float u4[4];
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const float s0 = __builtin_fmaf(x[0][reg], x[0][reg], 0.0f), s1 = __builtin_fmaf(x[1][reg], x[1][reg], 0.0f);
+                        const float s2 = __builtin_fmaf(x[2][reg], x[2][reg], 0.0f), s3 = __builtin_fmaf(x[3][reg], x[3][reg], 0.0f);
+                        const float t0 = s0 + s2, t1 = s1 + s3;   // dim ^ 32
+                        u4[reg] = t0 + t1;                        // dim ^ 16
+                    }
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) u4[reg] = u4[reg] + lane_xor(u4[reg], 32);  // dim ^ 8
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) u4[reg] = u4[reg] + lane_xor(u4[reg], 16);  // dim ^ 4
+                    const float a0 = u4[0] + u4[2], a1 = u4[1] + u4[3];                           // dim ^ 2
+                    const float ss = a0 + a1;                                                     // dim ^ 1
+                    const float rinv = rsqrtf(ss / 64.0f + ta->qk_eps);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        x[j][0] = x[j][0] * rinv * wv[j].x; x[j][1] = x[j][1] * rinv * wv[j].y;
+                        x[j][2] = x[j][2] * rinv * wv[j].z; x[j][3] = x[j][3] * rinv * wv[j].w;
+                    }
+                }
+                float o[4][4];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const float cc[4] = {cv[b][jj].x, cv[b][jj].y, cv[b][jj].z, cv[b][jj].w};
+                    const float sn[4] = {sv[b][jj].x, sv[b][jj].y, sv[b][jj].z, sv[b][jj].w};
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const float lo_ = x[jj][reg], hi_ = x[jj + 2][reg];     // dims d < 32 and d + 32
+                        o[jj][reg] = lo_ * cc[reg] + (-hi_) * sn[reg];
+                        o[jj + 2][reg] = hi_ * cc[reg] + lo_ * sn[reg];
+                    }
+                }
+                if (is_q) {
+                    if (rok) {
+                        float* qrow = ta->q_out + ((int64_t)(row0 + rr) * nh + head) * 64 + 4 * fq;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) *(float4*)(qrow + 16 * j) = make_float4(o[j][0], o[j][1], o[j][2], o[j][3]);
+                    }
+                } else if (rok && crow >= 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        kv_store4_rt(ta->k_cache, ((int64_t)crow * kvh + (head - nh)) * 64 + 16 * j + 4 * fq, o[j], ta->kv_dtype);
+                }
+            }
+        }
+    } else if (EPI == EPI_STORE) {
 #pragma unroll
         for (int i = 0; i < MFR; ++i) {
             const int rr = i * 16 + fr;
@@ -224,7 +329,8 @@ __device__ __forceinline__ void os_block(const GemmI8Args& p, const char* Bg, co
 
 // The tiles of a launch: MFR row fragments (128 or 144 rows) per tile, NW waves per workgroup, blocks of at most WMAX units.
 template <int EPI, int DB, int NW, int WMAX, int MFR>
-__device__ __forceinline__ void os_run(const GemmI8Args& p, const int8_t* __restrict__ Bf, const int n_items, const int parts, const int rotk) {
+__device__ __forceinline__ void os_run(const GemmI8Args& p, const int8_t* __restrict__ Bf, const int n_items, const int parts, const int rotk,
+                                       const RowTailArgs* ta = nullptr) {
     constexpr int OS_NT = NW * 64, BM = MFR * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int K = p.K, KS = K >> 6;
@@ -243,7 +349,7 @@ __device__ __forceinline__ void os_run(const GemmI8Args& p, const int8_t* __rest
     // that stream the same group's weights meet in that XCD's L2
     const int slot = (nwg & 7) == 0 ? (w & 7) * (nwg >> 3) + (w >> 3) : w;
     const bool st = EPI == EPI_SWIGLU && p.want_stats != 0;
-    const int U = p.N >> 5;  // units (pairs of fragment columns) per tile
+    const int U = EPI == EPI_QKR ? p.N >> 6 : p.N >> 5;  // units per tile: pairs of fragment columns (fused qkv projection: heads of 64 columns)
     if (st) {
         for (int i = tid; i < I64H_STAT_TAB; i += OS_NT) { tab_lo[i] = I64H_ORDERED_ZERO; tab_hi[i] = I64H_ORDERED_ZERO; }
     }
@@ -294,7 +400,14 @@ __device__ __forceinline__ void os_run(const GemmI8Args& p, const int8_t* __rest
         if (tid < BM) {
             const int r = row0 + min(tid, rows - 1);
             s_rs[tid] = p.row_scale[r];
-            s_rel[tid] = (EPI == EPI_SWIGLU && p.out_row_slot) ? p.out_row_slot[r] : 0;
+            if constexpr (EPI == EPI_QKR) {  // the row's position and its token row in the paged cache (-1: no block behind it)
+                const int pos = ta->positions[r];
+                const int pb = ta->block_table[(int64_t)ta->slot_ids[r] * ta->max_blocks_per_seq + pos / ta->block];
+                s_rel[tid] = pos;
+                ((int*)tab_lo)[tid] = pb >= 0 ? pb * ta->block + pos % ta->block : -1;
+            } else {
+                s_rel[tid] = (EPI == EPI_SWIGLU && p.out_row_slot) ? p.out_row_slot[r] : 0;
+            }
         }
         const float ws = p.w_scale[g];
         const char* Bg = (const char*)Bf + (int64_t)g * p.N * K;
@@ -321,15 +434,22 @@ __device__ __forceinline__ void os_run(const GemmI8Args& p, const int8_t* __rest
         // Workgroups that share a group's weights would otherwise walk the same addresses in step and queue on one L2 channel
         // after another: each wave starts at a K step of its own (integer sums are exact in any order).
         const int rk = (int)(((unsigned)slot * (unsigned)rotk + (unsigned)wid * (unsigned)(rotk != 0)) % (unsigned)KS);
-        if (WMAX >= 2) {
+        if constexpr (EPI == EPI_QKR) {
+            for (; cnt >= 1; --cnt, ++u) {  // one head (four fragment columns) per block
+                os_block<EPI, DB, 2, MFR>(p, Bg, KS, rk, 2 * u, g, row0, rows, ws, false, true, 0, 0, item, lane, sp, ta);
+                sp = nullptr;
+            }
+        } else if (WMAX >= 2) {
             for (; cnt >= 2; cnt -= 2, u += 2) {
                 os_block<EPI, DB, WMAX >= 2 ? 2 : 1, MFR>(p, Bg, KS, rk, u, g, row0, rows, ws, st, uni, sl0, sl1, item, lane, sp);
                 sp = nullptr;
             }
         }
-        for (; cnt >= 1; --cnt, ++u) {
-            os_block<EPI, DB, 1, MFR>(p, Bg, KS, rk, u, g, row0, rows, ws, st, uni, sl0, sl1, item, lane, sp);
-            sp = nullptr;
+        if constexpr (EPI != EPI_QKR) {
+            for (; cnt >= 1; --cnt, ++u) {
+                os_block<EPI, DB, 1, MFR>(p, Bg, KS, rk, u, g, row0, rows, ws, st, uni, sl0, sl1, item, lane, sp);
+                sp = nullptr;
+            }
         }
         sp = (p.stamps && item == slot) ? p.stamps + ((int64_t)w * 16 + wid) * 8 + lane : nullptr;
         if (sp && lane == 0) sp[6] = __builtin_amdgcn_s_memtime();
@@ -360,11 +480,11 @@ __device__ __forceinline__ int os_count_tiles(const GemmI8Args& p, const int BM,
 // of the grid - e.g. 8 groups of about 4096 rows are 260 tiles of 128 rows (two rounds of 256 workgroups) but 232 tiles of 144.
 template <int EPI, int DB, int NW, int WMAX>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4)))
-void gemm_i8_os_kernel(GemmI8Args p, const int8_t* __restrict__ Bf, int parts, int rotk, int tall_ok) {
+void gemm_i8_os_kernel(GemmI8Args p, const int8_t* __restrict__ Bf, int parts, int rotk, int tall_ok, RowTailArgs ta) {
     const int lane = threadIdx.x & 63, nwg = gridDim.x;
     if (tall_ok < 0) {  // long K (up to 2432): only 64 operand rows x K fit LDS
         const int t4 = __builtin_amdgcn_readfirstlane(os_count_tiles(p, 64, lane));
-        os_run<EPI, DB, NW, WMAX, 4>(p, Bf, t4 * parts, parts, rotk);
+        os_run<EPI, DB, NW, WMAX, 4>(p, Bf, t4 * parts, parts, rotk, &ta);
         return;
     }
     const int t8 = __builtin_amdgcn_readfirstlane(os_count_tiles(p, 128, lane));
@@ -375,8 +495,8 @@ void gemm_i8_os_kernel(GemmI8Args p, const int8_t* __restrict__ Bf, int parts, i
         const int r8 = (t8 * parts + nwg - 1) / nwg, r9 = (t9 * parts + nwg - 1) / nwg;
         tall = r9 * 9 < r8 * 8;
     }
-    if (tall) os_run<EPI, DB, NW, WMAX, 9>(p, Bf, t9 * parts, parts, rotk);
-    else os_run<EPI, DB, NW, WMAX, 8>(p, Bf, t8 * parts, parts, rotk);
+    if (tall) os_run<EPI, DB, NW, WMAX, 9>(p, Bf, t9 * parts, parts, rotk, &ta);
+    else os_run<EPI, DB, NW, WMAX, 8>(p, Bf, t8 * parts, parts, rotk, &ta);
 }
 
 static int g_os_grid = 256;  // tuning knob: workgroups of the persistent grid (one per CU)
@@ -389,7 +509,7 @@ static int g_os_tall = 1;  // tuning knob: 0 = tiles of 128 rows only
 static size_t os_lds_bytes(int K, int mfr) { return (size_t)(K / 64) * mfr * 1024 + mfr * 128 + 2 * I64H_STAT_TAB * 4 + 16 * 16 + 1024; }  // image, row arrays, table, per-wave words, prefetch sink
 
 template <int EPI, int DB, int NW, int WMAX>
-static int launch_os(const GemmI8Args& p, const int8_t* Bf, int n_items, int parts, hipStream_t st) {
+static int launch_os(const GemmI8Args& p, const int8_t* Bf, int n_items, int parts, hipStream_t st, const RowTailArgs* tail = nullptr) {
     const bool shortt = os_lds_bytes(p.K, 8) > 160 * 1024;  // long K: tiles of 64 rows
     const bool tall = !shortt && g_os_tall && os_lds_bytes(p.K, 9) <= 160 * 1024;
     const size_t lds = os_lds_bytes(p.K, shortt ? 4 : tall ? 9 : 8);
@@ -404,7 +524,10 @@ static int launch_os(const GemmI8Args& p, const int8_t* Bf, int n_items, int par
     }
     int nwg = n_items < g_os_grid ? n_items : g_os_grid;
     if (nwg >= 8) nwg &= ~7;
-    hipLaunchKernelGGL((gemm_i8_os_kernel<EPI, DB, NW, WMAX>), dim3((unsigned)nwg), dim3(NW * 64), lds, st, p, Bf, parts, g_os_rotk, shortt ? -1 : tall ? 1 : 0);
+    RowTailArgs ta;
+    memset(&ta, 0, sizeof(ta));
+    if (tail) ta = *tail;
+    hipLaunchKernelGGL((gemm_i8_os_kernel<EPI, DB, NW, WMAX>), dim3((unsigned)nwg), dim3(NW * 64), lds, st, p, Bf, parts, g_os_rotk, shortt ? -1 : tall ? 1 : 0, ta);
     I64H_CHECK_LAUNCH();
     return 0;
 }
@@ -456,6 +579,46 @@ int i64h_pack_weight_frags(const int8_t* B, int8_t* out, int32_t G, int32_t N, i
     hipLaunchKernelGGL(pack_frags_kernel, dim3((unsigned)((frags + 3) / 4)), dim3(256), 0, (hipStream_t)stream, B, out, frags, N / 16, K / 64);
     I64H_CHECK_LAUNCH();
     return 0;
+}
+
+// The fused qkv projection of a prefill-sized chunk on the operand-stationary kernel: i64h_gemm_i8_frags (plain epilogue) followed
+// by i64h_qk_norm_rope_kv, in one launch - the [rows, (nh + 2 kvh) * 64] fp32 projection is never stored.  Same bits in q_out and
+// in the cache.  head_dim 64 only; N = (num_heads + 2 * num_kv_heads) * 64.
+int i64h_gemm_i8_frags_qkv_rope_kv(const int8_t* A, const float* row_scale, const int8_t* B_frags, const float* w_scale, int64_t M_total,
+                                   int32_t K, const float* q_norm_w, const float* k_norm_w, float qk_eps, const float* rope_tab,
+                                   const int32_t* positions, const int32_t* slot_ids, const int32_t* block_table, int32_t max_blocks_per_seq,
+                                   float* q_out, void* k_cache, void* v_cache, int32_t kv_dtype, int32_t num_heads, int32_t num_kv_heads,
+                                   int32_t head_dim, int32_t block_size, void* stream) {
+    I64H_CHECK_ARG(A && row_scale && B_frags && w_scale && rope_tab && positions && slot_ids && block_table && q_out && k_cache && v_cache,
+                   "gemm_i8_frags_qkv_rope_kv: null argument");
+    I64H_CHECK_ARG(head_dim == 64 && num_heads > 0 && num_kv_heads > 0 && block_size > 0 && kv_dtype >= 0 && kv_dtype <= 4,
+                   "gemm_i8_frags_qkv_rope_kv: head_dim %d (64 only), heads %d / %d, block %d, kv dtype %d", head_dim, num_heads, num_kv_heads,
+                   block_size, kv_dtype);
+    const int N = (num_heads + 2 * num_kv_heads) * 64;
+    I64H_CHECK_ARG(M_total >= 0 && M_total < (1ll << 31), "gemm_i8_frags_qkv_rope_kv: bad row count");
+    I64H_CHECK_ARG(i64h_gemm_i8_frags_ok(N, K, EPI_STORE), "gemm_i8_frags_qkv_rope_kv: shape N=%d K=%d unsupported", N, K);
+    I64H_CHECK_ARG(((uintptr_t)A | (uintptr_t)B_frags | (uintptr_t)q_out | (uintptr_t)k_cache | (uintptr_t)v_cache | (uintptr_t)rope_tab |
+                    (uintptr_t)q_norm_w | (uintptr_t)k_norm_w) % 16 == 0, "gemm_i8_frags_qkv_rope_kv: 16-byte alignment");
+    if (M_total == 0) return 0;
+    GemmI8Args p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.row_scale = row_scale; p.w_scale = w_scale; p.G = 1; p.M_total = (int)M_total; p.N = N; p.K = K;
+    p.stamps = g_os_stamps;
+    RowTailArgs ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.positions = positions; ta.slot_ids = slot_ids; ta.block_table = block_table; ta.max_blocks_per_seq = max_blocks_per_seq;
+    ta.rope_tab = rope_tab; ta.qw = q_norm_w; ta.kw = k_norm_w; ta.qk_eps = qk_eps; ta.q_out = q_out; ta.k_cache = k_cache; ta.v_cache = v_cache;
+    ta.kv_dtype = kv_dtype; ta.nh = num_heads; ta.kvh = num_kv_heads; ta.block = block_size;
+    const int tile_rows = os_lds_bytes(K, 8) > 160 * 1024 ? 64 : OS_BM;
+    const int m_tiles = (int)((M_total + tile_rows - 1) / tile_rows);
+    const int heads = N / 64;
+    int parts = 1;
+    if (m_tiles < (g_os_grid * 3) / 4) {  // few row tiles: the heads of a tile are dealt to several workgroups
+        parts = (g_os_grid + m_tiles - 1) / m_tiles;
+        const int maxp = heads / 8 > 0 ? heads / 8 : 1;  // at least one head per wave
+        if (parts > maxp) parts = maxp;
+    }
+    return launch_os<EPI_QKR, 2, 8, 2>(p, B_frags, m_tiles * parts, parts, (hipStream_t)stream, &ta);
 }
 
 // i64h_gemm_i8 with the weights given as a fragment pack (same arguments otherwise, same results bit for bit)

@@ -3,6 +3,7 @@
 // write, RoPE (float and Q14), integer softmax (Q7, exp LUT) and the Q7 SiLU*up activation.
 #include "i64h_common.h"
 #include "i64h_gridsync.h"
+#include "i64h_kv_dev.h"
 #include <hip/hip_bf16.h>
 #include <hip/hip_fp16.h>
 
@@ -422,14 +423,6 @@ __global__ __launch_bounds__(FRQ_WAVES * 64) void fused_residual_norm_quant_kern
 // over the workgroup's waves.  q_out [n, nh, hd] fp32.  K (normed, rotated) and V (raw) go to the paged cache
 // (num_blocks, block, kvh, hd) at block_table[slot[t]][pos/block], pos % block.  rope_tab[pos][0..hd/2) = cos,
 // [hd/2..hd) = sin (fp32, built by the host with the same formula as the reference).
-template <typename KV>
-__device__ __forceinline__ KV to_kv(float v);
-template <> __device__ __forceinline__ float to_kv<float>(float v) { return v; }
-template <> __device__ __forceinline__ __hip_bfloat16 to_kv<__hip_bfloat16>(float v) { return __float2bfloat16(v); }
-template <> __device__ __forceinline__ __half to_kv<__half>(float v) { return __float2half(v); }
-template <> __device__ __forceinline__ F8E4 to_kv<F8E4>(float v) { return F8E4{f32_to_e4m3fn(v)}; }
-template <> __device__ __forceinline__ F8E5 to_kv<F8E5>(float v) { return F8E5{f32_to_e5m2(v)}; }
-
 #define QKR_MAX_HD 256
 template <typename KV>
 __global__ __launch_bounds__(256) void qk_norm_rope_kv_kernel(const float* __restrict__ qkv, const float* __restrict__ qw,
@@ -483,23 +476,6 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kv_kernel(const float* __res
 // butterfly order (dim ^ 32, ^ 16, ^ 8, ^ 4, ^ 2, ^ 1; additions commute, so every dim ends with the same bits as there): dim ^ 32 is
 // lane ^ 8 of the 16, dim ^ 16 lane ^ 4, dim ^ 8 lane ^ 2, dim ^ 4 lane ^ 1 (DPP moves inside the row of 16), dim ^ 2 and ^ 1 are the
 // lane's own components.  The rotation partner dim +- 32 is lane ^ 8 again.
-template <typename KV>
-__device__ __forceinline__ void kv_store4(KV* dst, const float (&o)[4]) {
-    if constexpr (sizeof(KV) == 4) {
-        *(float4*)dst = make_float4(o[0], o[1], o[2], o[3]);
-    } else if constexpr (sizeof(KV) == 2) {
-        unsigned short h[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { const KV t = to_kv<KV>(o[c]); h[c] = __builtin_bit_cast(unsigned short, t); }
-        *(uint2*)dst = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-    } else {
-        uint32_t w = 0;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { const KV t = to_kv<KV>(o[c]); w |= (uint32_t)__builtin_bit_cast(unsigned char, t) << (8 * c); }
-        *(uint32_t*)dst = w;
-    }
-}
-
 template <typename KV>
 __global__ __launch_bounds__(256) void qk_norm_rope_kv_vec_kernel(const float* __restrict__ qkv, const float* __restrict__ qw,
                                                                   const float* __restrict__ kw, float qk_eps, const float* __restrict__ rope_tab,

@@ -262,6 +262,7 @@ class I64MoEModel:
             self._bufs[key] = _Buffers(self.cfg, n, n_logit_rows, self.device, ep_world=self.ep.world if self.ep is not None else 0)
         return self._bufs[key]
 
+    FUSE_QKV_PREFILL = os.environ.get("I64H_FUSE_QKV_PREFILL", "1") != "0"  # prefill chunks: QK norm + RoPE + cache write in the qkv GEMM's epilogue
     FUSE_NORM_QUANT = os.environ.get("I64H_FUSE_NORM_QUANT", "1") != "0"  # prefill chunks: residual + norm + quantization in one launch
 
     def _fq_rows(self) -> int:
@@ -464,6 +465,16 @@ class I64MoEModel:
                 ops.gemm_i8_qkv_rope_kv(ops.gemm_desc(B.normed, W["qkv"].w_q, W["qkv"].w_s, B.qkv, a_slot_base=base + 0, stats=st, w_frags=self._wf(W["qkv"])),
                                         W["q_norm"], W["k_norm"], 1e-6, self.rope, positions, slot_ids, kvc.block_table, kvc.k[l], kvc.v[l],
                                         B.q, cfg.num_heads, cfg.num_kv_heads, cfg.head_dim)
+            elif (self.FUSE_QKV_PREFILL and n >= self.FRAGS_MIN_ROWS and cfg.head_dim == 64
+                  and ops.gemm_i8_frags_ok(W["qkv"].N, W["qkv"].K, ops.EPI_STORE)):
+                # prefill-sized chunk: the projection on the operand-stationary kernel with QK norm, RoPE and the cache write in its
+                # epilogue (a 64-column block is one head); the fp32 projection is never stored
+                if not fq:
+                    ops.call("i64h_quantize_dynamic", ops.ptr(B.normed), n, H, 0, 0, 0, base + 0, ops.ptr(st), ops.ptr(B.xa), ops.ptr(B.xs), 0,
+                             ops._stream())
+                ops.gemm_i8_frags_qkv_rope_kv(B.xa, B.xs, W["qkv"].frags(), W["qkv"].w_s, W["q_norm"], W["k_norm"], 1e-6, self.rope, positions,
+                                              slot_ids, kvc.block_table, kvc.k[l], kvc.v[l], cfg.num_heads, cfg.num_kv_heads, cfg.head_dim,
+                                              q_out=B.q)
             else:
                 if fq:
                     self._gemm_i8(B.xa, B.xs, W["qkv"], B.qkv)

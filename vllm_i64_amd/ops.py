@@ -428,6 +428,22 @@ def fused_residual_norm(h: torch.Tensor, norm_weight: Optional[torch.Tensor], ep
     return h_out, normed
 
 
+def gemm_i8_frags_qkv_rope_kv(a8: torch.Tensor, row_scale: torch.Tensor, w_frags: torch.Tensor, w_scale: torch.Tensor, q_norm_w, k_norm_w,
+                              qk_eps: float, rope_tab, positions, slot_ids, block_table, k_cache, v_cache, num_heads: int,
+                              num_kv_heads: int, head_dim: int, q_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The fused qkv projection of a prefill-sized chunk (quantized operand rows, weights as a fragment pack) with per-head
+    RMSNorm, RoPE and the paged-cache write in its epilogue: gemm_i8_frags + qk_norm_rope_kv in one launch, same bits."""
+    _chk(a8, torch.int8, "a8"), _chk(row_scale, torch.float32, "row_scale"), _chk(positions, torch.int32, "positions")
+    _chk(slot_ids, torch.int32, "slot_ids"), _chk(block_table, torch.int32, "block_table"), _chk(rope_tab, torch.float32, "rope_tab")
+    n, K = a8.shape
+    if q_out is None:
+        q_out = torch.empty(n, num_heads, head_dim, dtype=torch.float32, device=a8.device)
+    call("i64h_gemm_i8_frags_qkv_rope_kv", ptr(a8), ptr(row_scale), ptr(w_frags), ptr(w_scale), n, K, ptr(q_norm_w), ptr(k_norm_w),
+         float(qk_eps), ptr(rope_tab), ptr(positions), ptr(slot_ids), ptr(block_table), block_table.shape[1], ptr(q_out), ptr(k_cache),
+         ptr(v_cache), KV_DTYPE_CODE[k_cache.dtype], num_heads, num_kv_heads, head_dim, k_cache.shape[1], _stream())
+    return q_out
+
+
 def fused_residual_norm_quant_rows() -> int:
     """Rows one launch of fused_residual_norm_quant takes on this device."""
     return int(_lib.load().i64h_fused_residual_norm_quant_rows())
