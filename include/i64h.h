@@ -351,6 +351,7 @@ int i64h_fused_residual_norm(const float* h, const float* add, const float* moe_
  *   q_rows[t], q_scale[t]                         the call over all rows, slot = slot_base + slots[t][0] (slots NULL: slot_base)
  *   g_rows[gather_inv[k*n+t]], g_scale[...]       the (route, expert) bucket calls, slot = slot_base + slots[t][1+k], k < gather_k
  *                                                 (g_rows NULL: none)
+ * num_slots: the relative slot ids in `slots` lie in [0, num_slots) (0: unknown - the parameters are then derived per row).
  * n <= i64h_fused_residual_norm_quant_rows() (64 rows per workgroup, one workgroup per CU), H <= 1024.  sync: the zeroed sync
  * words of i64h_decode_sync_words(); a launch leaves them zero; launches sharing them must not overlap. */
 int64_t i64h_fused_residual_norm_quant_rows(void);
@@ -358,7 +359,7 @@ int i64h_fused_residual_norm_quant(const float* h, const float* add, const float
                                    const float* route_weights, int32_t top_k, float routed_scale, float shared_scale, float* h_out,
                                    const float* norm_weight, float eps, int64_t n, int32_t H, const int32_t* slots, int32_t slots_per_row,
                                    int32_t slot_base, uint32_t* stats, int8_t* q_rows, float* q_scale, const int32_t* gather_inv,
-                                   int32_t gather_k, int8_t* g_rows, float* g_scale, uint32_t* sync, void* stream);
+                                   int32_t gather_k, int8_t* g_rows, float* g_scale, uint32_t* sync, int32_t num_slots, void* stream);
 /* Per-head QK RMSNorm + rotate-half RoPE on the fused qkv projection, q to q_out, K/V into the paged cache
  * (model.py:172-184,212-219; core/kv_cache.py:294-316).  rope_tab [max_pos, head_dim] = cos(head_dim/2) | sin(head_dim/2).
  * kv_dtype 0 fp32, 1 fp16, 2 bf16, 3 fp8 e4m3fn, 4 fp8 e5m2 (one byte per element, the plain cast of the reference's

@@ -207,7 +207,7 @@ def test_fused_residual_norm_quant_equals_norm_then_quantize(dev, mode, n, H):
             g2 = torch.empty(top_k * n, H, dtype=torch.int8, device=dev)
             gs2 = torch.empty(top_k * n, dtype=torch.float32, device=dev)
             gk = dict(gather_inv=inv, gather_k=top_k, g_rows=g2, g_scale=gs2)
-        ho2 = ops.fused_residual_norm_quant(h, w, 1e-6, st_b, sync, q2, s2, slots=slots, slot_base=1, **kw, **gk)
+        ho2 = ops.fused_residual_norm_quant(h, w, 1e-6, st_b, sync, q2, s2, slots=slots, slot_base=1, num_slots=(1 + nb) if rep == 0 else 0, **kw, **gk)
         assert torch.equal(ho, ho2)
         assert all(torch.equal(a, b) for a, b in zip(ops.qparams(st_a, n_slots), ops.qparams(st_b, n_slots)))
         assert torch.equal(qs, s2) and torch.equal(qa, q2)

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(FRQ_WAVES * 64) void fused_residual_norm_quant_kern
                                                                                     uint32_t* __restrict__ stats, int8_t* __restrict__ qa,
                                                                                     float* __restrict__ qs, const int32_t* __restrict__ g_inv,
                                                                                     int g_k, int8_t* __restrict__ ga, float* __restrict__ gs,
-                                                                                    uint32_t* sync) {
+                                                                                    uint32_t* sync, int n_rel) {
     __shared__ uint32_t tab_lo[I64H_STAT_TAB], tab_hi[I64H_STAT_TAB];
     for (int i = threadIdx.x; i < I64H_STAT_TAB; i += FRQ_WAVES * 64) { tab_lo[i] = I64H_ORDERED_ZERO; tab_hi[i] = I64H_ORDERED_ZERO; }
     __syncthreads();
@@ -381,6 +381,25 @@ __global__ __launch_bounds__(FRQ_WAVES * 64) void fused_residual_norm_quant_kern
     gsy.nwg = gridDim.x;
     gsy.epoch = 0;
     grid_barrier(gsy);
+    // The parameters of a slot take a 64-word coherent read, a wave-wide fold and the fp64 arithmetic of choose_qparams_u7: with
+    // a known, small number of relative slots every wave derives a few of them ONCE into an LDS table (the rows of a workgroup
+    // report to many buckets, so deriving them per row and route costs more than everything else behind the barrier).
+    __shared__ float qt_scale[I64H_STAT_TAB], qt_inv[I64H_STAT_TAB];
+    __shared__ int qt_zp[I64H_STAT_TAB];
+    const bool tab = n_rel > 0 && n_rel <= I64H_STAT_TAB;
+    if (tab) {
+        for (int sidx = threadIdx.x >> 6; sidx < n_rel; sidx += FRQ_WAVES) {
+            const QParams qq = frq_params(stats, slot_base + sidx, lane);
+            if (lane == 0) { qt_scale[sidx] = qq.scale; qt_inv[sidx] = qq.inv_scale; qt_zp[sidx] = qq.zp; }
+        }
+        __syncthreads();
+    }
+    auto params_of = [&](int rel) {
+        QParams r;
+        if (tab && rel >= 0 && rel < n_rel) { r.scale = qt_scale[rel]; r.inv_scale = qt_inv[rel]; r.zp = qt_zp[rel]; }
+        else r = frq_params(stats, slot_base + rel, lane);
+        return r;
+    };
     int prev_slot = -1;
     QParams q;
     q.scale = 0.0f; q.inv_scale = 0.0f; q.zp = 0;
@@ -388,9 +407,9 @@ __global__ __launch_bounds__(FRQ_WAVES * 64) void fused_residual_norm_quant_kern
     for (int r = 0; r < FRR_RPW; ++r) {
         const int64_t t = t0 + r;
         if (t >= p.n) break;
-        const int slot = slot_base + (slots ? slots[t * spr] : 0);
+        const int slot = slots ? slots[t * spr] : 0;
         if (slot != prev_slot) {  // wave-uniform
-            q = frq_params(stats, slot, lane);
+            q = params_of(slot);
             prev_slot = slot;
         }
         if (lane == 0) qs[t] = q.scale;
@@ -402,9 +421,8 @@ __global__ __launch_bounds__(FRQ_WAVES * 64) void fused_residual_norm_quant_kern
         }
         if (ga) {
             for (int k = 0; k < g_k; ++k) {
-                const int gslot = slot_base + slots[t * spr + 1 + k];
                 const int64_t dst = g_inv[(int64_t)k * p.n + t];
-                const QParams gq = frq_params(stats, gslot, lane);
+                const QParams gq = params_of(slots[t * spr + 1 + k]);
                 if (lane == 0) gs[dst] = gq.scale;
                 uint32_t* gr = (uint32_t*)(ga + dst * H);
 #pragma unroll
@@ -762,7 +780,7 @@ int i64h_fused_residual_norm_quant(const float* h, const float* add, const float
                                    const float* route_weights, int32_t top_k, float routed_scale, float shared_scale, float* h_out,
                                    const float* norm_weight, float eps, int64_t n, int32_t H, const int32_t* slots, int32_t slots_per_row,
                                    int32_t slot_base, uint32_t* stats, int8_t* q_rows, float* q_scale, const int32_t* gather_inv,
-                                   int32_t gather_k, int8_t* g_rows, float* g_scale, uint32_t* sync, void* stream) {
+                                   int32_t gather_k, int8_t* g_rows, float* g_scale, uint32_t* sync, int32_t num_slots, void* stream) {
     I64H_CHECK_ARG(n >= 0 && H > 0 && H % 4 == 0 && H <= 1024, "fused_residual_norm_quant: H=%d unsupported (multiple of 4, <= 1024)", H);
     I64H_CHECK_ARG(n <= i64h_fused_residual_norm_quant_rows(), "fused_residual_norm_quant: %lld rows exceed one resident grid (%lld)", (long long)n,
                    (long long)i64h_fused_residual_norm_quant_rows());
@@ -784,7 +802,7 @@ int i64h_fused_residual_norm_quant(const float* h, const float* add, const float
     const int rows_per_wg = FRQ_WAVES * FRR_RPW;
     hipLaunchKernelGGL(fused_residual_norm_quant_kernel, dim3((unsigned)((n + rows_per_wg - 1) / rows_per_wg)), dim3(FRQ_WAVES * 64), 0,
                        (hipStream_t)stream, fa, norm_weight, slots, (int)slots_per_row, (int)slot_base, stats, q_rows, q_scale, gather_inv,
-                       (int)gather_k, g_rows, g_scale, sync);
+                       (int)gather_k, g_rows, g_scale, sync, slots ? (int)num_slots : 1);
     I64H_CHECK_LAUNCH();
     return 0;
 }

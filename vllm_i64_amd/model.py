@@ -504,7 +504,7 @@ class I64MoEModel:
                 if cfg.is_moe and B.plan.rows > 0:  # the (route, expert) bucket calls' rows, gathered into bucket order
                     gk = dict(gather_inv=B.plan.inv[l], gather_k=cfg.top_k, g_rows=B.ea, g_scale=B.es)
                 ops.fused_residual_norm_quant(B.h, W["ln2"], eps, st, self.dec_sync, B.xa, B.xs, add=B.o, h_out=B.h, slots=ln2_slots,
-                                              slot_base=ln2_base, **gk)
+                                              slot_base=ln2_base, num_slots=1 + self.nb, **gk)
             else:
                 ops.fused_residual_norm(B.h, W["ln2"], eps, add=B.o, h_out=B.h, normed=B.normed, slots=ln2_slots, slot_base=ln2_base,
                                         stats=ln2_stats)

@@ -455,9 +455,9 @@ def fused_residual_norm_quant(h: torch.Tensor, norm_weight: torch.Tensor, eps: f
                               moe_shared: Optional[torch.Tensor] = None, route_weights: Sequence[float] = (), routed_scale: float = 1.0,
                               shared_scale: float = 1.0, h_out: Optional[torch.Tensor] = None, slots: Optional[torch.Tensor] = None,
                               slot_base: int = 0, gather_inv: Optional[torch.Tensor] = None, gather_k: int = 0,
-                              g_rows: Optional[torch.Tensor] = None, g_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+                              g_rows: Optional[torch.Tensor] = None, g_scale: Optional[torch.Tensor] = None, num_slots: int = 0) -> torch.Tensor:
     """fused_residual_norm + quantize_dynamic of every Linear call that reads the normalised rows, in one launch (the
-    normalised rows themselves are not stored).  Returns h_out."""
+    normalised rows themselves are not stored).  num_slots: the relative slot ids lie in [0, num_slots) (0: unknown).  Returns h_out."""
     _chk(h, torch.float32, "h"), _chk(q_rows, torch.int8, "q_rows"), _chk(q_scale, torch.float32, "q_scale")
     n, H = h.shape
     if h_out is None:
@@ -466,7 +466,7 @@ def fused_residual_norm_quant(h: torch.Tensor, norm_weight: torch.Tensor, eps: f
     spr = 1 if slots is None else (slots.shape[1] if slots.dim() == 2 else 1)
     call("i64h_fused_residual_norm_quant", ptr(h), ptr(add), ptr(moe_rows), ptr(moe_inv), ptr(moe_shared), ctypes.addressof(rw),
          len(route_weights), float(routed_scale), float(shared_scale), ptr(h_out), ptr(norm_weight), float(eps), n, H, ptr(slots), spr,
-         slot_base, ptr(stats), ptr(q_rows), ptr(q_scale), ptr(gather_inv), gather_k, ptr(g_rows), ptr(g_scale), ptr(sync), _stream())
+         slot_base, ptr(stats), ptr(q_rows), ptr(q_scale), ptr(gather_inv), gather_k, ptr(g_rows), ptr(g_scale), ptr(sync), num_slots, _stream())
     return h_out
 
 
