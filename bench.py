@@ -380,11 +380,13 @@ def main():
         # folded in the epilogue.  One event pair around one launch per layer; a second series on ONE layer's weights (which
         # then stay cached) is reported beside it.
         Lr = cfg.num_layers
+        fp8_os = bool(fp8 and gm.FP8_FRAGS and R >= gm.FRAGS_MIN_ROWS and ops.gemm_i8_frags_ok(2 * cfg.expert_inter, cfg.hidden_size, ops.EPI_SWIGLU))
 
         def launch(l):
             if fp8:
-                ops.gemm_fp8(a8, rs, gm.layers[l]["exp_gu"].w_q, gm.layers[l]["exp_gu"].w_s, o8, group_offsets=Bp.plan.expert_offsets[l],
-                             epilogue=ops.EPI_SWIGLU)
+                Wl = gm.layers[l]["exp_gu"]
+                ops.gemm_fp8(a8, rs, Wl.w_q, Wl.w_s, o8, group_offsets=Bp.plan.expert_offsets[l], epilogue=ops.EPI_SWIGLU,
+                             w_frags=Wl.frags(True) if fp8_os else None)   # the runner's own choice of kernel
             else:
                 gm._gemm_i8(a8, rs, gm.layers[l]["exp_gu"], o8, group_offsets=Bp.plan.expert_offsets[l], epilogue=ops.EPI_SWIGLU,
                             row_slot=Bp.plan.sorted_bucket[l], slot_base=l * gm.spl + 4 + gm.nb, stats=gm.stats)  # the runner's own dispatch
@@ -405,8 +407,9 @@ def main():
         g_ms_same = series(lambda j: 0)
         g_ops = 2.0 * R * (2 * cfg.expert_inter) * cfg.hidden_size
         tops = g_ops / (g_ms * 1e-3) / 1e12
-        mfma = {"bound": "mfma", "kernel": ("gemm_fp8_kernel<SWIGLU> (v_mfma_f32_16x16x32_fp8_fp8: the non-scaled form, which runs at the bf16 "
-                                            "rate, half the peak below)" if fp8 else
+        mfma = {"bound": "mfma", "kernel": ((("gemm_i8_os_kernel<SWIGLU, e4m3> (operand-stationary, weights as a fragment pack; " if fp8_os else
+                                              "gemm_fp8_kernel<SWIGLU> (") + "v_mfma_f32_16x16x32_fp8_fp8: the non-scaled form, which runs at the "
+                                             "bf16 rate, half the peak below)") if fp8 else
                                            ("gemm_i8_os_kernel<SWIGLU> (operand-stationary, weights as a fragment pack)"
                                             if R >= gm.FRAGS_MIN_ROWS and ops.gemm_i8_frags_ok(2 * cfg.expert_inter, cfg.hidden_size, ops.EPI_SWIGLU)
                                             else "gemm_i8_rs_kernel<SWIGLU>")) +

@@ -146,6 +146,12 @@ int i64h_pack_weight_frags(const int8_t* B, int8_t* out, int32_t G, int32_t N, i
 int i64h_gemm_i8_frags(const int8_t* A, const float* row_scale, const int8_t* B_frags, const float* w_scale, const int32_t* group_offsets,
                        int32_t num_groups, int64_t M_total, int32_t N, int32_t K, float* C, int32_t epilogue, const int32_t* row_slot,
                        int32_t slot_base, uint32_t* stats, const float* col_scale, void* stream);
+/* i64h_gemm_fp8_ex on the operand-stationary kernel (prefill-sized calls; fp8_linear / fp8_fused_gate_up of vllm_i64/core/fp8.py:169-249
+ * with the weights as a fragment pack of the e4m3 bytes): same arguments and meaning, same shape conditions as i64h_gemm_i8_frags_ok;
+ * the fp32 sums run in the kernel's own order (last-bit differences from the tiled kernel). */
+int i64h_gemm_fp8_frags(const uint8_t* A, const float* a_scale, const int32_t* a_src_row, int32_t a_src_mod, const uint8_t* B_frags,
+                        const float* b_scale, const int32_t* group_offsets, int32_t num_groups, int64_t M, int32_t N, int32_t K, float* C,
+                        const int32_t* c_row_map, int32_t epilogue, void* stream);
 /* The fused qkv projection of a prefill-sized chunk: i64h_gemm_i8_frags (plain epilogue) + i64h_qk_norm_rope_kv in one launch - the
  * linear of the attention block with q/k RMSNorm, RoPE and the cache write of model.py:203-236 in its epilogue (a 64-column block
  * of the operand-stationary kernel is one head); the fp32 projection is never stored; same bits in q_out and in the cache.

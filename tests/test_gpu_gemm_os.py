@@ -238,3 +238,37 @@ def test_fused_qkv_projection_with_norm_rope_and_cache_write_in_the_epilogue(dev
     assert torch.equal(q1, q2)
     assert torch.equal(kc1.view(torch.uint8), kc2.view(torch.uint8)) and torch.equal(vc1.view(torch.uint8), vc2.view(torch.uint8))
     assert not torch.equal(kc1.view(torch.uint8), caches()[0].view(torch.uint8))  # the cache really was written
+
+
+@pytest.mark.parametrize("M,N,K,G,epi,gather", [(5000, 1024, 448, 4, 0, False), (4600, 896, 1024, 4, 1, True), (4300, 1536, 1024, 1, 0, False),
+                                                (4200, 1024, 1792, 1, 0, False), (6000, 512, 1024, 3, 1, False), (4500, 1024, 448, 4, 0, True)])
+def test_fp8_operands_on_the_operand_stationary_kernel_against_the_tiled_kernel(dev, M, N, K, G, epi, gather):
+    """e4m3 operands (per-token and per-output-channel scales, grouped, optional operand-row gather and output-row scatter,
+    SwiGLU) on the operand-stationary kernel against the tiled e4m3 kernel: the products are exact, the fp32 sums run in
+    different orders - bound: 2e-5 of the row's magnitude (what one matrix-core sum deviates from the exact sum), and against a
+    float64 product of the decoded operands."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    src_rows = M // 2 if gather else M
+    x = torch.randn(src_rows, K, generator=g).to(dev)
+    w = (torch.randn(G * N, K, generator=g) * 0.05).to(dev)
+    xq, xs = ops.quantize_fp8_rows(x)
+    wq, wsc = ops.quantize_fp8_rows(w)
+    wq, wsc = wq.view(G, N, K), wsc.view(G, N)
+    wf = ops.pack_weight_frags(wq)
+    off = None
+    if G > 1:
+        cnt = torch.bincount(torch.randint(0, G, (M,), generator=g), minlength=G)
+        off = torch.cat([torch.zeros(1, dtype=torch.long), cnt.cumsum(0)]).to(torch.int32).to(dev)
+    kw = {}
+    if gather:
+        kw.update(a_src_row=torch.randint(0, 4 * src_rows, (M,), generator=g).to(torch.int32).to(dev), a_src_mod=src_rows)
+        if not epi:
+            kw["c_row_map"] = torch.randperm(M, generator=g).to(torch.int32).to(dev)
+    out_n = N // 2 if epi else N
+    ref = ops.gemm_fp8(xq, xs, wq, wsc, torch.zeros(M, out_n, device=dev), m=M, group_offsets=off, epilogue=epi, **kw)
+    got = ops.gemm_fp8(xq, xs, wq, wsc, torch.zeros(M, out_n, device=dev), m=M, group_offsets=off, epilogue=epi, w_frags=wf, **kw)
+    scale = ref.abs().amax(dim=1, keepdim=True).clamp_min(1e-6)
+    rel = float(((got - ref).abs() / scale).max())
+    print(f"fp8 operand-stationary vs tiled: max difference {rel:.2e} of the row magnitude")
+    assert rel <= 4e-5

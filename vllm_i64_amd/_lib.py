@@ -80,6 +80,7 @@ SIGNATURES: Dict[str, str] = {
     "i64h_pack_weight_frags": "ppiiip",
     "i64h_gemm_i8_frags": "pppppiliipipippp",
     "i64h_gemm_i8_frags_ok": "iii",
+    "i64h_gemm_fp8_frags": "pppipppiliippip",
     "i64h_gemm_i8_frags_qkv_rope_kv": "pppplippfppppipppiiiiip",
     "i64h_set_gemm_os": "ii",
     "i64h_set_gemm_os_rotation": "i",

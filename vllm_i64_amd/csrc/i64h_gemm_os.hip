@@ -54,9 +54,14 @@ __global__ __launch_bounds__(256) void pack_frags_kernel(const int8_t* __restric
     *(v4i*)(out + f * 1024 + lane * 16) = v;
 }
 
+template <bool F8> struct OsAcc { typedef v4i type; };
+template <> struct OsAcc<true> { typedef v4f type; };
+__device__ __forceinline__ long os_lo64(const v4i& v) { return (long)(((unsigned long long)(unsigned)v.y << 32) | (unsigned)v.x); }
+__device__ __forceinline__ long os_hi64(const v4i& v) { return (long)(((unsigned long long)(unsigned)v.w << 32) | (unsigned)v.z); }
+
 // One block of a tile: all 128 rows x W units, a unit being two weight fragment columns (SwiGLU: 16 gate columns and their 16 up
 // partners; plain: 32 adjacent columns).  u0 = first unit; sp = this wave's stamp slots or nullptr.
-template <int EPI, int DB, int W, int MFR>
+template <int EPI, int DB, int W, int MFR, bool F8 = false>
 __device__ __forceinline__ void os_block(const GemmI8Args& p, const char* Bg, const int KS, const int rk, const int u0, const int g, const int row0,
                                          const int rows, const float ws, const bool st, const bool uni, const int sl0, const int sl1,
                                          const int item, const int lane, unsigned long long* sp, const RowTailArgs* ta = nullptr) {
@@ -88,11 +93,14 @@ __device__ __forceinline__ void os_block(const GemmI8Args& p, const char* Bg, co
     auto bfrag = [&](int j, int kk) { return *(const v4i*)(Bg + (bo[j] + (uint32_t)kk * 1024u) + lane16); };
     auto afrag = [&](int i, int kk) { return *(const v4i*)(img + (uint32_t)(kk * MFR + i) * 1024u + lane16); };
 
-    v4i acc[MFR][NJ];
+    // int8 operands: exact int32 sums; e4m3 operands (F8): fp32 sums of exact products, two 32-deep matrix-core steps per 64 bytes
+    // of K (a lane's low and high 8 bytes - both operands are cut the same way, so the sum runs over all of K)
+    using AccV = typename OsAcc<F8>::type;
+    AccV acc[MFR][NJ];
 #pragma unroll
     for (int i = 0; i < MFR; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = (v4i){0, 0, 0, 0};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (AccV){0, 0, 0, 0};
     v4i bq[DB][NJ], af[MFR];
     {
         // the weight fragments of the first DB steps, oldest first: the counted waits of the loop rely on this order
@@ -113,8 +121,16 @@ __device__ __forceinline__ void os_block(const GemmI8Args& p, const char* Bg, co
             const int kn = kof(k + 1);
 #pragma unroll
             for (int i = 0; i < MFR; ++i) {
+                if constexpr (F8) {
+                    const long a0 = os_lo64(af[i]), a1 = os_hi64(af[i]);
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bq[u][j], af[i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(os_lo64(bq[u][j]), a0, acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(os_hi64(bq[u][j]), a1, acc[i][j], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(bq[u][j], af[i], acc[i][j], 0, 0, 0);
+                }
                 af[i] = afrag(i, kn);
             }
             if (more) {
@@ -251,7 +267,7 @@ __device__ __forceinline__ void os_block(const GemmI8Args& p, const char* Bg, co
             if (rr >= rows) continue;
             const float qs = s_rs[rr];
             const float m = qs * ws;
-            float* crow = p.C + (int64_t)(row0 + rr) * p.N;
+            float* crow = p.C + (int64_t)((F8 && p.c_row_map) ? p.c_row_map[row0 + rr] : row0 + rr) * p.N;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int c0 = cj[j] * 16 + fq * 4;
@@ -277,9 +293,16 @@ __device__ __forceinline__ void os_block(const GemmI8Args& p, const char* Bg, co
                 float v[4];
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
-                    const float gate = (float)acc[i][j][reg] * m;
-                    const float up = (float)acc[i][j + W][reg] * m;
-                    v[reg] = os_silu(gate) * up;
+                    if constexpr (F8) {  // per-output-channel weight scales; the expression of the tiled e4m3 kernel
+                        const float qs = rok ? s_rs[rr] : 0.0f;
+                        const float gate = (float)acc[i][j][reg] * (qs * p.col_scale[(int64_t)g * p.N + c0 + reg]);
+                        const float up = (float)acc[i][j + W][reg] * (qs * p.col_scale[(int64_t)g * p.N + I + c0 + reg]);
+                        v[reg] = (gate / (1.0f + expf(-gate))) * up;
+                    } else {
+                        const float gate = (float)acc[i][j][reg] * m;
+                        const float up = (float)acc[i][j + W][reg] * m;
+                        v[reg] = os_silu(gate) * up;
+                    }
                 }
                 if (rok) {
                     *(float4*)(crow + c0) = make_float4(v[0], v[1], v[2], v[3]);
@@ -328,7 +351,7 @@ __device__ __forceinline__ void os_block(const GemmI8Args& p, const char* Bg, co
 }
 
 // The tiles of a launch: MFR row fragments (128 or 144 rows) per tile, NW waves per workgroup, blocks of at most WMAX units.
-template <int EPI, int DB, int NW, int WMAX, int MFR>
+template <int EPI, int DB, int NW, int WMAX, int MFR, bool F8 = false>
 __device__ __forceinline__ void os_run(const GemmI8Args& p, const int8_t* __restrict__ Bf, const int n_items, const int parts, const int rotk,
                                        const RowTailArgs* ta = nullptr) {
     constexpr int OS_NT = NW * 64, BM = MFR * 16;
@@ -392,24 +415,33 @@ __device__ __forceinline__ void os_run(const GemmI8Args& p, const int8_t* __rest
         }
 #endif
         // the tile's operand rows -> fragment image: the KS x MFR fragments are dealt to the waves in image order
+        // gathered operand rows (the e4m3 launches only): the tile's source rows first - one index load per row, not per fragment
+        const bool gather = F8 && p.a_src_row != nullptr;
+        if constexpr (F8) {
+            if (gather) {
+                if (tid < BM) s_rel[tid] = (int)((uint32_t)p.a_src_row[row0 + min(tid, rows - 1)] % (uint32_t)p.a_src_mod);
+                __syncthreads();
+            }
+        }
         for (int f = wid; f < KS * MFR; f += NW) {
             const int ks = f / MFR, i = f - ks * MFR;
             const int r = min(i * 16 + fr, rows - 1);  // rows past the tile's end repeat its last row (never stored)
-            os_glds16((const char*)p.A + (int64_t)(row0 + r) * K + ks * 64 + fq * 16, img + f * 1024);
+            const int64_t src = gather ? (int64_t)s_rel[r] : (int64_t)(row0 + r);
+            os_glds16((const char*)p.A + src * K + ks * 64 + fq * 16, img + f * 1024);
         }
         if (tid < BM) {
-            const int r = row0 + min(tid, rows - 1);
+            const int r = gather ? s_rel[min(tid, rows - 1)] : row0 + min(tid, rows - 1);
             s_rs[tid] = p.row_scale[r];
             if constexpr (EPI == EPI_QKR) {  // the row's position and its token row in the paged cache (-1: no block behind it)
                 const int pos = ta->positions[r];
                 const int pb = ta->block_table[(int64_t)ta->slot_ids[r] * ta->max_blocks_per_seq + pos / ta->block];
                 s_rel[tid] = pos;
                 ((int*)tab_lo)[tid] = pb >= 0 ? pb * ta->block + pos % ta->block : -1;
-            } else {
+            } else if (!gather) {  // (with gathered rows the array holds the source rows; such launches fold no statistics)
                 s_rel[tid] = (EPI == EPI_SWIGLU && p.out_row_slot) ? p.out_row_slot[r] : 0;
             }
         }
-        const float ws = p.w_scale[g];
+        const float ws = p.w_scale ? p.w_scale[g] : 1.0f;
         const char* Bg = (const char*)Bf + (int64_t)g * p.N * K;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -436,18 +468,18 @@ __device__ __forceinline__ void os_run(const GemmI8Args& p, const int8_t* __rest
         const int rk = (int)(((unsigned)slot * (unsigned)rotk + (unsigned)wid * (unsigned)(rotk != 0)) % (unsigned)KS);
         if constexpr (EPI == EPI_QKR) {
             for (; cnt >= 1; --cnt, ++u) {  // one head (four fragment columns) per block
-                os_block<EPI, DB, 2, MFR>(p, Bg, KS, rk, 2 * u, g, row0, rows, ws, false, true, 0, 0, item, lane, sp, ta);
+                os_block<EPI, DB, 2, MFR, F8>(p, Bg, KS, rk, 2 * u, g, row0, rows, ws, false, true, 0, 0, item, lane, sp, ta);
                 sp = nullptr;
             }
         } else if (WMAX >= 2) {
             for (; cnt >= 2; cnt -= 2, u += 2) {
-                os_block<EPI, DB, WMAX >= 2 ? 2 : 1, MFR>(p, Bg, KS, rk, u, g, row0, rows, ws, st, uni, sl0, sl1, item, lane, sp);
+                os_block<EPI, DB, WMAX >= 2 ? 2 : 1, MFR, F8>(p, Bg, KS, rk, u, g, row0, rows, ws, st, uni, sl0, sl1, item, lane, sp);
                 sp = nullptr;
             }
         }
         if constexpr (EPI != EPI_QKR) {
             for (; cnt >= 1; --cnt, ++u) {
-                os_block<EPI, DB, 1, MFR>(p, Bg, KS, rk, u, g, row0, rows, ws, st, uni, sl0, sl1, item, lane, sp);
+                os_block<EPI, DB, 1, MFR, F8>(p, Bg, KS, rk, u, g, row0, rows, ws, st, uni, sl0, sl1, item, lane, sp);
                 sp = nullptr;
             }
         }
@@ -478,13 +510,13 @@ __device__ __forceinline__ int os_count_tiles(const GemmI8Args& p, const int BM,
 
 // The tile height is chosen per launch, on the device (the group sizes live there): 128 rows, or 144 when that needs fewer rounds
 // of the grid - e.g. 8 groups of about 4096 rows are 260 tiles of 128 rows (two rounds of 256 workgroups) but 232 tiles of 144.
-template <int EPI, int DB, int NW, int WMAX>
+template <int EPI, int DB, int NW, int WMAX, bool F8 = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4)))
 void gemm_i8_os_kernel(GemmI8Args p, const int8_t* __restrict__ Bf, int parts, int rotk, int tall_ok, RowTailArgs ta) {
     const int lane = threadIdx.x & 63, nwg = gridDim.x;
     if (tall_ok < 0) {  // long K (up to 2432): only 64 operand rows x K fit LDS
         const int t4 = __builtin_amdgcn_readfirstlane(os_count_tiles(p, 64, lane));
-        os_run<EPI, DB, NW, WMAX, 4>(p, Bf, t4 * parts, parts, rotk, &ta);
+        os_run<EPI, DB, NW, WMAX, 4, F8>(p, Bf, t4 * parts, parts, rotk, &ta);
         return;
     }
     const int t8 = __builtin_amdgcn_readfirstlane(os_count_tiles(p, 128, lane));
@@ -495,8 +527,8 @@ void gemm_i8_os_kernel(GemmI8Args p, const int8_t* __restrict__ Bf, int parts, i
         const int r8 = (t8 * parts + nwg - 1) / nwg, r9 = (t9 * parts + nwg - 1) / nwg;
         tall = r9 * 9 < r8 * 8;
     }
-    if (tall) os_run<EPI, DB, NW, WMAX, 9>(p, Bf, t9 * parts, parts, rotk, &ta);
-    else os_run<EPI, DB, NW, WMAX, 8>(p, Bf, t8 * parts, parts, rotk, &ta);
+    if (tall) os_run<EPI, DB, NW, WMAX, 9, F8>(p, Bf, t9 * parts, parts, rotk, &ta);
+    else os_run<EPI, DB, NW, WMAX, 8, F8>(p, Bf, t8 * parts, parts, rotk, &ta);
 }
 
 static int g_os_grid = 256;  // tuning knob: workgroups of the persistent grid (one per CU)
@@ -508,7 +540,7 @@ static int g_os_rotk = 0;  // tuning knob: per-workgroup rotation of the K order
 static int g_os_tall = 1;  // tuning knob: 0 = tiles of 128 rows only
 static size_t os_lds_bytes(int K, int mfr) { return (size_t)(K / 64) * mfr * 1024 + mfr * 128 + 2 * I64H_STAT_TAB * 4 + 16 * 16 + 1024; }  // image, row arrays, table, per-wave words, prefetch sink
 
-template <int EPI, int DB, int NW, int WMAX>
+template <int EPI, int DB, int NW, int WMAX, bool F8 = false>
 static int launch_os(const GemmI8Args& p, const int8_t* Bf, int n_items, int parts, hipStream_t st, const RowTailArgs* tail = nullptr) {
     const bool shortt = os_lds_bytes(p.K, 8) > 160 * 1024;  // long K: tiles of 64 rows
     const bool tall = !shortt && g_os_tall && os_lds_bytes(p.K, 9) <= 160 * 1024;
@@ -518,7 +550,7 @@ static int launch_os(const GemmI8Args& p, const int8_t* Bf, int n_items, int par
         int device = 0;
         I64H_CHECK_HIP(hipGetDevice(&device));
         if (device < 0 || device >= 64 || !raised[device]) {
-            I64H_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_i8_os_kernel<EPI, DB, NW, WMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            I64H_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_i8_os_kernel<EPI, DB, NW, WMAX, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             if (device >= 0 && device < 64) raised[device] = true;
         }
     }
@@ -527,7 +559,7 @@ static int launch_os(const GemmI8Args& p, const int8_t* Bf, int n_items, int par
     RowTailArgs ta;
     memset(&ta, 0, sizeof(ta));
     if (tail) ta = *tail;
-    hipLaunchKernelGGL((gemm_i8_os_kernel<EPI, DB, NW, WMAX>), dim3((unsigned)nwg), dim3(NW * 64), lds, st, p, Bf, parts, g_os_rotk, shortt ? -1 : tall ? 1 : 0, ta);
+    hipLaunchKernelGGL((gemm_i8_os_kernel<EPI, DB, NW, WMAX, F8>), dim3((unsigned)nwg), dim3(NW * 64), lds, st, p, Bf, parts, g_os_rotk, shortt ? -1 : tall ? 1 : 0, ta);
     I64H_CHECK_LAUNCH();
     return 0;
 }
@@ -579,6 +611,41 @@ int i64h_pack_weight_frags(const int8_t* B, int8_t* out, int32_t G, int32_t N, i
     hipLaunchKernelGGL(pack_frags_kernel, dim3((unsigned)((frags + 3) / 4)), dim3(256), 0, (hipStream_t)stream, B, out, frags, N / 16, K / 64);
     I64H_CHECK_LAUNCH();
     return 0;
+}
+
+// e4m3fn operands on the same kernel (the prefill-sized form of i64h_gemm_fp8_ex: per-token activation scales, per-output-channel
+// weight scales, optional operand-row gather and output-row scatter, grouped, SwiGLU): C = (sum_k A * B) * (a_scale[row] *
+// b_scale[col]) with fp32 sums on v_mfma_f32_16x16x32_fp8_fp8.  B_frags = i64h_pack_weight_frags of the e4m3 bytes.
+int i64h_gemm_fp8_frags(const uint8_t* A, const float* a_scale, const int32_t* a_src_row, int32_t a_src_mod, const uint8_t* B_frags,
+                        const float* b_scale, const int32_t* group_offsets, int32_t num_groups, int64_t M, int32_t N, int32_t K, float* C,
+                        const int32_t* c_row_map, int32_t epilogue, void* stream) {
+    I64H_CHECK_ARG(A && a_scale && B_frags && b_scale && C, "gemm_fp8_frags: null argument");
+    I64H_CHECK_ARG(M >= 0 && M < (1ll << 31) && num_groups >= 1 && num_groups <= MAX_GROUPS, "gemm_fp8_frags: bad sizes");
+    I64H_CHECK_ARG(i64h_gemm_i8_frags_ok(N, K, epilogue), "gemm_fp8_frags: shape N=%d K=%d epilogue=%d unsupported", N, K, epilogue);
+    I64H_CHECK_ARG(((uintptr_t)A | (uintptr_t)B_frags | (uintptr_t)C) % 16 == 0, "gemm_fp8_frags: 16-byte alignment");
+    I64H_CHECK_ARG(a_src_row == nullptr || a_src_mod > 0, "gemm_fp8_frags: a_src_row needs a_src_mod > 0");
+    I64H_CHECK_ARG(c_row_map == nullptr || epilogue == EPI_STORE, "gemm_fp8_frags: an output row map needs the plain epilogue");
+    if (M == 0) return 0;
+    GemmI8Args p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.row_scale = a_scale; p.a_src_row = a_src_row; p.a_src_mod = a_src_mod; p.col_scale = b_scale; p.c_row_map = c_row_map;
+    p.group_off = group_offsets; p.G = num_groups; p.M_total = (int)M; p.N = N; p.K = K; p.C = C;
+    p.stamps = g_os_stamps;
+    const int G = group_offsets ? num_groups : 1;
+    const int tile_rows = os_lds_bytes(K, 8) > 160 * 1024 ? 64 : OS_BM;
+    const int m_tiles = (int)((M + tile_rows - 1) / tile_rows) + (group_offsets ? G : 0);
+    const int units = N / 32;
+    int parts = 1;
+    if (m_tiles < (g_os_grid * 3) / 4) {
+        parts = (g_os_grid + m_tiles - 1) / m_tiles;
+        const int maxp = units / 16 > 0 ? units / 16 : 1;
+        if (parts > maxp) parts = maxp;
+    }
+    const int n_items = m_tiles * parts;
+    hipStream_t st = (hipStream_t)stream;
+    if (epilogue == EPI_SWIGLU) return launch_os<EPI_SWIGLU, 2, 8, 2, true>(p, (const int8_t*)B_frags, n_items, parts, st);
+    if (tile_rows == 64) return launch_os<EPI_STORE, 2, 8, 2, true>(p, (const int8_t*)B_frags, n_items, parts, st);
+    return launch_os<EPI_STORE, 2, 12, 1, true>(p, (const int8_t*)B_frags, n_items, parts, st);
 }
 
 // The fused qkv projection of a prefill-sized chunk on the operand-stationary kernel: i64h_gemm_i8_frags (plain epilogue) followed

@@ -262,6 +262,7 @@ class I64MoEModel:
             self._bufs[key] = _Buffers(self.cfg, n, n_logit_rows, self.device, ep_world=self.ep.world if self.ep is not None else 0)
         return self._bufs[key]
 
+    FP8_FRAGS = os.environ.get("I64H_FP8_FRAGS", "1") != "0"  # e4m3 runner: prefill-sized Linears on the operand-stationary kernel
     FUSE_QKV_PREFILL = os.environ.get("I64H_FUSE_QKV_PREFILL", "1") != "0"  # prefill chunks: QK norm + RoPE + cache write in the qkv GEMM's epilogue
     FUSE_NORM_QUANT = os.environ.get("I64H_FUSE_NORM_QUANT", "1") != "0"  # prefill chunks: residual + norm + quantization in one launch
 
@@ -579,7 +580,12 @@ class I64MoEModel:
                 return ops.gemm_fp8_rows(x, Wp.w_q, Wp.w_s, out, w_frags=Wp.frags(kw.get("epilogue", ops.EPI_STORE) == ops.EPI_SWIGLU), **kw)
             if x is not None:
                 ops.quantize_fp8_rows(x, xq, xs)
-            return ops.gemm_fp8(xq, xs, Wp.w_q, Wp.w_s, out, **kw)
+            rows = kw.get("m") or xq.shape[0]
+            epi = kw.get("epilogue", ops.EPI_STORE)
+            wf = None
+            if self.FP8_FRAGS and rows >= self.FRAGS_MIN_ROWS and ops.gemm_i8_frags_ok(Wp.w_q.shape[1], K, epi):
+                wf = Wp.frags(epi == ops.EPI_SWIGLU)   # prefill-sized call: the operand-stationary kernel on the weight's fragment pack
+            return ops.gemm_fp8(xq, xs, Wp.w_q, Wp.w_s, out, w_frags=wf, **kw)
 
         for l, W in enumerate(self.layers):
             if record is not None:

@@ -284,13 +284,18 @@ def quantize_fp8_rows(x: torch.Tensor, q: Optional[torch.Tensor] = None, scale: 
 
 
 def gemm_fp8(a: torch.Tensor, a_scale: torch.Tensor, w: torch.Tensor, w_scale: torch.Tensor, out: torch.Tensor, *, m: Optional[int] = None,
-             a_src_row=None, a_src_mod: int = 0, group_offsets=None, c_row_map=None, epilogue: int = EPI_STORE) -> torch.Tensor:
+             a_src_row=None, a_src_mod: int = 0, group_offsets=None, c_row_map=None, epilogue: int = EPI_STORE, w_frags=None) -> torch.Tensor:
     """out rows = (e4m3fn a rows) . (e4m3fn w [G, N, K])^T * a_scale[row] * w_scale[g, col] on the fp8 matrix cores (the
-    torch._scaled_mm branch of fp8_linear, vllm_i64/core/fp8.py:169-193); optional row gather / grouped weights / row scatter."""
+    torch._scaled_mm branch of fp8_linear, vllm_i64/core/fp8.py:169-193); optional row gather / grouped weights / row scatter.
+    w_frags: the fragment pack of w - the call then runs on the operand-stationary kernel (prefill-sized calls)."""
     if w.dim() == 2:
         w, w_scale = w.unsqueeze(0), w_scale.reshape(1, -1)
     G, N, K = w.shape
     assert a.shape[1] == K and epilogue in (EPI_STORE, EPI_SWIGLU)
+    if w_frags is not None:
+        call("i64h_gemm_fp8_frags", ptr(a), ptr(a_scale), ptr(a_src_row), a_src_mod, ptr(w_frags), ptr(w_scale), ptr(group_offsets), G,
+             m if m is not None else a.shape[0], N, K, ptr(out), ptr(c_row_map), epilogue, _stream())
+        return out
     call("i64h_gemm_fp8_ex", ptr(a), ptr(a_scale), ptr(a_src_row), a_src_mod, ptr(w), ptr(w_scale), ptr(group_offsets), G,
          m if m is not None else a.shape[0], N, K, ptr(out), ptr(c_row_map), epilogue, _stream())
     return out
