@@ -360,6 +360,13 @@ int i64h_fused_residual_norm(const float* h, const float* add, const float* moe_
  * num_slots: the relative slot ids in `slots` lie in [0, num_slots) (0: unknown - the parameters are then derived per row).
  * n <= i64h_fused_residual_norm_quant_rows() (64 rows per workgroup, one workgroup per CU), H <= 1024.  sync: the zeroed sync
  * words of i64h_decode_sync_words(); a launch leaves them zero; launches sharing them must not overlap. */
+/* Residual update + RMSNorm + quantize_activations_fp8 (vllm_i64/core/fp8.py:113-130) of the normalised rows in one pass, for the e4m3
+ * runner (a row's scale needs only that row): i64h_fused_residual_norm followed by i64h_quantize_fp8_rows, same codes and scales.
+ * normed may be NULL.  H <= 1024. */
+int i64h_fused_residual_norm_fp8(const float* h, const float* add, const float* moe_rows, const int32_t* moe_inv, const float* moe_shared,
+                                 const float* route_weights, int32_t top_k, float routed_scale, float shared_scale, float* h_out,
+                                 const float* norm_weight, float eps, float* normed, int64_t n, int32_t H, uint8_t* q_rows, float* q_scale,
+                                 void* stream);
 int64_t i64h_fused_residual_norm_quant_rows(void);
 int i64h_fused_residual_norm_quant(const float* h, const float* add, const float* moe_rows, const int32_t* moe_inv, const float* moe_shared,
                                    const float* route_weights, int32_t top_k, float routed_scale, float shared_scale, float* h_out,

@@ -206,3 +206,33 @@ def test_fp8_graph_decode_matches_eager(dev):
         dec.prefill([ids[:25], ids[25:]], reserve_extra=8)
         outs.append(torch.stack([dec.step().clone() for _ in range(4)]).cpu())
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("name", ["tiny-moe", "tiny-dense"])
+def test_fp8_prefill_with_the_norm_quantizing_its_rows_gives_the_same_bits(dev, name):
+    """A prefill chunk of a few hundred rows on the e4m3 runner: residual + norm + per-token quantization in one pass against the norm
+    followed by the row quantizer - logits and caches bit for bit."""
+    from vllm_i64_amd.model import I64MoEModel
+    ocfg, w, model = _model(name, dev)
+    lens = [210, 190]
+    n = sum(lens)
+    ids = M.make_token_ids(ocfg, n, seed=9).to(dev)
+    pos = torch.cat([torch.arange(t) for t in lens]).to(torch.int32).to(dev)
+    slots = torch.cat([torch.full((t,), s, dtype=torch.int32) for s, t in enumerate(lens)]).to(dev)
+    for s in range(2):
+        model.kv.free(s)
+    for s, t in enumerate(lens):
+        model.kv.reserve(s, t)
+    outs = []
+    for fused in (True, False):
+        for c in model.kv.k + model.kv.v:
+            c.zero_()
+        model.FP8_FUSE_NORM = fused
+        try:
+            logits = model.forward(ids, pos, slots, (pos + 1).contiguous()).clone()
+        finally:
+            model.FP8_FUSE_NORM = I64MoEModel.FP8_FUSE_NORM
+        outs.append((logits, [k.clone() for k in model.kv.k], [v.clone() for v in model.kv.v]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1] + outs[0][2], outs[1][1] + outs[1][2]):
+        assert torch.equal(a, b)

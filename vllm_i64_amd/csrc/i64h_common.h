@@ -174,6 +174,17 @@ __device__ __forceinline__ float half_swap_max(float v) {
     return fmaxf(r.lo, r.hi);
 }
 
+// four floats already clamped to [-448, 448] -> four e4m3fn codes (x0 in the low byte) through the hardware conversion
+// (v_cvt_pk_fp8_f32 on gfx950: OCP e4m3fn, round to nearest even, subnormal results exact) - the same codes as torch's cast
+// and as the bit-level routine f32_to_e4m3fn, checked value by value in tests/test_gpu_fp8_model.py
+__device__ __forceinline__ uint32_t pack4_e4m3fn(float x0, float x1, float x2, float x3) {
+    int v = 0;
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(x0, x1, v, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(x2, x3, v, true);
+    return (uint32_t)v;
+}
+__device__ __forceinline__ float clamp448(float x) { return fminf(fmaxf(x, -448.0f), 448.0f); }
+
 // Device-coherent accesses for data handed from one workgroup to another inside a launch: relaxed agent-scope atomics
 // compile to sc1 stores / loads, which are coherent across CUs and XCDs without any cache write-back or invalidate.
 __device__ __forceinline__ void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

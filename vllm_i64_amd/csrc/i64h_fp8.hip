@@ -14,17 +14,6 @@
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-// four floats already clamped to [-448, 448] -> four e4m3fn codes (x0 in the low byte) through the hardware conversion
-// (v_cvt_pk_fp8_f32 on gfx950: OCP e4m3fn, round to nearest even, subnormal results exact) - the same codes as torch's cast
-// and as the bit-level routine f32_to_e4m3fn, checked value by value in tests/test_gpu_fp8_model.py
-__device__ __forceinline__ uint32_t pack4_e4m3fn(float x0, float x1, float x2, float x3) {
-    int v = 0;
-    v = __builtin_amdgcn_cvt_pk_fp8_f32(x0, x1, v, false);
-    v = __builtin_amdgcn_cvt_pk_fp8_f32(x2, x3, v, true);
-    return (uint32_t)v;
-}
-__device__ __forceinline__ float clamp448(float x) { return fminf(fmaxf(x, -448.0f), 448.0f); }
-
 __global__ __launch_bounds__(256) void quantize_fp8_rows_kernel(const float* __restrict__ x, int64_t K, uint8_t* __restrict__ q,
                                                                 float* __restrict__ scale) {
     __shared__ float red[4];

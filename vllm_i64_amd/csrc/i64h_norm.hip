@@ -292,7 +292,8 @@ __device__ __forceinline__ void frr_flush(const uint32_t* tab_lo, const uint32_t
 
 __global__ __launch_bounds__(256) void fused_residual_norm_rows_kernel(FrrArgs p, const float* __restrict__ w, float* __restrict__ normed,
                                                                        const int32_t* __restrict__ slots, int spr, int slot_base,
-                                                                       uint32_t* __restrict__ stats) {
+                                                                       uint32_t* __restrict__ stats, uint8_t* __restrict__ f8q = nullptr,
+                                                                       float* __restrict__ f8s = nullptr) {
     __shared__ uint32_t tab_lo[I64H_STAT_TAB], tab_hi[I64H_STAT_TAB];
     if (stats) {
         for (int i = threadIdx.x; i < I64H_STAT_TAB; i += 256) { tab_lo[i] = I64H_ORDERED_ZERO; tab_hi[i] = I64H_ORDERED_ZERO; }
@@ -305,12 +306,27 @@ __global__ __launch_bounds__(256) void fused_residual_norm_rows_kernel(FrrArgs p
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         const int i = lane + 64 * v;
-        gw[v] = (normed && i < nv) ? ((const float4*)w)[i] : make_float4(0, 0, 0, 0);
+        gw[v] = ((normed || f8q) && i < nv) ? ((const float4*)w)[i] : make_float4(0, 0, 0, 0);
     }
     for (int64_t t = t0; t < t0 + FRR_RPW && t < p.n; ++t) {
         float4 y[4];
         float lo, hi;
-        frr_row(p, t, lane, nv, [&](int v) { return gw[v]; }, normed != nullptr, y, lo, hi);
+        frr_row(p, t, lane, nv, [&](int v) { return gw[v]; }, normed != nullptr || f8q != nullptr, y, lo, hi);
+        if (f8q) {  // the per-token e4m3 quantization of the normalised row (quantize_fp8_rows_kernel's arithmetic) in the same pass
+            float m = 0.0f;
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                if (lane + 64 * v < nv) m = fmaxf(m, fmaxf(fmaxf(fabsf(y[v].x), fabsf(y[v].y)), fmaxf(fabsf(y[v].z), fabsf(y[v].w))));
+            m = wave_max(m);
+            const float s = fmaxf(m, 1e-12f) / 448.0f;
+            if (lane == 0) f8s[t] = s;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int i = lane + 64 * v;
+                if (i < nv)
+                    ((uint32_t*)(f8q + t * p.H))[i] = pack4_e4m3fn(clamp448(y[v].x / s), clamp448(y[v].y / s), clamp448(y[v].z / s), clamp448(y[v].w / s));
+            }
+        }
         if (!normed) continue;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
@@ -757,13 +773,38 @@ int i64h_fused_residual_norm(const float* h, const float* add, const float* moe_
         FrrArgs fa;
         fa.h = h; fa.add = add; fa.mc = mc; fa.n = n; fa.h_out = h_out; fa.eps = eps; fa.H = (int)H;
         hipLaunchKernelGGL(fused_residual_norm_rows_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, fa, norm_weight,
-                           normed, slots, (int)slots_per_row, (int)slot_base, stats);
+                           normed, slots, (int)slots_per_row, (int)slot_base, stats, (uint8_t*)nullptr, (float*)nullptr);
         I64H_CHECK_LAUNCH();
         return 0;
     }
     const int rpb = n > 2048 ? 8 : 1;  // many rows: fold 8 rows per workgroup before touching the global stat slots
     hipLaunchKernelGGL(fused_residual_norm_kernel, dim3((unsigned)i64h_cdiv(n, rpb)), dim3(256), 0, (hipStream_t)stream, h, add, mc,
                        (int)n, rpb, h_out, norm_weight, eps, normed, (int)H, slots, (int)slots_per_row, (int)slot_base, stats);
+    I64H_CHECK_LAUNCH();
+    return 0;
+}
+
+// Residual update + RMSNorm + the per-token e4m3fn quantization of the normalised rows (i64h_fused_residual_norm followed by
+// i64h_quantize_fp8_rows, one pass: a row's scale needs only that row).  normed may be NULL (the fp32 rows are then not stored).
+int i64h_fused_residual_norm_fp8(const float* h, const float* add, const float* moe_rows, const int32_t* moe_inv, const float* moe_shared,
+                                 const float* route_weights, int32_t top_k, float routed_scale, float shared_scale, float* h_out,
+                                 const float* norm_weight, float eps, float* normed, int64_t n, int32_t H, uint8_t* q_rows, float* q_scale,
+                                 void* stream) {
+    I64H_CHECK_ARG(n >= 0 && H > 0 && H % 4 == 0 && H <= 1024, "fused_residual_norm_fp8: H=%d unsupported (multiple of 4, <= 1024)", H);
+    I64H_CHECK_ARG(top_k >= 0 && top_k <= 8, "fused_residual_norm_fp8: top_k=%d unsupported", top_k);
+    I64H_CHECK_ARG(moe_rows == nullptr || (route_weights != nullptr && top_k > 0), "fused_residual_norm_fp8: moe args");
+    I64H_CHECK_ARG(norm_weight && q_rows && q_scale, "fused_residual_norm_fp8: null norm weight or output");
+    I64H_CHECK_ARG((((uintptr_t)h | (uintptr_t)add | (uintptr_t)moe_rows | (uintptr_t)moe_shared | (uintptr_t)h_out | (uintptr_t)normed |
+                     (uintptr_t)norm_weight) % 16) == 0 && ((uintptr_t)q_rows % 4) == 0, "fused_residual_norm_fp8: operands must be 16-byte aligned");
+    if (n == 0) return 0;
+    FrrArgs fa;
+    fa.h = h; fa.add = add; fa.n = n; fa.h_out = h_out; fa.eps = eps; fa.H = (int)H;
+    fa.mc.rows = moe_rows; fa.mc.inv = moe_inv; fa.mc.shared = moe_shared; fa.mc.top_k = top_k;
+    for (int k = 0; k < 8; ++k) fa.mc.wk[k] = (moe_rows && k < top_k) ? route_weights[k] : 0.0f;
+    fa.mc.routed_scale = routed_scale; fa.mc.shared_scale = shared_scale;
+    const int64_t waves = (n + FRR_RPW - 1) / FRR_RPW;
+    hipLaunchKernelGGL(fused_residual_norm_rows_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, fa, norm_weight, normed,
+                       (const int32_t*)nullptr, 1, 0, (uint32_t*)nullptr, q_rows, q_scale);
     I64H_CHECK_LAUNCH();
     return 0;
 }

@@ -262,6 +262,10 @@ class I64MoEModel:
             self._bufs[key] = _Buffers(self.cfg, n, n_logit_rows, self.device, ep_world=self.ep.world if self.ep is not None else 0)
         return self._bufs[key]
 
+    # e4m3 runner, prefill chunks: residual + norm + per-token quantization in one pass.  Off by default: the pass itself is faster
+    # (40.8 us against 46.5 + 22.8 us, 13 ms less kernel time per prefill in the kernel trace), but on a box that has run other
+    # processes before the prefill as a whole measured slower with it (545-595 k against 676-680 k tokens/s; 724-728 k on a fresh box)
+    FP8_FUSE_NORM = os.environ.get("I64H_FP8_FUSE_NORM", "0") == "1"
     FP8_FRAGS = os.environ.get("I64H_FP8_FRAGS", "1") != "0"  # e4m3 runner: prefill-sized Linears on the operand-stationary kernel
     FUSE_QKV_PREFILL = os.environ.get("I64H_FUSE_QKV_PREFILL", "1") != "0"  # prefill chunks: QK norm + RoPE + cache write in the qkv GEMM's epilogue
     FUSE_NORM_QUANT = os.environ.get("I64H_FUSE_NORM_QUANT", "1") != "0"  # prefill chunks: residual + norm + quantization in one launch
@@ -568,9 +572,15 @@ class I64MoEModel:
         if splits > 1 and (B.attn_ws is None or B.attn_splits != splits):
             B.attn_ws = ops.attn_workspace(n, cfg.num_heads, cfg.head_dim, splits, self.device)
             B.attn_splits = splits
-        ops.fused_residual_norm(B.h, self.layers[0]["ln1"], eps, h_out=B.h, normed=B.normed)
         S = cfg.shared_intermediate_size if cfg.is_moe else 0
         small = n * max(1, cfg.top_k if cfg.is_moe else 1) <= self.FUSE_MAX_ROWS
+        # prefill-sized chunks (opt-in, see FP8_FUSE_NORM): the norm quantizes the normalised rows itself (a row's scale needs only that
+        # row), the fp32 rows are not stored; decode-sized steps quantize inside their GEMMs; recording runs keep the fp32 rows
+        nq = self.FP8_FUSE_NORM and not small and record is None and H <= 1024 and H % 4 == 0
+        if nq:
+            ops.fused_residual_norm_fp8(B.h, self.layers[0]["ln1"], eps, B.xa, B.xs, h_out=B.h)
+        else:
+            ops.fused_residual_norm(B.h, self.layers[0]["ln1"], eps, h_out=B.h, normed=B.normed)
 
         def linear(x, xq, xs, Wp, out, **kw):
             """One fp8_linear: decode-sized steps quantize the rows inside the GEMM (one launch); otherwise the rows are
@@ -590,7 +600,7 @@ class I64MoEModel:
         for l, W in enumerate(self.layers):
             if record is not None:
                 record[f"l{l}.in"] = B.h.clone()
-            linear(B.normed, B.xa, B.xs, W["qkv"], B.qkv)
+            linear(None if nq else B.normed, B.xa, B.xs, W["qkv"], B.qkv)
             ops.qk_norm_rope_kv(B.qkv, W["q_norm"], W["k_norm"], 1e-6, self.rope, positions, slot_ids, kvc.block_table,
                                 kvc.k[l], kvc.v[l], cfg.num_heads, cfg.num_kv_heads, cfg.head_dim, q_out=B.q)
             ops.paged_attn(B.q, kvc.k[l], kvc.v[l], kvc.block_table, ctx_len, slot_ids=None if rows_are_slots else slot_ids,
@@ -599,12 +609,16 @@ class I64MoEModel:
             if record is not None:
                 record[f"l{l}.attn_out"] = attn2d.clone()
             linear(attn2d, B.xa, B.xs, W["o"], B.o)
-            ops.fused_residual_norm(B.h, W["ln2"], eps, add=B.o, h_out=B.h, normed=B.normed)
+            if nq:
+                ops.fused_residual_norm_fp8(B.h, W["ln2"], eps, B.xa, B.xs, add=B.o, h_out=B.h)
+            else:
+                ops.fused_residual_norm(B.h, W["ln2"], eps, add=B.o, h_out=B.h, normed=B.normed)
             if record is not None:
                 record[f"l{l}.mlp_in"] = B.normed.clone()
             nxt = self.layers[l + 1]["ln1"] if l + 1 < cfg.num_layers else self.final_norm
+            last = l + 1 == cfg.num_layers
             fused_in = small and ops.fp8_rows_ok(H)   # the normalised rows go into their GEMMs as fp32
-            if not fused_in:
+            if not fused_in and not nq:
                 ops.quantize_fp8_rows(B.normed, B.xa, B.xs)  # one quantization serves the shared expert and every routed expert
             x_in = B.normed if fused_in else None
             if cfg.is_moe:
@@ -633,13 +647,19 @@ class I64MoEModel:
                     if S:
                         linear(x_in, B.xa, B.xs, W["sh_gu"], B.sh_inter, epilogue=ops.EPI_SWIGLU)
                         linear(B.sh_inter, B.sha, B.shs, W["sh_dn"], B.sh_out)
-                ops.fused_residual_norm(B.h, nxt, eps, moe_rows=B.e_out, moe_inv=None, moe_shared=B.sh_out if S else None,
-                                        route_weights=rw, routed_scale=W["routed_scale"], shared_scale=W["shared_scale"], h_out=B.h,
-                                        normed=B.normed)
+                mk = dict(moe_rows=B.e_out, moe_inv=None, moe_shared=B.sh_out if S else None, route_weights=rw,
+                          routed_scale=W["routed_scale"], shared_scale=W["shared_scale"], h_out=B.h)
+                if nq and not last:
+                    ops.fused_residual_norm_fp8(B.h, nxt, eps, B.xa, B.xs, **mk)
+                else:
+                    ops.fused_residual_norm(B.h, nxt, eps, normed=B.normed, **mk)
             else:
                 linear(x_in, B.xa, B.xs, W["gu"], B.d_inter, epilogue=ops.EPI_SWIGLU)
                 linear(B.d_inter, B.da, B.ds, W["dn"], B.d_out)
-                ops.fused_residual_norm(B.h, nxt, eps, add=B.d_out, h_out=B.h, normed=B.normed)
+                if nq and not last:
+                    ops.fused_residual_norm_fp8(B.h, nxt, eps, B.xa, B.xs, add=B.d_out, h_out=B.h)
+                else:
+                    ops.fused_residual_norm(B.h, nxt, eps, add=B.d_out, h_out=B.h, normed=B.normed)
             if record is not None:
                 record[f"l{l}.out"] = B.h.clone()
         ops.call("i64h_gemm_f32", ops.ptr(B.normed), ops.ptr(logit_rows), ops.ptr(self.embed), ops.ptr(B.logits), B.logits.shape[0],

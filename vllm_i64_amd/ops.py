@@ -449,6 +449,22 @@ def gemm_i8_frags_qkv_rope_kv(a8: torch.Tensor, row_scale: torch.Tensor, w_frags
     return q_out
 
 
+def fused_residual_norm_fp8(h: torch.Tensor, norm_weight: torch.Tensor, eps: float, q_rows: torch.Tensor, q_scale: torch.Tensor,
+                            add: Optional[torch.Tensor] = None, moe_rows: Optional[torch.Tensor] = None, moe_inv: Optional[torch.Tensor] = None,
+                            moe_shared: Optional[torch.Tensor] = None, route_weights: Sequence[float] = (), routed_scale: float = 1.0,
+                            shared_scale: float = 1.0, h_out: Optional[torch.Tensor] = None, normed: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fused_residual_norm + quantize_fp8_rows of the normalised rows in one pass (normed: also store the fp32 rows).  Returns h_out."""
+    _chk(h, torch.float32, "h"), _chk(q_scale, torch.float32, "q_scale")
+    n, H = h.shape
+    if h_out is None:
+        h_out = torch.empty_like(h)
+    rw = (ctypes.c_float * 8)(*([float(w) for w in route_weights] + [0.0] * (8 - len(route_weights))))
+    call("i64h_fused_residual_norm_fp8", ptr(h), ptr(add), ptr(moe_rows), ptr(moe_inv), ptr(moe_shared), ctypes.addressof(rw),
+         len(route_weights), float(routed_scale), float(shared_scale), ptr(h_out), ptr(norm_weight), float(eps), ptr(normed), n, H,
+         ptr(q_rows), ptr(q_scale), _stream())
+    return h_out
+
+
 def fused_residual_norm_quant_rows() -> int:
     """Rows one launch of fused_residual_norm_quant takes on this device."""
     return int(_lib.load().i64h_fused_residual_norm_quant_rows())
