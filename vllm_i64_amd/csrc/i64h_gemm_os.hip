@@ -391,7 +391,10 @@ __device__ __forceinline__ void os_run(const GemmI8Args& p, const int8_t* __rest
         if (g < 0) continue;  // past the last tile (uniform over the workgroup: every wave found the same)
         // ---- this wave's share of the tile's units: the units of the item dealt evenly over the waves (waves w, w + 4, ... share
         // a SIMD, so the SIMDs get equal shares whenever the unit count is a multiple of 4), walked in blocks of up to WMAX units ----
-        const int ulo = (int)((int64_t)np * U / parts), uhi = (int)((int64_t)(np + 1) * U / parts);
+        // (fused qkv projection: the heads are dealt to the parts round-robin - head = local index * parts + part -, so that every part
+        // holds the same mix of q, k and v heads, whose epilogues cost differently)
+        const int ulo = EPI == EPI_QKR ? 0 : (int)((int64_t)np * U / parts);
+        const int uhi = EPI == EPI_QKR ? (U - np + parts - 1) / parts : (int)((int64_t)(np + 1) * U / parts);
         const int n = uhi - ulo, base = n / NW, rem = n - base * NW;
         int cnt = base + (wid < rem ? 1 : 0);
         int u = ulo + wid * base + min(wid, rem);
@@ -468,7 +471,7 @@ __device__ __forceinline__ void os_run(const GemmI8Args& p, const int8_t* __rest
         const int rk = (int)(((unsigned)slot * (unsigned)rotk + (unsigned)wid * (unsigned)(rotk != 0)) % (unsigned)KS);
         if constexpr (EPI == EPI_QKR) {
             for (; cnt >= 1; --cnt, ++u) {  // one head (four fragment columns) per block
-                os_block<EPI, DB, 2, MFR, F8>(p, Bg, KS, rk, 2 * u, g, row0, rows, ws, false, true, 0, 0, item, lane, sp, ta);
+                os_block<EPI, DB, 2, MFR, F8>(p, Bg, KS, rk, 2 * (u * parts + np), g, row0, rows, ws, false, true, 0, 0, item, lane, sp, ta);
                 sp = nullptr;
             }
         } else if (WMAX >= 2) {
