@@ -192,8 +192,9 @@ struct FrrArgs {
 };
 // One row in one wave: the residual update (stored to h_out), the normalised row in y (lane l: float4 l + 64 v of the row), its
 // range with zero in lo / hi (per lane: fold with wave_min / wave_max).
-template <typename GW>
-__device__ __forceinline__ void frr_row(const FrrArgs& p, const int64_t t, const int lane, const int nv, const GW& gw, const bool norm,
+// ri(k): the bucket-order row of the routed output (route k, token t)
+template <typename GW, typename RI>
+__device__ __forceinline__ void frr_row(const FrrArgs& p, const int64_t t, const int lane, const int nv, const GW& gw, const RI& ri, const bool norm,
                                         float4 (&y)[4], float& lo, float& hi) {
     const MoeCombine& mc = p.mc;
     const int H = p.H;
@@ -203,7 +204,7 @@ __device__ __forceinline__ void frr_row(const FrrArgs& p, const int64_t t, const
     if (mc.rows) {
 #pragma unroll
         for (int k = 0; k < 8; ++k)
-            if (k < mc.top_k) rrow[k] = mc.inv ? (int64_t)mc.inv[(int64_t)k * n + t] : (int64_t)k * n + t;
+            if (k < mc.top_k) rrow[k] = ri(k);
     }
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -266,6 +267,21 @@ __device__ __forceinline__ void frr_row(const FrrArgs& p, const int64_t t, const
     }
 }
 // a row's range into the workgroup's table of relative slots (lanes < number of slots of the row)
+// rel_of_lane: lane l < number of slots of the row holds the row's l-th relative slot
+__device__ __forceinline__ void frr_fold_rel(uint32_t* tab_lo, uint32_t* tab_hi, int ns, int rel_of_lane, int lane, float lo, float hi,
+                                             uint32_t* stats, int slot_base) {
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+    if (lane < ns) {
+        const int rel = rel_of_lane;
+        if (rel >= 0 && rel < I64H_STAT_TAB) {
+            atomicMin(&tab_lo[rel], f32_to_ordered(lo));
+            atomicMax(&tab_hi[rel], f32_to_ordered(hi));
+        } else {
+            stat_update(stats, slot_base + rel, blockIdx.x, lo, hi);
+        }
+    }
+}
 __device__ __forceinline__ void frr_fold(uint32_t* tab_lo, uint32_t* tab_hi, const int32_t* slots, int spr, int64_t t, int lane, float lo, float hi,
                                          uint32_t* stats, int slot_base) {
     lo = wave_min(lo);
@@ -311,7 +327,9 @@ __global__ __launch_bounds__(256) void fused_residual_norm_rows_kernel(FrrArgs p
     for (int64_t t = t0; t < t0 + FRR_RPW && t < p.n; ++t) {
         float4 y[4];
         float lo, hi;
-        frr_row(p, t, lane, nv, [&](int v) { return gw[v]; }, normed != nullptr || f8q != nullptr, y, lo, hi);
+        frr_row(p, t, lane, nv, [&](int v) { return gw[v]; },
+                [&](int k) { return p.mc.inv ? (int64_t)p.mc.inv[(int64_t)k * p.n + t] : (int64_t)k * p.n + t; },
+                normed != nullptr || f8q != nullptr, y, lo, hi);
         if (f8q) {  // the per-token e4m3 quantization of the normalised row (quantize_fp8_rows_kernel's arithmetic) in the same pass
             float m = 0.0f;
 #pragma unroll
@@ -379,14 +397,26 @@ __global__ __launch_bounds__(FRQ_WAVES * 64) void fused_residual_norm_quant_kern
     __shared__ float4 s_w[256];  // the norm weights stay in LDS: the registers hold the rows
     for (int i = threadIdx.x; i < 256; i += FRQ_WAVES * 64) s_w[i] = i < nv ? ((const float4*)w)[i] : make_float4(0, 0, 0, 0);
     __syncthreads();
+    // the rows' slot ids (lane l: the row's l-th slot) and gather destinations (lane k: route k) are requested before the rows:
+    // behind the rows each would be a dependent round trip of its own, in both phases
+    const int ns = slots ? spr : 1;
+    int sl[FRR_RPW], gd[FRR_RPW], cr[FRR_RPW];  // cr: lane k = the row of the routed output of route k that the combine reads
+#pragma unroll
+    for (int r = 0; r < FRR_RPW; ++r) {
+        const int64_t t = t0 + r;
+        sl[r] = (slots && t < p.n && lane < spr) ? slots[t * spr + lane] : 0;
+        gd[r] = (ga && t < p.n && lane < g_k) ? g_inv[(int64_t)lane * p.n + t] : 0;
+        cr[r] = (p.mc.rows && p.mc.inv && t < p.n && lane < p.mc.top_k) ? p.mc.inv[(int64_t)lane * p.n + t] : 0;
+    }
     float4 y[FRR_RPW][4];
 #pragma unroll
     for (int r = 0; r < FRR_RPW; ++r) {
         const int64_t t = t0 + r;
         if (t < p.n) {
             float lo, hi;
-            frr_row(p, t, lane, nv, [&](int v) { return s_w[lane + 64 * v]; }, true, y[r], lo, hi);
-            frr_fold(tab_lo, tab_hi, slots, spr, t, lane, lo, hi, stats, slot_base);
+            frr_row(p, t, lane, nv, [&](int v) { return s_w[lane + 64 * v]; },
+                    [&](int k) { return p.mc.inv ? (int64_t)__builtin_amdgcn_readlane(cr[r], k) : (int64_t)k * p.n + t; }, true, y[r], lo, hi);
+            frr_fold_rel(tab_lo, tab_hi, ns, sl[r], lane, lo, hi, stats, slot_base);
         }
     }
     __syncthreads();
@@ -423,7 +453,7 @@ __global__ __launch_bounds__(FRQ_WAVES * 64) void fused_residual_norm_quant_kern
     for (int r = 0; r < FRR_RPW; ++r) {
         const int64_t t = t0 + r;
         if (t >= p.n) break;
-        const int slot = slots ? slots[t * spr] : 0;
+        const int slot = __builtin_amdgcn_readlane(sl[r], 0);
         if (slot != prev_slot) {  // wave-uniform
             q = params_of(slot);
             prev_slot = slot;
@@ -437,8 +467,8 @@ __global__ __launch_bounds__(FRQ_WAVES * 64) void fused_residual_norm_quant_kern
         }
         if (ga) {
             for (int k = 0; k < g_k; ++k) {
-                const int64_t dst = g_inv[(int64_t)k * p.n + t];
-                const QParams gq = params_of(slots[t * spr + 1 + k]);
+                const int64_t dst = __builtin_amdgcn_readlane(gd[r], k);
+                const QParams gq = params_of(__builtin_amdgcn_readlane(sl[r], 1 + k));
                 if (lane == 0) gs[dst] = gq.scale;
                 uint32_t* gr = (uint32_t*)(ga + dst * H);
 #pragma unroll
