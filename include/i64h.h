@@ -241,6 +241,15 @@ typedef struct i64h_fp8_rows_desc {
     int32_t b_frags;                /* 1 = B points to the fragment pack of the e4m3 bytes (i64h_pack_weight_frags; N % 16 == 0, epilogue 1: N % 32 == 0) */
 } i64h_fp8_rows_desc;
 int i64h_gemm_fp8_rows_pair(const i64h_fp8_rows_desc* a, const i64h_fp8_rows_desc* b, int32_t epilogue, void* stream);
+/* Decode-sized fused form for e4m3 weights: qkv projection (one problem of i64h_gemm_fp8_rows_pair, epilogue 0: one group, no row
+ * maps, 256 <= K) + per-head QK RMSNorm + rotate-half RoPE + paged-KV write in one launch (arguments as i64h_qk_norm_rope_kv;
+ * head_dim 64, N = (heads + 2 kv heads) * 64; d->C is not written).  No counterpart in the reference: it stands for the pair
+ * (fp8_linear qkv projection, QK norm / rotary / cache write) of the decoder layer (vllm_i64/core/fp8.py:137-194,
+ * vllm_i64/models/complexity_deep/model.py:165-184) without the kernel boundary and the fp32 qkv round trip in between. */
+int i64h_gemm_fp8_rows_qkv_rope_kv(const i64h_fp8_rows_desc* d, const float* q_norm_w, const float* k_norm_w, float qk_eps,
+                                   const float* rope_tab, const int32_t* positions, const int32_t* slot_ids, const int32_t* block_table,
+                                   int32_t max_blocks_per_seq, float* q_out, void* k_cache, void* v_cache, int32_t kv_dtype,
+                                   int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, int32_t block_size, void* stream);
 
 /* ---- one MoE layer behind one call --------------------------------------------------------------------------------------
  * out[n, H] = TokenRoutedMLP(x, token_ids) of the int8 CPU engine: routes = table[:, clamp(ids)], every (route, expert)

@@ -236,3 +236,69 @@ def test_fp8_prefill_with_the_norm_quantizing_its_rows_gives_the_same_bits(dev, 
     assert torch.equal(outs[0][0], outs[1][0])
     for a, b in zip(outs[0][1] + outs[0][2], outs[1][1] + outs[1][2]):
         assert torch.equal(a, b)
+
+
+def test_fp8_fused_qkv_rope_kv_equals_two_launch_path(dev):
+    """Decode-sized e4m3 qkv projection with the QK norm / RoPE / cache write in its epilogue against the projection followed by
+    the row kernel: same q, same cache bytes (identical operation order), all cache dtypes, ragged last row block, a hole in the
+    block table, weights row-major and as a fragment pack, with and without norm weights."""
+    from vllm_i64_amd import ops
+    from vllm_i64_amd.model import pack_fp8, rope_table
+    g = torch.Generator().manual_seed(72)
+    nh, kvh, hd, H = 8, 2, 64, 256
+    tab = rope_table(128, hd, 10000.0).to(dev)
+    w = pack_fp8(torch.empty((nh + 2 * kvh) * hd, H).normal_(0, 0.05, generator=g), dev)
+    qw, kw = (torch.rand(hd, generator=g) + 0.5).to(dev), (torch.rand(hd, generator=g) + 0.5).to(dev)
+    for n, dt, norm, packed in ((37, torch.float32, True, True), (64, torch.bfloat16, True, False), (5, torch.float16, False, True),
+                                (20, torch.float8_e4m3fn, True, True), (33, torch.float8_e5m2, True, False)):
+        x = torch.empty(n, H).normal_(0, 1, generator=g).to(dev)
+        slot = (torch.arange(n, dtype=torch.int32) % 7).to(dev)
+        pos = (torch.arange(n, dtype=torch.int32) // 7 + 3).to(dev)   # rows of one sequence get distinct cache cells
+        nblk = 7 * 8
+        bt = torch.randperm(nblk, generator=g).to(torch.int32).view(7, 8)
+        bt[3, 0] = -1                                                 # a sequence without a block behind its position: nothing is written
+        bt = bt.to(dev)
+        outs = []
+        for fused in (False, True):
+            kc = torch.zeros(nblk, 16, kvh, hd, device=dev).to(dt)
+            vc = torch.zeros(nblk, 16, kvh, hd, device=dev).to(dt)
+            q = torch.zeros(n, nh, hd, device=dev)
+            qkv = torch.zeros(n, (nh + 2 * kvh) * hd, device=dev)
+            wf = w.frags(False) if packed else None
+            if fused:
+                ops.gemm_fp8_rows_qkv_rope_kv(ops.fp8_rows_desc(x, w.w_q, w.w_s, qkv, w_frags=wf), qw if norm else None, kw if norm else None,
+                                              1e-6, tab, pos, slot, bt, kc, vc, q, nh, kvh, hd)
+                assert qkv.abs().sum() == 0
+            else:
+                ops.gemm_fp8_rows(x, w.w_q, w.w_s, qkv, w_frags=wf)
+                ops.qk_norm_rope_kv(qkv, qw if norm else None, kw if norm else None, 1e-6, tab, pos, slot, bt, kc, vc, nh, kvh, hd, q_out=q)
+            outs.append((q.cpu(), kc.cpu().view(torch.uint8) if dt.itemsize == 1 else kc.cpu().float(),
+                         vc.cpu().view(torch.uint8) if dt.itemsize == 1 else vc.cpu().float()))
+        for a, b in zip(outs[0], outs[1]):
+            assert torch.equal(a, b)
+        assert outs[1][0].abs().sum() > 0 and outs[1][1].float().abs().sum() > 0
+
+
+def test_fp8_decode_steps_with_the_fused_qkv_launch_give_the_same_bits(dev):
+    """Greedy decode steps of the e4m3 runner on a model with 64-wide heads: with the fused qkv launch and with the two-launch path -
+    logits bit for bit."""
+    import dataclasses
+    from vllm_i64_amd.config import ModelConfig
+    from vllm_i64_amd.model import GreedyDecoder, I64MoEModel
+    ocfg = dataclasses.replace(M.named_config("tiny-moe"), hidden_size=256, num_heads=4, num_kv_heads=2, name="tiny-moe-hd64")
+    w = M.make_weights(ocfg, seed=0)
+    model = I64MoEModel(ModelConfig.from_any(ocfg), w, device=dev, max_seqs=3, num_kv_blocks=64, quant="fp8")
+    assert model.cfg.head_dim == 64
+    ids = M.make_token_ids(ocfg, 45, seed=6)
+    outs = []
+    for fused in (True, False):
+        for s in range(3):
+            model.kv.free(s)
+        model.FP8_FUSE_QKV = fused
+        try:
+            dec = GreedyDecoder(model, 3, use_graph=False)
+            dec.prefill([ids[:20], ids[20:27], ids[27:]], reserve_extra=8)
+            outs.append(torch.stack([dec.step().clone() for _ in range(4)]).cpu())
+        finally:
+            model.FP8_FUSE_QKV = I64MoEModel.FP8_FUSE_QKV
+    assert torch.equal(outs[0], outs[1])

@@ -10,6 +10,7 @@
 //   fp8.py:256-283) and a SwiGLU epilogue silu(gate) * up over the fused [2I, K] weight.
 // Workgroup = 4 waves (2 x 2), tile 64 x 64, K stages of 128 bytes, double-buffered LDS (row stride 144 bytes).
 #include "i64h_common.h"
+#include "i64h_gemm_dev.h"
 #include "i64h.h"
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -196,8 +197,11 @@ struct Fp8RowsPair {
     int nblk0;  // workgroups [0, nblk0) run p[0], the rest p[1] (e.g. the routed experts and the shared expert of one layer)
 };
 
+// EPI 2: the workgroup's 64 columns are one 64-wide head of the fused qkv projection - per-head RMSNorm, rotate-half RoPE, q to
+// q_out, K / V into the paged cache in the epilogue (the arithmetic and operation order of qk_norm_rope_kv_kernel on the values
+// EPI 0 would have stored; p.C is not written).
 template <int EPI>
-__global__ __launch_bounds__(256) void gemm_fp8_skinny_kernel(Fp8RowsPair pp) {
+__global__ __launch_bounds__(256) void gemm_fp8_skinny_kernel(Fp8RowsPair pp, RowTailArgs ta) {
     extern __shared__ __attribute__((aligned(16))) char f8s_smem[];
     const bool second = (int)blockIdx.x >= pp.nblk0;
     const Fp8RowsArgs& p = pp.p[second ? 1 : 0];
@@ -211,14 +215,14 @@ __global__ __launch_bounds__(256) void gemm_fp8_skinny_kernel(Fp8RowsPair pp) {
     const int G = p.G, M = p.M, N = p.N, K = p.K;
     float* __restrict__ C = p.C;
     const int32_t* __restrict__ c_row_map = p.c_row_map;
-    constexpr int NF = EPI ? 2 : 1;
+    constexpr int NF = EPI == 1 ? 2 : 1;
     const int LDA = K + 32;
     char* rows_q = f8s_smem;                                 // [16][LDA] e4m3 codes
     float* row_s = (float*)(f8s_smem + F8S_BM * LDA);        // [16] scales
     int* s_info = (int*)(row_s + F8S_BM);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
-    const int I = N / 2, nout = EPI ? I : N;
+    const int I = N / 2, nout = EPI == 1 ? I : N;
     const int n_tiles = (nout + 63) / 64;
     const int mt = bid / n_tiles, nt = bid % n_tiles;
     if (wid == 0) {  // (group, first row, rows) of m-tile mt: lane i looks at group c0 + i; the grid is an upper bound
@@ -251,6 +255,34 @@ __global__ __launch_bounds__(256) void gemm_fp8_skinny_kernel(Fp8RowsPair pp) {
     const int g = s_info[0], row0 = s_info[1], rows = s_info[2];
     if (g < 0) return;
 
+    // EPI 2: cache slot and rotation of this wave's rows (wid, wid + 4, ...).  Positions and sequence slots are requested in front
+    // of the operand rows, the cache block and the rotation (which need them) behind the rows and the first weights: loads return
+    // in order, so neither look-up stands in front of the operand as a round trip of its own.
+    int qk_pos[4] = {0, 0, 0, 0}, qk_pb[4] = {0, 0, 0, 0}, qk_sl[4] = {0, 0, 0, 0};
+    float qk_c[4] = {0, 0, 0, 0}, qk_s[4] = {0, 0, 0, 0};
+    float qk_w = 1.0f;  // this lane's norm weight (head = column tile nt)
+    if constexpr (EPI == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rj = wid + 4 * j;
+            const int64_t t = row0 + (rj < rows ? rj : 0);
+            qk_pos[j] = ta.positions[t];
+            qk_sl[j] = ta.slot_ids[t];
+        }
+        const float* nw = nt < ta.nh ? ta.qw : ta.kw;
+        if (nw && nt < ta.nh + ta.kvh) qk_w = nw[lane];
+    }
+    auto tail_lookup = [&]() {
+        if constexpr (EPI == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                qk_pb[j] = ta.block_table[(int64_t)qk_sl[j] * ta.max_blocks_per_seq + qk_pos[j] / ta.block];
+                const float* cs = ta.rope_tab + (int64_t)qk_pos[j] * 64;
+                qk_c[j] = cs[lane & 31];
+                qk_s[j] = cs[32 + (lane & 31)];
+            }
+        }
+    };
     // ---- operand rows: thread (r = tid / 16, c = tid % 16) owns float4 chunks c, c + 16, ... of row r ----
     const int r = tid >> 4, c = tid & 15;
     const bool rok = r < rows;
@@ -298,6 +330,7 @@ __global__ __launch_bounds__(256) void gemm_fp8_skinny_kernel(Fp8RowsPair pp) {
             v[j] = (rok && i < nv) ? ap[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         bload(0);
+        tail_lookup();
 #pragma unroll
         for (int j = 0; j < F8S_MAXV; ++j) m = fmaxf(m, fmaxf(fmaxf(fabsf(v[j].x), fabsf(v[j].y)), fmaxf(fabsf(v[j].z), fabsf(v[j].w))));
     } else {
@@ -306,6 +339,7 @@ __global__ __launch_bounds__(256) void gemm_fp8_skinny_kernel(Fp8RowsPair pp) {
             m = fmaxf(m, fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w))));
         }
         bload(0);
+        tail_lookup();
     }
     m = row16_max(m);  // the 16 threads of a row are 16 consecutive lanes
     const float sc = fmaxf(m, 1e-12f) / 448.0f;
@@ -348,16 +382,56 @@ __global__ __launch_bounds__(256) void gemm_fp8_skinny_kernel(Fp8RowsPair pp) {
         }
     }
     // ---- epilogue: D[row = 4 fq + reg][col = fr] ----
+    if constexpr (EPI == 2) {
+        // (launcher: N = (heads + 2 kv heads) * 64, so every column exists.)  The tile goes through LDS once so that a wave owns
+        // whole rows (lane = dim), the shape and operation order of the stand-alone row kernel.
+        const float ws0 = b_scale[(int64_t)g * N + col];
+        __syncthreads();  // the operand codes in LDS are no longer needed (their scales lie behind them and stay)
+        float* s_c = (float*)f8s_smem;  // [16][64]
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int rr = fq * 4 + reg;
+            s_c[rr * 64 + wid * 16 + fr] = acc[0][reg] * (row_s[rr] * ws0);
+        }
+        __syncthreads();
+        const int head = nt, nh = ta.nh, kvh = ta.kvh, hd = 64, half = 32;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int rj = wid + 4 * j;
+            if (rj >= rows) break;
+            const int64_t t = row0 + rj;
+            const int pos = qk_pos[j], pb = qk_pb[j];
+            const int64_t cache_row = ((int64_t)pb * ta.block + pos % ta.block) * kvh;  // in heads
+            const float x = s_c[rj * 64 + lane];
+            if (head >= nh + kvh) {  // V: the projection itself goes into the cache
+                if (pb >= 0) kv_store(ta.v_cache, (cache_row + (head - nh - kvh)) * hd + lane, x, ta.kv_dtype);
+                continue;
+            }
+            const bool is_q = head < nh;
+            const float* w = is_q ? ta.qw : ta.kw;
+            float ss = __builtin_fmaf(x, x, 0.0f);
+            ss = wave_sum(ss);
+            const float rr = w ? rsqrtf(ss / (float)hd + ta.qk_eps) : 1.0f;
+            const float self = w ? x * rr * qk_w : x;
+            const float partner = lane_xor(self, 32);
+            const float cc = qk_c[j], sn = qk_s[j];
+            const float other = lane < half ? -partner : partner;
+            const float o = self * cc + other * sn;
+            if (is_q) ta.q_out[(t * nh + head) * hd + lane] = o;
+            else if (pb >= 0) kv_store(ta.k_cache, (cache_row + (head - nh)) * hd + lane, o, ta.kv_dtype);
+        }
+        return;
+    }
     if (!col_ok) return;
     const float ws0 = b_scale[(int64_t)g * N + col];
-    const float ws1 = EPI ? b_scale[(int64_t)g * N + I + col] : 0.0f;
+    const float ws1 = EPI == 1 ? b_scale[(int64_t)g * N + I + col] : 0.0f;
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int rr = fq * 4 + reg;
         if (rr >= rows) continue;
         const float as = row_s[rr];
         const int64_t crow = c_row_map ? c_row_map[row0 + rr] : row0 + rr;
-        if (EPI) {
+        if (EPI == 1) {
             const float gate = acc[0][reg] * (as * ws0), up = acc[NF - 1][reg] * (as * ws1);
             C[crow * I + col] = (gate / (1.0f + expf(-gate))) * up;
         } else {
@@ -368,7 +442,7 @@ __global__ __launch_bounds__(256) void gemm_fp8_skinny_kernel(Fp8RowsPair pp) {
 
 // long K: more dynamic LDS than the default limit; once per kernel and device (one process may drive several GPUs)
 static int raise_lds_limit(const void* kernel, int which) {
-    static bool raised[2][64] = {};
+    static bool raised[3][64] = {};
     int device = 0;
     I64H_CHECK_HIP(hipGetDevice(&device));
     if (device < 0 || device >= 64 || !raised[which][device]) {
@@ -462,13 +536,51 @@ int i64h_gemm_fp8_rows_pair(const i64h_fp8_rows_desc* a, const i64h_fp8_rows_des
     const int kmax = b && b->K > a->K ? b->K : a->K;
     const size_t lds = (size_t)F8S_BM * (kmax + 32) + F8S_BM * 4 + 16;
     hipStream_t st = (hipStream_t)stream;
+    RowTailArgs ta;
+    memset(&ta, 0, sizeof(ta));
     if (epilogue) {
         if (lds > 64 * 1024 && raise_lds_limit((const void*)gemm_fp8_skinny_kernel<1>, 1)) return 1;
-        hipLaunchKernelGGL(gemm_fp8_skinny_kernel<1>, dim3((unsigned)(n0 + n1)), dim3(256), lds, st, pp);
+        hipLaunchKernelGGL(gemm_fp8_skinny_kernel<1>, dim3((unsigned)(n0 + n1)), dim3(256), lds, st, pp, ta);
     } else {
         if (lds > 64 * 1024 && raise_lds_limit((const void*)gemm_fp8_skinny_kernel<0>, 0)) return 1;
-        hipLaunchKernelGGL(gemm_fp8_skinny_kernel<0>, dim3((unsigned)(n0 + n1)), dim3(256), lds, st, pp);
+        hipLaunchKernelGGL(gemm_fp8_skinny_kernel<0>, dim3((unsigned)(n0 + n1)), dim3(256), lds, st, pp, ta);
     }
+    I64H_CHECK_LAUNCH();
+    return 0;
+}
+
+// qkv projection of a decode-sized step + per-head QK RMSNorm + rotate-half RoPE + paged-KV write in one launch:
+// i64h_gemm_fp8_rows_pair(d, NULL, 0) followed by i64h_qk_norm_rope_kv(d->C, ...) without the fp32 qkv round trip (d->C is not
+// written).  One group, no row maps, head_dim 64, N = (heads + 2 kv heads) * 64.
+int i64h_gemm_fp8_rows_qkv_rope_kv(const i64h_fp8_rows_desc* d, const float* q_norm_w, const float* k_norm_w, float qk_eps,
+                                   const float* rope_tab, const int32_t* positions, const int32_t* slot_ids, const int32_t* block_table,
+                                   int32_t max_blocks_per_seq, float* q_out, void* k_cache, void* v_cache, int32_t kv_dtype,
+                                   int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, int32_t block_size, void* stream) {
+    I64H_CHECK_ARG(d != nullptr, "gemm_fp8_rows_qkv_rope_kv: problem missing");
+    if (fp8_rows_check(d, 0, "gemm_fp8_rows_qkv_rope_kv")) return 1;
+    I64H_CHECK_ARG(d->group_offsets == nullptr && d->a_src_row == nullptr && d->c_row_map == nullptr,
+                   "gemm_fp8_rows_qkv_rope_kv: one group, no row maps");
+    I64H_CHECK_ARG(head_dim == 64 && d->N == (num_heads + 2 * num_kv_heads) * 64,
+                   "gemm_fp8_rows_qkv_rope_kv: head_dim %d / N %d unsupported (head_dim 64, N = (heads + 2 kv heads) * 64)", head_dim, d->N);
+    I64H_CHECK_ARG(kv_dtype >= 0 && kv_dtype <= 4 && block_size > 0, "gemm_fp8_rows_qkv_rope_kv: bad kv dtype / block size");
+    I64H_CHECK_ARG(positions && slot_ids && block_table && rope_tab && q_out && k_cache && v_cache, "gemm_fp8_rows_qkv_rope_kv: null argument");
+    if (d->M == 0) return 0;
+    RowTailArgs ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.positions = positions; ta.slot_ids = slot_ids; ta.block_table = block_table; ta.max_blocks_per_seq = max_blocks_per_seq;
+    ta.rope_tab = rope_tab; ta.qw = q_norm_w; ta.kw = k_norm_w; ta.qk_eps = qk_eps; ta.q_out = q_out; ta.k_cache = k_cache; ta.v_cache = v_cache;
+    ta.kv_dtype = kv_dtype; ta.nh = num_heads; ta.kvh = num_kv_heads; ta.block = block_size;
+    Fp8RowsPair pp;
+    pp.p[0] = fp8_rows_args(d);
+    pp.p[1] = pp.p[0];
+    const int64_t n0 = fp8_rows_blocks(d, 0);
+    I64H_CHECK_ARG(n0 < (1ll << 31), "gemm_fp8_rows_qkv_rope_kv: grid too large");
+    pp.nblk0 = (int)n0;
+    // the 4 KB head tile reuses the operand codes' LDS and must end in front of the row scales behind them: 16 (K + 32) >= 4096
+    I64H_CHECK_ARG(d->K >= 256, "gemm_fp8_rows_qkv_rope_kv: K=%d too short (>= 256)", d->K);
+    const size_t lds = (size_t)F8S_BM * (d->K + 32) + F8S_BM * 4 + 16;
+    if (lds > 64 * 1024 && raise_lds_limit((const void*)gemm_fp8_skinny_kernel<2>, 2)) return 1;
+    hipLaunchKernelGGL(gemm_fp8_skinny_kernel<2>, dim3((unsigned)n0), dim3(256), lds, (hipStream_t)stream, pp, ta);
     I64H_CHECK_LAUNCH();
     return 0;
 }

@@ -266,6 +266,10 @@ class I64MoEModel:
     # (40.8 us against 46.5 + 22.8 us, 13 ms less kernel time per prefill in the kernel trace), but on a box that has run other
     # processes before the prefill as a whole measured slower with it (545-595 k against 676-680 k tokens/s; 724-728 k on a fresh box)
     FP8_FUSE_NORM = os.environ.get("I64H_FP8_FUSE_NORM", "0") == "1"
+    # e4m3 runner, decode-sized steps: QK norm + RoPE + cache write in the epilogue of the qkv projection (8 instead of 9 launches per
+    # layer, bit-identical).  Off by default: measured slower (2.163 against 2.118 ms per step in alternating runs on one box - the
+    # fused launch takes 13.0 us where the projection takes 7.7 and the row kernel 4.8)
+    FP8_FUSE_QKV = os.environ.get("I64H_FP8_FUSE_QKV", "0") == "1"
     FP8_FRAGS = os.environ.get("I64H_FP8_FRAGS", "1") != "0"  # e4m3 runner: prefill-sized Linears on the operand-stationary kernel
     FUSE_QKV_PREFILL = os.environ.get("I64H_FUSE_QKV_PREFILL", "1") != "0"  # prefill chunks: QK norm + RoPE + cache write in the qkv GEMM's epilogue
     FUSE_NORM_QUANT = os.environ.get("I64H_FUSE_NORM_QUANT", "1") != "0"  # prefill chunks: residual + norm + quantization in one launch
@@ -600,9 +604,17 @@ class I64MoEModel:
         for l, W in enumerate(self.layers):
             if record is not None:
                 record[f"l{l}.in"] = B.h.clone()
-            linear(None if nq else B.normed, B.xa, B.xs, W["qkv"], B.qkv)
-            ops.qk_norm_rope_kv(B.qkv, W["q_norm"], W["k_norm"], 1e-6, self.rope, positions, slot_ids, kvc.block_table,
-                                kvc.k[l], kvc.v[l], cfg.num_heads, cfg.num_kv_heads, cfg.head_dim, q_out=B.q)
+            if (self.FP8_FUSE_QKV and small and not nq and record is None and cfg.head_dim == 64 and ops.fp8_rows_ok(H) and H >= 256
+                    and (W["q_norm"] is None) == (W["k_norm"] is None)):
+                # decode-sized step: QK norm, RoPE and the cache write ride in the epilogue of the qkv projection (one launch)
+                Wq = W["qkv"]
+                ops.gemm_fp8_rows_qkv_rope_kv(ops.fp8_rows_desc(B.normed, Wq.w_q, Wq.w_s, B.qkv, w_frags=Wq.frags(False)), W["q_norm"],
+                                              W["k_norm"], 1e-6, self.rope, positions, slot_ids, kvc.block_table, kvc.k[l], kvc.v[l], B.q,
+                                              cfg.num_heads, cfg.num_kv_heads, cfg.head_dim)
+            else:
+                linear(None if nq else B.normed, B.xa, B.xs, W["qkv"], B.qkv)
+                ops.qk_norm_rope_kv(B.qkv, W["q_norm"], W["k_norm"], 1e-6, self.rope, positions, slot_ids, kvc.block_table,
+                                    kvc.k[l], kvc.v[l], cfg.num_heads, cfg.num_kv_heads, cfg.head_dim, q_out=B.q)
             ops.paged_attn(B.q, kvc.k[l], kvc.v[l], kvc.block_table, ctx_len, slot_ids=None if rows_are_slots else slot_ids,
                            softmax_scale=1.0 / math.sqrt(cfg.head_dim), splits=splits, out=B.attn, workspace=B.attn_ws)
             attn2d = B.attn.view(n, H)

@@ -332,6 +332,16 @@ def gemm_fp8_rows_pair(a_desc, b_desc=None, epilogue: int = EPI_STORE):
     call("i64h_gemm_fp8_rows_pair", ctypes.addressof(a_desc), ctypes.addressof(b_desc) if b_desc is not None else 0, epilogue, _stream())
 
 
+def gemm_fp8_rows_qkv_rope_kv(desc, q_norm_w, k_norm_w, qk_eps, rope_tab, positions, slot_ids, block_table, k_cache, v_cache, q_out,
+                              num_heads: int, num_kv_heads: int, head_dim: int):
+    """qkv projection on e4m3 weights (desc: one problem of gemm_fp8_rows_pair, decode-sized) + QK norm + RoPE + paged-KV write in
+    one launch."""
+    call("i64h_gemm_fp8_rows_qkv_rope_kv", ctypes.addressof(desc), ptr(q_norm_w), ptr(k_norm_w), float(qk_eps), ptr(rope_tab),
+         ptr(positions), ptr(slot_ids), ptr(block_table), block_table.shape[1], ptr(q_out), ptr(k_cache), ptr(v_cache),
+         KV_DTYPE_CODE[k_cache.dtype], num_heads, num_kv_heads, head_dim, k_cache.shape[1], _stream())
+    return q_out
+
+
 def fp8_rows_ok(k: int) -> bool:
     return k % 64 == 0 and k <= 8192
 
