@@ -617,7 +617,10 @@ static_assert(SK_AREA_MIN >= 2 * I64H_STAT_TAB * 4 && SK_AREA_MIN >= 16 * 64 * 4
 
 __host__ __device__ __forceinline__ int sk_pad_tiles(int n_tiles) { return n_tiles >= 6 ? (n_tiles + 7) & ~7 : n_tiles; }
 
-template <int EPI, int NW>
+// HW > 1: the workgroup has HW * NW waves; the extra ("helper") waves take their share of the operand rows - request, quantize,
+// park in LDS - and then only keep the barriers: the phase in front of the K loop is bound by what one wave can request and
+// quantize, not by the CU.
+template <int EPI, int NW, int HW = 1>
 __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const int bid, char* smem, const RowTailArgs& ta) {
     constexpr int NF = (EPI == EPI_SWIGLU) ? 2 : 1;  // B fragments per wave per step
     // K steps (64 deep) whose B fragments are in flight together: all of K = 1024 in one batch (half with two fragments per step)
@@ -632,13 +635,16 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
     int* q_zp = (int*)(q_scale + SK_BM);
 
     const int nout = (EPI == EPI_SWIGLU) ? p.N / 2 : p.N;
-    constexpr int BNB = NW * 16, NT = NW * 64;  // output columns / threads per workgroup
+    constexpr int BNB = NW * 16, NT = NW * HW * 64;  // output columns / threads per workgroup
+    constexpr int CPT = 4 / HW;                     // 16-element operand chunks per thread and pass
+    static_assert(HW == 1 || HW == 2, "helper factor (16 waves leave 128 registers per lane: measured 3.28 against 1.94 ms per step)");
     // workgroups are dealt to the 8 XCDs round-robin and every XCD has an L2 of its own: with the column-tile count padded to a
     // multiple of 8, the row tiles that stream the same weight slice run on ONE XCD and the slice crosses the fabric once
     const int n_tiles = (nout + BNB - 1) / BNB, n_pad = sk_pad_tiles(n_tiles);
     const int mt = bid / n_pad, nt = bid % n_pad;
     if (nt >= n_tiles) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const bool helper = HW > 1 && wid >= NW;  // wave-uniform
 #define SK_STAMP(i) do { if (p.stamps && tid == 0) p.stamps[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     SK_STAMP(0);
     int g, row0, rows;
@@ -658,7 +664,7 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
     // EPI_QKR: cache slot and rotation of this wave's rows (wid, wid + 4, ...) are looked up now, far ahead of their use
     int qk_pos[4] = {0, 0, 0, 0}, qk_pb[4] = {0, 0, 0, 0};
     float qk_c[4] = {0, 0, 0, 0}, qk_s[4] = {0, 0, 0, 0};
-    if constexpr (EPI == EPI_QKR) {
+    if (EPI == EPI_QKR && !helper) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = wid + 4 * j;
@@ -676,14 +682,14 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
     const int8_t* Bg = p.B + (int64_t)g * p.N * K;
     const int I = p.N / 2;
     // this lane's weight rows (output columns)
-    const int col = nt * BNB + wid * 16 + fr;
-    const bool col_ok = col < nout;
+    const int col = nt * BNB + (helper ? 0 : wid) * 16 + fr;
+    const bool col_ok = col < nout && !helper;
     const int8_t* bp[NF];
     int bstep = 64;  // bytes from one K step of a lane's weight stream to the next
     if (p.b_frags) {
         // weights as a fragment pack: fragment (column fragment c, step s) is the 1 KB at (c * K / 64 + s) * 1024 with this lane's
         // 16 bytes at lane * 16 - a wave's load is 8 whole cache lines instead of 16 rows x 64 bytes
-        const int c16 = nt * NW + wid;
+        const int c16 = nt * NW + (helper ? 0 : wid);
         const int c_ok = c16 * 16 < nout ? c16 : 0;
         bp[0] = Bg + (int64_t)c_ok * K * 16 + lane * 16;
         if (NF == 2) bp[1] = Bg + (int64_t)((I >> 4) + c_ok) * K * 16 + lane * 16;
@@ -719,7 +725,7 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int r = i * 16 + fq * 4 + reg;
-                c_row[i][reg] = (p.c_row_map && r < rows) ? p.c_row_map[row0 + r] : row0 + r;
+                c_row[i][reg] = (p.c_row_map && r < rows && !helper) ? p.c_row_map[row0 + r] : row0 + r;
             }
     }
     // SwiGLU with statistics: the slot of each of this lane's four output rows, requested now (the epilogue would otherwise
@@ -731,7 +737,7 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int r = i * 16 + fq * 4 + reg;
-                o_rel[i][reg] = (p.want_stats != 0 && p.out_row_slot && r < rows) ? p.out_row_slot[row0 + r] : 0;
+                o_rel[i][reg] = (p.want_stats != 0 && p.out_row_slot && r < rows && !helper) ? p.out_row_slot[row0 + r] : 0;
             }
     }
 
@@ -753,15 +759,15 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
     const int mfr = (rows + 15) / 16;          // live row fragments
     const int cpr = K / 16;                    // 16-element chunks per row
     const int total_chunks = mfr * 16 * cpr;   // rows padded to whole fragments (padding rows are zero)
-    float4 f[4][4];
-    int rr[4], kc[4];
-    bool aok[4];
+    float4 f[CPT][4];
+    int rr[CPT], kc[CPT];
+    bool aok[CPT];
     // every load is issued (clamped to a valid address) so that the compiler can count the loads in flight; rows outside the
     // tile are zeroed when they are used
     auto a_issue = [&](int c0) {
-        int src[4];
+        int src[CPT];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < CPT; ++u) {
             const int c = c0 + u * NT;
             const int cc = min(c, total_chunks - 1);
             rr[u] = cc / cpr;
@@ -769,23 +775,23 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
             aok[u] = c < total_chunks && rr[u] < rows;
             src[u] = row0 + (rr[u] < rows ? rr[u] : 0);
         }
-        if (p.a_src_row) {  // all four indices are requested before the first one is waited for
+        if (p.a_src_row) {  // all indices are requested before the first one is waited for
 #pragma unroll
-            for (int u = 0; u < 4; ++u) src[u] = p.a_src_row[src[u]];
+            for (int u = 0; u < CPT; ++u) src[u] = p.a_src_row[src[u]];
         }
         if (p.a_src_mod > 0) {  // source rows are int32 entries or tile rows: 32-bit arithmetic
 #pragma unroll
-            for (int u = 0; u < 4; ++u) src[u] = (int)((uint32_t)src[u] % (uint32_t)p.a_src_mod);
+            for (int u = 0; u < CPT; ++u) src[u] = (int)((uint32_t)src[u] % (uint32_t)p.a_src_mod);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < CPT; ++u) {
             const float* ap = (const float*)p.A + (int64_t)src[u] * K + kc[u] * 16;
 #pragma unroll
             for (int e = 0; e < 4; ++e) f[u][e] = *(const float4*)(ap + e * 4);
         }
     };
     a_issue(tid);
-    bload(0);
+    if (!helper) bload(0);
     SK_STAMP(1);
     if (tid < SK_BM) {
         QParams q;
@@ -800,9 +806,9 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
     }
     __syncthreads();
     SK_STAMP(2);
-    for (int c0 = tid; c0 < total_chunks; c0 += NT * 4) {
+    for (int c0 = tid; c0 < total_chunks; c0 += NT * CPT) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < CPT; ++u) {
             const int c = c0 + u * NT;
             if (c >= total_chunks) continue;
             QParams q;
@@ -812,7 +818,7 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
             for (int e = 0; e < 4; ++e) w[e] = aok[u] ? quantize4_u7_signed(f[u][e], q) : 0u;
             *(uint4*)(smem + rr[u] * LDA + kc[u] * 16) = make_uint4(w[0], w[1], w[2], w[3]);
         }
-        if (c0 + NT * 4 < total_chunks) a_issue(c0 + NT * 4);
+        if (c0 + NT * CPT < total_chunks) a_issue(c0 + NT * CPT);
     }
     __syncthreads();
     SK_STAMP(3);
@@ -822,7 +828,7 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
     for (int i = 0; i < SK_MF; ++i)
 #pragma unroll
         for (int f = 0; f < NF; ++f) acc[i][f] = (v4i){0, 0, 0, 0};
-    for (int s0 = 0; s0 < nsteps; s0 += SK_STEPS) {
+    for (int s0 = 0; s0 < (helper ? 0 : nsteps); s0 += SK_STEPS) {
         v4i bc[NF][SK_STEPS];
 #pragma unroll
         for (int s = 0; s < SK_STEPS; ++s)
@@ -858,17 +864,19 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
         static_assert(SK_MF == 1 && NW == 4, "one row fragment, four waves = 64 columns");
         __syncthreads();  // the operand rows in LDS are no longer needed
         float* s_c = (float*)smem;  // [16][64]
+        if (!helper) {
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int r = fq * 4 + reg;
-            s_c[r * 64 + wid * 16 + fr] = (float)acc[0][0][reg] * (q_scale[r] * ws);
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = fq * 4 + reg;
+                s_c[r * 64 + wid * 16 + fr] = (float)acc[0][0][reg] * (q_scale[r] * ws);
+            }
         }
         __syncthreads();
         const int head = nt, nh = ta.nh, kvh = ta.kvh, hd = 64, half = 32;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = wid + 4 * j;
-            if (r >= rows) break;
+            if (r >= rows || helper) break;
             const int64_t t = row0 + r;
             const int pos = qk_pos[j], pb = qk_pb[j];
             const int64_t cache_row = ((int64_t)pb * ta.block + pos % ta.block) * kvh;  // in heads
@@ -903,6 +911,7 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
         for (int i = 0; i < SK_MF; ++i)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
+                if (helper) break;
                 const int r = i * 16 + fq * 4 + reg;
                 const bool rok = r < rows;
                 const float m = rok ? q_scale[r] * ws : 0.0f;
@@ -944,11 +953,11 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
 #undef SK_STAMP
 }
 
-template <int EPI, int NW>
-__global__ __launch_bounds__(NW * 64) void gemm_i8_skinny_kernel(GemmI8Pair pp, RowTailArgs ta) {
+template <int EPI, int NW, int HW = 1>
+__global__ __launch_bounds__(NW * HW * 64) void gemm_i8_skinny_kernel(GemmI8Pair pp, RowTailArgs ta) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if ((int)blockIdx.x < pp.nblk0) gemm_i8_skinny_body<EPI, NW>(pp.p[0], blockIdx.x, smem, ta);
-    else gemm_i8_skinny_body<EPI, NW>(pp.p[1], blockIdx.x - pp.nblk0, smem, ta);
+    if ((int)blockIdx.x < pp.nblk0) gemm_i8_skinny_body<EPI, NW, HW>(pp.p[0], blockIdx.x, smem, ta);
+    else gemm_i8_skinny_body<EPI, NW, HW>(pp.p[1], blockIdx.x - pp.nblk0, smem, ta);
 }
 
 // ---- fp32 GEMM on the f32 matrix cores: C[M,N] = A[M,K] @ B[N,K]^T ------------------------------------------------
@@ -1223,9 +1232,13 @@ static int skinny_blocks(const i64h_gemm_desc* d, int bnb) {
 }
 
 static int g_skinny_waves = 0;  // 0 = default; test/tuning override through i64h_set_skinny_waves
+static int g_skinny_helpers = 1;  // four-wave workgroups get four helper waves for the operand rows (i64h_set_skinny_helpers)
 
-template <int EPI, int NW>
+template <int EPI, int NW, int HW = 1>
 static int launch_skinny(const i64h_gemm_desc* a, const i64h_gemm_desc* b, hipStream_t st, const RowTailArgs* tail = nullptr) {
+    if constexpr (NW == 4 && HW == 1) {
+        if (g_skinny_helpers) return launch_skinny<EPI, 4, 2>(a, b, st, tail);
+    }
     RowTailArgs ta;
     if (tail) ta = *tail; else memset(&ta, 0, sizeof(ta));
     GemmI8Pair pp;
@@ -1247,11 +1260,11 @@ static int launch_skinny(const i64h_gemm_desc* a, const i64h_gemm_desc* b, hipSt
         int device = 0;
         I64H_CHECK_HIP(hipGetDevice(&device));
         if (device < 0 || device >= 64 || !raised[device]) {
-            I64H_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_i8_skinny_kernel<EPI, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            I64H_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_i8_skinny_kernel<EPI, NW, HW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             if (device >= 0 && device < 64) raised[device] = true;
         }
     }
-    hipLaunchKernelGGL((gemm_i8_skinny_kernel<EPI, NW>), dim3((unsigned)total), dim3(NW * 64), lds, st, pp, ta);
+    hipLaunchKernelGGL((gemm_i8_skinny_kernel<EPI, NW, HW>), dim3((unsigned)total), dim3(NW * HW * 64), lds, st, pp, ta);
     I64H_CHECK_LAUNCH();
     return 0;
 }
@@ -1276,6 +1289,12 @@ static bool skinny_ok(const i64h_gemm_desc* d) {
 }
 
 extern "C" {
+
+// tuning knob: 1 (default) = the decode-sized kernel's four-wave workgroups get four helper waves for the operand rows
+int i64h_set_skinny_helpers(int32_t on) {
+    g_skinny_helpers = on ? 1 : 0;
+    return 0;
+}
 
 // tuning knob: 1 (default) = short-K prefill-sized problems use 64-byte stages, four workgroups per CU; 0 = always 128-byte stages
 int i64h_set_gemm_stage64(int32_t on) {
