@@ -624,7 +624,8 @@ template <int EPI, int NW, int HW = 1>
 __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const int bid, char* smem, const RowTailArgs& ta) {
     constexpr int NF = (EPI == EPI_SWIGLU) ? 2 : 1;  // B fragments per wave per step
     // K steps (64 deep) whose B fragments are in flight together: all of K = 1024 in one batch (half with two fragments per step)
-    constexpr int SK_STEPS = 16 / NF;
+    // (with helper waves a wave streams half of K: 8 steps cover K = 1024 in one batch for either epilogue)
+    constexpr int SK_STEPS = HW > 1 ? 8 : 16 / NF;
     const int K = p.K, LDA = K + 32;
     // LDS: operand rows [16][LDA] int8, reused by the epilogues (statistics table, head tile of EPI_QKR: SK_AREA_MIN bytes at
     // least, which matters for K < 224) | info (16 B) | q_inv[16] q_scale[16] q_zp[16]
@@ -682,21 +683,30 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
     const int8_t* Bg = p.B + (int64_t)g * p.N * K;
     const int I = p.N / 2;
     // this lane's weight rows (output columns)
-    const int col = nt * BNB + (helper ? 0 : wid) * 16 + fr;
-    const bool col_ok = col < nout && !helper;
+    // With helper waves and room in LDS for the partial sums, a helper wave also takes the second half of the K steps of the
+    // column fragment of main wave wid - NW (integer partial sums add exactly, in any order)
+    const int wcol = helper ? wid - NW : wid;
+    const int col = nt * BNB + wcol * 16 + fr;
+    const bool col_in = col < nout;
+    const bool col_ok = col_in && !helper;
+    constexpr int PART_OFF = SK_AREA_MIN, PART_BYTES = NW * SK_MF * NF * 64 * 16;
+    const bool ksplit = HW > 1 && SK_BM * LDA >= PART_OFF + PART_BYTES && nsteps >= 2;  // uniform over the workgroup
+    const int s_half = (nsteps + 1) / 2;
+    const int s_begin = (ksplit && helper) ? s_half : 0;
+    const int s_end = ksplit ? (helper ? nsteps : s_half) : (helper ? 0 : nsteps);
     const int8_t* bp[NF];
     int bstep = 64;  // bytes from one K step of a lane's weight stream to the next
     if (p.b_frags) {
         // weights as a fragment pack: fragment (column fragment c, step s) is the 1 KB at (c * K / 64 + s) * 1024 with this lane's
         // 16 bytes at lane * 16 - a wave's load is 8 whole cache lines instead of 16 rows x 64 bytes
-        const int c16 = nt * NW + (helper ? 0 : wid);
+        const int c16 = nt * NW + wcol;
         const int c_ok = c16 * 16 < nout ? c16 : 0;
         bp[0] = Bg + (int64_t)c_ok * K * 16 + lane * 16;
         if (NF == 2) bp[1] = Bg + (int64_t)((I >> 4) + c_ok) * K * 16 + lane * 16;
         bstep = 1024;
     } else {
-        bp[0] = Bg + (int64_t)(col_ok ? col : 0) * K + fq * 16;
-        if (NF == 2) bp[1] = Bg + (int64_t)(I + (col_ok ? col : 0)) * K + fq * 16;
+        bp[0] = Bg + (int64_t)(col_in ? col : 0) * K + fq * 16;
+        if (NF == 2) bp[1] = Bg + (int64_t)(I + (col_in ? col : 0)) * K + fq * 16;
     }
 
     // the statistics of the rows' Linear calls are requested first: vector loads retire in order, so everything that is
@@ -791,7 +801,7 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
         }
     };
     a_issue(tid);
-    if (!helper) bload(0);
+    if (s_end > s_begin) bload(s_begin);
     SK_STAMP(1);
     if (tid < SK_BM) {
         QParams q;
@@ -828,16 +838,16 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
     for (int i = 0; i < SK_MF; ++i)
 #pragma unroll
         for (int f = 0; f < NF; ++f) acc[i][f] = (v4i){0, 0, 0, 0};
-    for (int s0 = 0; s0 < (helper ? 0 : nsteps); s0 += SK_STEPS) {
+    for (int s0 = s_begin; s0 < s_end; s0 += SK_STEPS) {
         v4i bc[NF][SK_STEPS];
 #pragma unroll
         for (int s = 0; s < SK_STEPS; ++s)
 #pragma unroll
             for (int f = 0; f < NF; ++f) bc[f][s] = bq[f][s];
-        if (s0 + SK_STEPS < nsteps) bload(s0 + SK_STEPS);  // next batch streams in behind the MFMAs of this one
+        if (s0 + SK_STEPS < s_end) bload(s0 + SK_STEPS);  // next batch streams in behind the MFMAs of this one
 #pragma unroll
         for (int s = 0; s < SK_STEPS; ++s) {
-            if (s0 + s >= nsteps) break;
+            if (s0 + s >= s_end) break;
 #pragma unroll
             for (int i = 0; i < SK_MF; ++i) {
                 if (i >= mfr) break;
@@ -848,6 +858,23 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
         }
     }
 
+    if (HW > 1 && ksplit) {
+        __syncthreads();  // every wave is done with the operand rows: their LDS takes the helper waves' partial sums
+        v4i* part = (v4i*)(smem + PART_OFF) + (wcol * (SK_MF * NF)) * 64 + lane;
+        if (helper) {
+#pragma unroll
+            for (int i = 0; i < SK_MF; ++i)
+#pragma unroll
+                for (int f = 0; f < NF; ++f) part[(i * NF + f) * 64] = acc[i][f];
+        }
+        __syncthreads();
+        if (!helper) {
+#pragma unroll
+            for (int i = 0; i < SK_MF; ++i)
+#pragma unroll
+                for (int f = 0; f < NF; ++f) acc[i][f] += part[(i * NF + f) * 64];
+        }
+    }
     SK_STAMP(4);
     if constexpr (EPI == EPI_STORE) {
 #pragma unroll
