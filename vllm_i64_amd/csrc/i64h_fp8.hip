@@ -200,8 +200,10 @@ struct Fp8RowsPair {
 // EPI 2: the workgroup's 64 columns are one 64-wide head of the fused qkv projection - per-head RMSNorm, rotate-half RoPE, q to
 // q_out, K / V into the paged cache in the epilogue (the arithmetic and operation order of qk_norm_rope_kv_kernel on the values
 // EPI 0 would have stored; p.C is not written).
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_fp8_skinny_kernel(Fp8RowsPair pp, RowTailArgs ta) {
+// HW = 2: eight waves - all of them request and quantize the operand rows (32 threads per row), waves 4..7 then only keep the
+// barriers: the phase in front of the K loop is bound by what one wave can request and convert, not by the CU.
+template <int EPI, int HW = 2>
+__global__ __launch_bounds__(256 * HW) void gemm_fp8_skinny_kernel(Fp8RowsPair pp, RowTailArgs ta) {
     extern __shared__ __attribute__((aligned(16))) char f8s_smem[];
     const bool second = (int)blockIdx.x >= pp.nblk0;
     const Fp8RowsArgs& p = pp.p[second ? 1 : 0];
@@ -221,6 +223,7 @@ __global__ __launch_bounds__(256) void gemm_fp8_skinny_kernel(Fp8RowsPair pp, Ro
     float* row_s = (float*)(f8s_smem + F8S_BM * LDA);        // [16] scales
     int* s_info = (int*)(row_s + F8S_BM);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const bool helper = HW > 1 && wid >= 4;  // wave-uniform
     const int fr = lane & 15, fq = lane >> 4;
     const int I = N / 2, nout = EPI == 1 ? I : N;
     const int n_tiles = (nout + 63) / 64;
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(256) void gemm_fp8_skinny_kernel(Fp8RowsPair pp, Ro
     int qk_pos[4] = {0, 0, 0, 0}, qk_pb[4] = {0, 0, 0, 0}, qk_sl[4] = {0, 0, 0, 0};
     float qk_c[4] = {0, 0, 0, 0}, qk_s[4] = {0, 0, 0, 0};
     float qk_w = 1.0f;  // this lane's norm weight (head = column tile nt)
-    if constexpr (EPI == 2) {
+    if (EPI == 2 && !helper) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int rj = wid + 4 * j;
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(256) void gemm_fp8_skinny_kernel(Fp8RowsPair pp, Ro
         if (nw && nt < ta.nh + ta.kvh) qk_w = nw[lane];
     }
     auto tail_lookup = [&]() {
-        if constexpr (EPI == 2) {
+        if (EPI == 2 && !helper) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 qk_pb[j] = ta.block_table[(int64_t)qk_sl[j] * ta.max_blocks_per_seq + qk_pos[j] / ta.block];
@@ -283,8 +286,9 @@ __global__ __launch_bounds__(256) void gemm_fp8_skinny_kernel(Fp8RowsPair pp, Ro
             }
         }
     };
-    // ---- operand rows: thread (r = tid / 16, c = tid % 16) owns float4 chunks c, c + 16, ... of row r ----
-    const int r = tid >> 4, c = tid & 15;
+    // ---- operand rows: thread (r = tid / TPR, c = tid % TPR) owns float4 chunks c, c + TPR, ... of row r ----
+    constexpr int TPR = 16 * HW, MAXV = F8S_MAXV / HW;  // threads per row; float4 per thread kept in registers
+    const int r = tid / TPR, c = tid % TPR;
     const bool rok = r < rows;
     int64_t src = row0 + (rok ? r : 0);
     if (a_src_row) src = a_src_row[src] % a_src_mod;
@@ -292,15 +296,15 @@ __global__ __launch_bounds__(256) void gemm_fp8_skinny_kernel(Fp8RowsPair pp, Ro
     const int nv = K / 4;
     // this lane's weight columns, requested behind the rows (loads return in order: the rows can be quantized while the
     // weights are still on their way)
-    const int col = nt * 64 + wid * 16 + fr;
-    const bool col_ok = col < nout;
+    const int col = nt * 64 + (helper ? 0 : wid) * 16 + fr;
+    const bool col_ok = col < nout && !helper;
     const uint8_t* Bg = B + (int64_t)g * N * K;
     const uint8_t* bp[NF];
     int bstep = 64;  // bytes from one 64-byte K block of a lane's weight stream to the next
     if (p.b_frags) {
         // fragment (column fragment c, K block t) = the 1 KB at (c * K / 64 + t) * 1024, this lane's 16 bytes at lane * 16: a wave's
         // load is 8 whole cache lines instead of 16 rows x 64 bytes
-        const int c16 = nt * 4 + wid;
+        const int c16 = nt * 4 + (helper ? 0 : wid);
         const int c_ok = c16 * 16 < nout ? c16 : 0;
         bp[0] = Bg + (int64_t)c_ok * K * 16 + lane * 16;
         if constexpr (NF == 2) bp[1] = Bg + (int64_t)((I >> 4) + c_ok) * K * 16 + lane * 16;
@@ -310,8 +314,8 @@ __global__ __launch_bounds__(256) void gemm_fp8_skinny_kernel(Fp8RowsPair pp, Ro
         if constexpr (NF == 2) bp[1] = Bg + (int64_t)(I + (col_ok ? col : 0)) * K + fq * 16;
     }
     float m = 0.0f;
-    const bool in_regs = nv <= 16 * F8S_MAXV;
-    float4 v[F8S_MAXV];
+    const bool in_regs = nv <= TPR * MAXV;
+    float4 v[MAXV];
     const int nblk = K / 64;
     constexpr int BATCH = 8;
     uint4 bq[NF][BATCH];
@@ -325,34 +329,35 @@ __global__ __launch_bounds__(256) void gemm_fp8_skinny_kernel(Fp8RowsPair pp, Ro
     };
     if (in_regs) {
 #pragma unroll
-        for (int j = 0; j < F8S_MAXV; ++j) {
-            const int i = c + 16 * j;
+        for (int j = 0; j < MAXV; ++j) {
+            const int i = c + TPR * j;
             v[j] = (rok && i < nv) ? ap[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        bload(0);
+        if (!helper) bload(0);
         tail_lookup();
 #pragma unroll
-        for (int j = 0; j < F8S_MAXV; ++j) m = fmaxf(m, fmaxf(fmaxf(fabsf(v[j].x), fabsf(v[j].y)), fmaxf(fabsf(v[j].z), fabsf(v[j].w))));
+        for (int j = 0; j < MAXV; ++j) m = fmaxf(m, fmaxf(fmaxf(fabsf(v[j].x), fabsf(v[j].y)), fmaxf(fabsf(v[j].z), fabsf(v[j].w))));
     } else {
-        for (int i = c; i < nv; i += 16) {
+        for (int i = c; i < nv; i += TPR) {
             const float4 x = rok ? ap[i] : make_float4(0.f, 0.f, 0.f, 0.f);
             m = fmaxf(m, fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w))));
         }
-        bload(0);
+        if (!helper) bload(0);
         tail_lookup();
     }
-    m = row16_max(m);  // the 16 threads of a row are 16 consecutive lanes
+    m = row16_max(m);  // the threads of a row are 16 (32) consecutive lanes
+    if constexpr (HW == 2) m = fmaxf(m, lane_xor(m, 16));
     const float sc = fmaxf(m, 1e-12f) / 448.0f;
     if (c == 0) row_s[r] = rok ? sc : 0.0f;
     auto q4 = [&](float4 x) -> uint32_t { return pack4_e4m3fn(clamp448(x.x / sc), clamp448(x.y / sc), clamp448(x.z / sc), clamp448(x.w / sc)); };
     if (in_regs) {
 #pragma unroll
-        for (int j = 0; j < F8S_MAXV; ++j) {
-            const int i = c + 16 * j;
+        for (int j = 0; j < MAXV; ++j) {
+            const int i = c + TPR * j;
             if (i < nv) *(uint32_t*)(rows_q + r * LDA + i * 4) = rok ? q4(v[j]) : 0u;
         }
     } else {
-        for (int i = c; i < nv; i += 16) *(uint32_t*)(rows_q + r * LDA + i * 4) = rok ? q4(ap[i]) : 0u;  // second read: cache
+        for (int i = c; i < nv; i += TPR) *(uint32_t*)(rows_q + r * LDA + i * 4) = rok ? q4(ap[i]) : 0u;  // second read: cache
     }
     __syncthreads();
 
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(256) void gemm_fp8_skinny_kernel(Fp8RowsPair pp, Ro
     v4f acc[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) acc[f] = (v4f){0.f, 0.f, 0.f, 0.f};
-    for (int t0 = 0; t0 < nblk; t0 += BATCH) {
+    for (int t0 = 0; t0 < (helper ? 0 : nblk); t0 += BATCH) {
         uint4 bc[NF][BATCH];
 #pragma unroll
         for (int t = 0; t < BATCH; ++t)
@@ -388,17 +393,19 @@ __global__ __launch_bounds__(256) void gemm_fp8_skinny_kernel(Fp8RowsPair pp, Ro
         const float ws0 = b_scale[(int64_t)g * N + col];
         __syncthreads();  // the operand codes in LDS are no longer needed (their scales lie behind them and stay)
         float* s_c = (float*)f8s_smem;  // [16][64]
+        if (!helper) {
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int rr = fq * 4 + reg;
-            s_c[rr * 64 + wid * 16 + fr] = acc[0][reg] * (row_s[rr] * ws0);
+            for (int reg = 0; reg < 4; ++reg) {
+                const int rr = fq * 4 + reg;
+                s_c[rr * 64 + wid * 16 + fr] = acc[0][reg] * (row_s[rr] * ws0);
+            }
         }
         __syncthreads();
         const int head = nt, nh = ta.nh, kvh = ta.kvh, hd = 64, half = 32;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int rj = wid + 4 * j;
-            if (rj >= rows) break;
+            if (rj >= rows || helper) break;
             const int64_t t = row0 + rj;
             const int pos = qk_pos[j], pb = qk_pb[j];
             const int64_t cache_row = ((int64_t)pb * ta.block + pos % ta.block) * kvh;  // in heads
@@ -540,10 +547,10 @@ int i64h_gemm_fp8_rows_pair(const i64h_fp8_rows_desc* a, const i64h_fp8_rows_des
     memset(&ta, 0, sizeof(ta));
     if (epilogue) {
         if (lds > 64 * 1024 && raise_lds_limit((const void*)gemm_fp8_skinny_kernel<1>, 1)) return 1;
-        hipLaunchKernelGGL(gemm_fp8_skinny_kernel<1>, dim3((unsigned)(n0 + n1)), dim3(256), lds, st, pp, ta);
+        hipLaunchKernelGGL(gemm_fp8_skinny_kernel<1>, dim3((unsigned)(n0 + n1)), dim3(512), lds, st, pp, ta);
     } else {
         if (lds > 64 * 1024 && raise_lds_limit((const void*)gemm_fp8_skinny_kernel<0>, 0)) return 1;
-        hipLaunchKernelGGL(gemm_fp8_skinny_kernel<0>, dim3((unsigned)(n0 + n1)), dim3(256), lds, st, pp, ta);
+        hipLaunchKernelGGL(gemm_fp8_skinny_kernel<0>, dim3((unsigned)(n0 + n1)), dim3(512), lds, st, pp, ta);
     }
     I64H_CHECK_LAUNCH();
     return 0;
@@ -580,7 +587,7 @@ int i64h_gemm_fp8_rows_qkv_rope_kv(const i64h_fp8_rows_desc* d, const float* q_n
     I64H_CHECK_ARG(d->K >= 256, "gemm_fp8_rows_qkv_rope_kv: K=%d too short (>= 256)", d->K);
     const size_t lds = (size_t)F8S_BM * (d->K + 32) + F8S_BM * 4 + 16;
     if (lds > 64 * 1024 && raise_lds_limit((const void*)gemm_fp8_skinny_kernel<2>, 2)) return 1;
-    hipLaunchKernelGGL(gemm_fp8_skinny_kernel<2>, dim3((unsigned)n0), dim3(256), lds, (hipStream_t)stream, pp, ta);
+    hipLaunchKernelGGL(gemm_fp8_skinny_kernel<2>, dim3((unsigned)n0), dim3(512), lds, (hipStream_t)stream, pp, ta);
     I64H_CHECK_LAUNCH();
     return 0;
 }

@@ -1263,8 +1263,8 @@ static int g_skinny_helpers = 1;  // four-wave workgroups get four helper waves 
 
 template <int EPI, int NW, int HW = 1>
 static int launch_skinny(const i64h_gemm_desc* a, const i64h_gemm_desc* b, hipStream_t st, const RowTailArgs* tail = nullptr) {
-    if constexpr (NW == 4 && HW == 1) {
-        if (g_skinny_helpers) return launch_skinny<EPI, 4, 2>(a, b, st, tail);
+    if constexpr ((NW == 4 || NW == 2) && HW == 1) {
+        if (g_skinny_helpers) return launch_skinny<EPI, NW, 2>(a, b, st, tail);
     }
     RowTailArgs ta;
     if (tail) ta = *tail; else memset(&ta, 0, sizeof(ta));

@@ -200,6 +200,8 @@ class I64MoEModel:
         its own sequences, attention, dense projections and shared expert (an engine of its own for those calls), and each MoE
         layer exchanges the routed rows with one all-to-all each way (vllm_i64_amd/ep.py)."""
         ops.call("i64h_set_skinny_helpers", int(self.SKINNY_HELPERS))
+        if os.environ.get("I64H_SKINNY_WAVES"):
+            ops.call("i64h_set_skinny_waves", int(os.environ["I64H_SKINNY_WAVES"]))
         self.cfg, self.device = cfg, torch.device(device)
         dev = self.device
         assert quant in ("int8", "fp8")
@@ -268,9 +270,8 @@ class I64MoEModel:
     # processes before the prefill as a whole measured slower with it (545-595 k against 676-680 k tokens/s; 724-728 k on a fresh box)
     FP8_FUSE_NORM = os.environ.get("I64H_FP8_FUSE_NORM", "0") == "1"
     # e4m3 runner, decode-sized steps: QK norm + RoPE + cache write in the epilogue of the qkv projection (8 instead of 9 launches per
-    # layer, bit-identical).  Off by default: measured slower (2.163 against 2.118 ms per step in alternating runs on one box - the
-    # fused launch takes 13.0 us where the projection takes 7.7 and the row kernel 4.8)
-    FP8_FUSE_QKV = os.environ.get("I64H_FP8_FUSE_QKV", "0") == "1"
+    # layer, bit-identical; 2.017 -> 1.992 ms per step once the kernel had its helper waves - before that it measured slower)
+    FP8_FUSE_QKV = os.environ.get("I64H_FP8_FUSE_QKV", "1") != "0"
     FP8_FRAGS = os.environ.get("I64H_FP8_FRAGS", "1") != "0"  # e4m3 runner: prefill-sized Linears on the operand-stationary kernel
     FUSE_QKV_PREFILL = os.environ.get("I64H_FUSE_QKV_PREFILL", "1") != "0"  # prefill chunks: QK norm + RoPE + cache write in the qkv GEMM's epilogue
     FUSE_NORM_QUANT = os.environ.get("I64H_FUSE_NORM_QUANT", "1") != "0"  # prefill chunks: residual + norm + quantization in one launch
