@@ -523,9 +523,9 @@ static Fp8RowsArgs fp8_rows_args(const i64h_fp8_rows_desc* d) {
 }
 static int64_t fp8_rows_blocks(const i64h_fp8_rows_desc* d, int epilogue) {
     if (d->M == 0) return 0;
-    const int G = d->group_offsets ? d->num_groups : 1;
     const int nout = epilogue ? d->N / 2 : d->N;
-    return ((d->M + F8S_BM - 1) / F8S_BM + G) * (int64_t)((nout + 63) / 64);
+    // grouped: an upper bound on the row tiles (every group may end with a partial tile); one group: exact
+    return ((d->M + F8S_BM - 1) / F8S_BM + (d->group_offsets ? d->num_groups : 0)) * (int64_t)((nout + 63) / 64);
 }
 
 int i64h_gemm_fp8_rows_pair(const i64h_fp8_rows_desc* a, const i64h_fp8_rows_desc* b, int32_t epilogue, void* stream) {

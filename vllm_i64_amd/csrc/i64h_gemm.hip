@@ -1252,9 +1252,9 @@ static bool rs_ok(const i64h_gemm_desc* d) {
 }
 
 static int skinny_blocks(const i64h_gemm_desc* d, int bnb) {
-    const int G = d->group_offsets ? d->num_groups : 1;
     const int nout = d->epilogue == EPI_SWIGLU ? d->N / 2 : d->N;
-    const int m_tiles = (int)((d->M_total + SK_BM - 1) / SK_BM) + G;
+    // grouped: an upper bound (every group may end with a partial tile); one group: exact
+    const int m_tiles = (int)((d->M_total + SK_BM - 1) / SK_BM) + (d->group_offsets ? d->num_groups : 0);
     return d->M_total == 0 ? 0 : m_tiles * sk_pad_tiles((nout + bnb - 1) / bnb);
 }
 

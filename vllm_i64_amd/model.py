@@ -644,15 +644,16 @@ class I64MoEModel:
                 if paired:
                     # decode-sized step: two launches, each with the routed experts (rows gathered in bucket order = grouped by
                     # expert, results scattered back into (route, token) order) and the shared expert as its second problem
+                    # (the shared expert's tiles first: the surplus tiles of the grouped problem's upper bound end the launch)
                     ops.gemm_fp8_rows_pair(
+                        ops.fp8_rows_desc(B.normed, W["sh_gu"].w_q, W["sh_gu"].w_s, B.sh_inter, w_frags=W["sh_gu"].frags(True)),
                         ops.fp8_rows_desc(B.normed, W["exp_gu"].w_q, W["exp_gu"].w_s, B.e_inter, m=R, a_src_row=plan.perm[l], a_src_mod=n,
                                           group_offsets=plan.expert_offsets[l], w_frags=W["exp_gu"].frags(True)),
-                        ops.fp8_rows_desc(B.normed, W["sh_gu"].w_q, W["sh_gu"].w_s, B.sh_inter, w_frags=W["sh_gu"].frags(True)),
                         epilogue=ops.EPI_SWIGLU)
                     ops.gemm_fp8_rows_pair(
+                        ops.fp8_rows_desc(B.sh_inter, W["sh_dn"].w_q, W["sh_dn"].w_s, B.sh_out, w_frags=W["sh_dn"].frags()),
                         ops.fp8_rows_desc(B.e_inter, W["exp_dn"].w_q, W["exp_dn"].w_s, B.e_out, group_offsets=plan.expert_offsets[l],
-                                          c_row_map=plan.perm[l], w_frags=W["exp_dn"].frags()),
-                        ops.fp8_rows_desc(B.sh_inter, W["sh_dn"].w_q, W["sh_dn"].w_s, B.sh_out, w_frags=W["sh_dn"].frags()))
+                                          c_row_map=plan.perm[l], w_frags=W["exp_dn"].frags()))
                 else:
                     if R:
                         # rows in bucket order are grouped by expert; the gather out of the token rows and the scatter back into
@@ -702,7 +703,9 @@ class I64MoEModel:
             s_gu = ops.gemm_desc(B.normed, W["sh_gu"].w_q, W["sh_gu"].w_s, B.sh_inter, a_slot_base=base + 2, epilogue=ops.EPI_SWIGLU,
                                  out_slot_base=base + 3 + nbk, stats=st, want_stats=True,
                                  w_frags=self._wf(W["sh_gu"], ops.EPI_SWIGLU, W["exp_gu"])) if shared else None
-            ops.gemm_i8_pair(e_gu, s_gu)
+            # the shared expert's tiles go first: the surplus tiles of the grouped problem's upper bound are then the launch's last
+            # workgroups (they exit at once) instead of real tiles that wait for a free CU
+            ops.gemm_i8_pair(s_gu, e_gu) if s_gu is not None else ops.gemm_i8_pair(e_gu)
             # the down projection stores its rows straight back in (route, token) order (plan.perm: sorted row -> k * n + t), so
             # the combine needs no index lookup in front of its row reads
             e_dn = ops.gemm_desc(B.e_inter, W["exp_dn"].w_q, W["exp_dn"].w_s, B.e_out, a_row_slot=plan.sorted_bucket[l],
@@ -710,7 +713,7 @@ class I64MoEModel:
                                  c_row_map=plan.perm[l], a_group_slots=cfg.top_k, w_frags=self._wf(W["exp_dn"], partner=W["sh_dn"] if shared else None))
             s_dn = ops.gemm_desc(B.sh_inter, W["sh_dn"].w_q, W["sh_dn"].w_s, B.sh_out, a_slot_base=base + 3 + nbk, stats=st,
                                  w_frags=self._wf(W["sh_dn"], partner=W["exp_dn"])) if shared else None
-            ops.gemm_i8_pair(e_dn, s_dn)
+            ops.gemm_i8_pair(s_dn, e_dn) if s_dn is not None else ops.gemm_i8_pair(e_dn)
             return None
         if shared:
             if prequantized:
