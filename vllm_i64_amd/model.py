@@ -761,13 +761,13 @@ class I64MoEModel:
             s_gu = ops.gemm_desc(B.normed, W["sh_gu"].w_q, W["sh_gu"].w_s, B.sh_inter, a_slot_base=base + spl - 1, epilogue=ops.EPI_SWIGLU,
                                  out_slot_base=base + 3 + nbk, stats=st, want_stats=True,
                                  w_frags=self._wf(W["sh_gu"], ops.EPI_SWIGLU, W["exp_gu"])) if shared else None
-            ops.gemm_i8_pair(e_gu, s_gu)
+            ops.gemm_i8_pair(s_gu, e_gu) if s_gu is not None else ops.gemm_i8_pair(e_gu)   # (shared expert's tiles first, as in _moe)
             e_dn = ops.gemm_desc(B.e_inter, W["exp_dn"].w_q, W["exp_dn"].w_s, out_buf, a_row_slot=plan.sorted_bucket[l],
                                  a_slot_base=base + 4 + nbk, group_offsets=eo, stats=st, m_total=R, c_row_map=c_map,
                                  w_frags=self._wf(W["exp_dn"], partner=W["sh_dn"] if shared else None))
             s_dn = ops.gemm_desc(B.sh_inter, W["sh_dn"].w_q, W["sh_dn"].w_s, B.sh_out, a_slot_base=base + 3 + nbk, stats=st,
                                  w_frags=self._wf(W["sh_dn"], partner=W["exp_dn"])) if shared else None
-            ops.gemm_i8_pair(e_dn, s_dn)
+            ops.gemm_i8_pair(s_dn, e_dn) if s_dn is not None else ops.gemm_i8_pair(e_dn)
             return ep.exchange(B.xsend, recv=B.xrecv).view(-1, H), B.recv_map[l]
         if shared:
             self._linear(B.normed, W["sh_gu"], base + spl - 1, B.xa, B.xs, B.sh_inter, epilogue=ops.EPI_SWIGLU, stats_slot=base + 3 + nbk)
