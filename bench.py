@@ -314,13 +314,31 @@ def main():
     splits = Bf.attn_splits
     # one event pair around the launches of all layers (every layer's cache is cold again by the time its turn comes), so that
     # the figure is the kernel's duration as a kernel trace reports it, without an event record and its gap in front of each launch
+    def attn_all_layers():
+        for l in range(cfg.num_layers):
+            ops.paged_attn(Bf.q, model.kv.k[l], model.kv.v[l], model.kv.block_table, dec.ctx_len, slot_ids=dec.slot_ids,
+                           softmax_scale=cfg.head_dim ** -0.5, splits=splits, out=Bf.attn, workspace=Bf.attn_ws)
+    # the launches go out as one graph replay, as in the decode step (launched one by one from the host, the gaps between them
+    # vary by a microsecond or two from box to box and end up in the figure)
+    attn_graph = None
+    if used_graph:
+        try:
+            attn_all_layers()
+            torch.cuda.synchronize()
+            attn_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(attn_graph, capture_error_mode="thread_local"):
+                attn_all_layers()
+        except Exception:
+            attn_graph = None
+            torch.cuda.synchronize()
     evs = []
     for rep in range(4):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for l in range(cfg.num_layers):
-            ops.paged_attn(Bf.q, model.kv.k[l], model.kv.v[l], model.kv.block_table, dec.ctx_len, slot_ids=dec.slot_ids,
-                           softmax_scale=cfg.head_dim ** -0.5, splits=splits, out=Bf.attn, workspace=Bf.attn_ws)
+        if attn_graph is not None:
+            attn_graph.replay()
+        else:
+            attn_all_layers()
         e1.record()
         evs.append((e0, e1))
     torch.cuda.synchronize()
