@@ -665,10 +665,11 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
     // EPI_QKR: cache slot and rotation of this wave's rows (wid, wid + 4, ...) are looked up now, far ahead of their use
     int qk_pos[4] = {0, 0, 0, 0}, qk_pb[4] = {0, 0, 0, 0};
     float qk_c[4] = {0, 0, 0, 0}, qk_s[4] = {0, 0, 0, 0};
-    if (EPI == EPI_QKR && !helper) {
+    constexpr int TW = NW * HW, QKJ = 16 / TW;  // EPI_QKR: every wave (helpers included) finishes rows wid, wid + TW, ...
+    if (EPI == EPI_QKR) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = wid + 4 * j;
+        for (int j = 0; j < QKJ; ++j) {
+            const int r = wid + TW * j;
             const int64_t t = row0 + (r < rows ? r : 0);
             qk_pos[j] = ta.positions[t];
             qk_pb[j] = ta.block_table[(int64_t)ta.slot_ids[t] * ta.max_blocks_per_seq + qk_pos[j] / ta.block];
@@ -901,9 +902,9 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
         __syncthreads();
         const int head = nt, nh = ta.nh, kvh = ta.kvh, hd = 64, half = 32;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = wid + 4 * j;
-            if (r >= rows || helper) break;
+        for (int j = 0; j < QKJ; ++j) {
+            const int r = wid + TW * j;
+            if (r >= rows) break;
             const int64_t t = row0 + r;
             const int pos = qk_pos[j], pb = qk_pb[j];
             const int64_t cache_row = ((int64_t)pb * ta.block + pos % ta.block) * kvh;  // in heads
