@@ -264,10 +264,11 @@ __global__ __launch_bounds__(256 * HW) void gemm_fp8_skinny_kernel(Fp8RowsPair p
     int qk_pos[4] = {0, 0, 0, 0}, qk_pb[4] = {0, 0, 0, 0}, qk_sl[4] = {0, 0, 0, 0};
     float qk_c[4] = {0, 0, 0, 0}, qk_s[4] = {0, 0, 0, 0};
     float qk_w = 1.0f;  // this lane's norm weight (head = column tile nt)
-    if (EPI == 2 && !helper) {
+    constexpr int TW = 4 * HW, QKJ = 16 / TW;  // EPI 2: every wave (helpers included) finishes rows wid, wid + TW, ...
+    if (EPI == 2) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int rj = wid + 4 * j;
+        for (int j = 0; j < QKJ; ++j) {
+            const int rj = wid + TW * j;
             const int64_t t = row0 + (rj < rows ? rj : 0);
             qk_pos[j] = ta.positions[t];
             qk_sl[j] = ta.slot_ids[t];
@@ -276,9 +277,9 @@ __global__ __launch_bounds__(256 * HW) void gemm_fp8_skinny_kernel(Fp8RowsPair p
         if (nw && nt < ta.nh + ta.kvh) qk_w = nw[lane];
     }
     auto tail_lookup = [&]() {
-        if (EPI == 2 && !helper) {
+        if (EPI == 2) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < QKJ; ++j) {
                 qk_pb[j] = ta.block_table[(int64_t)qk_sl[j] * ta.max_blocks_per_seq + qk_pos[j] / ta.block];
                 const float* cs = ta.rope_tab + (int64_t)qk_pos[j] * 64;
                 qk_c[j] = cs[lane & 31];
@@ -403,9 +404,9 @@ __global__ __launch_bounds__(256 * HW) void gemm_fp8_skinny_kernel(Fp8RowsPair p
         __syncthreads();
         const int head = nt, nh = ta.nh, kvh = ta.kvh, hd = 64, half = 32;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int rj = wid + 4 * j;
-            if (rj >= rows || helper) break;
+        for (int j = 0; j < QKJ; ++j) {
+            const int rj = wid + TW * j;
+            if (rj >= rows) break;
             const int64_t t = row0 + rj;
             const int pos = qk_pos[j], pb = qk_pb[j];
             const int64_t cache_row = ((int64_t)pb * ta.block + pos % ta.block) * kvh;  // in heads
