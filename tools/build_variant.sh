@@ -7,6 +7,6 @@ HERE=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $HERE/tools/ab
 OBJ=$HERE/tools/ab/${SRC%.hip}_$NAME.o
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -ffp-contract=off -I $HERE/include -I $HERE/vllm_i64_amd/csrc "$@" -c $HERE/vllm_i64_amd/csrc/$SRC -o $OBJ
-OTHERS=$(ls $HERE/vllm_i64_amd/build/*.o | grep -v "/${SRC%.hip}.o")
+OTHERS=$(ls $HERE/vllm_i64_amd/build/*.o | grep -vF "/${SRC%.hip}.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OTHERS $OBJ -o $HERE/tools/ab/libi64hip_$NAME.so
 echo $HERE/tools/ab/libi64hip_$NAME.so
