@@ -379,6 +379,14 @@ def test_argmax_and_advance(dev):
     x[3, 17] = x[3, 900] = 50.0  # tie -> first index
     assert torch.equal(ops.argmax_rows(x.to(dev)).cpu(), x.argmax(-1))
     assert int(ops.argmax_rows(x.to(dev))[3]) == 17
+    # widths of real vocabularies: one batch of eight loads per thread (32000), several batches (100003 is odd: the element-wise
+    # path; 131072: four batches), ties inside a thread's batch, across threads and across batches, an all -inf row
+    for D, ties in ((32000, (5, 31999)), (131072, (40000, 40004)), (131072, (7, 70000)), (100003, (99, 100002)), (65536, (65535, 65535))):
+        y = torch.empty(3, D).normal_(0, 1, generator=g)
+        y[1, ties[0]] = y[1, ties[1]] = 60.0
+        y[2] = float("-inf")
+        got = ops.argmax_rows(y.to(dev)).cpu()
+        assert int(got[0]) == int(y[0].argmax()) and int(got[1]) == ties[0] and int(got[2]) == 0
     p = torch.arange(5, dtype=torch.int32, device=dev)
     c = p + 1
     ops.advance(p, c)
