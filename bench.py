@@ -232,13 +232,15 @@ def main():
         os._exit(4)
 
     def emit_contingency():
-        """The graph replay with captured collectives did not come back: report the eagerly launched measurement of the same
-        steps (complete and valid, taken before the graph was tried) and leave."""
-        sys.stderr.write("bench.py: graph replay with captured collectives did not complete; reporting the eager measurement\n")
+        """The graph replay with captured collectives did not come back: print the eagerly launched measurement of the same
+        steps (complete and valid, taken before the graph was tried) so that the record is not lost, and leave with a
+        NON-ZERO status - a replay that hangs is a failure of the run, not a result (status 5; the step-time guard uses 4)."""
+        sys.stderr.write("bench.py: graph replay with captured collectives did not complete (a collective or a stream edge of the "
+                         "captured step stalls); the eager measurement is printed, exit status 5\n")
         sys.stderr.flush()
         if rank == 0 and contingency:
             os.write(result_fd, (json.dumps(contingency) + "\n").encode())
-        os._exit(0)
+        os._exit(5)
 
     def run_leg(expert_parallel: bool):
         """Build the runner, prefill (untimed; its own rate is reported), then the timed decode steps.  Expert parallelism over
@@ -350,15 +352,19 @@ def main():
     # --pmc WRITE_SIZE in runs of their own; FETCH_SIZE doubled, the gfx950 correction): a profiler cannot run inside this
     # process, so the figure is reported only when this run's workload is the one the passes were taken on
     traffic = None
-    this_workload = {"config": cfg.name, "weights": args.weights, "batch": B, "prompt_len": P, "kv_dtype": args.kv_dtype, "steps": args.steps, "warmup": args.warmup,
-                     "splits": splits}
+    # the counter figure belongs to a workload, not to a step count: the kernel's bytes per launch depend on the run only through
+    # the context length, so the stored per-launch bytes are scaled by ctx_now / ctx_profiled (the profiled figure is the mean
+    # over the last step of that run, whose context was prompt_len + warmup + steps)
+    this_workload = {"config": cfg.name, "weights": args.weights, "batch": B, "prompt_len": P, "kv_dtype": args.kv_dtype, "splits": splits}
     try:
         with open(os.path.join(ROOT, "profiles", PMC_PROFILE)) as f:
             prof = json.load(f)
-        if prof.get("workload") == this_workload:
+        pw = prof.get("workload", {})
+        if {k: pw.get(k) for k in this_workload} == this_workload:
+            ctx_prof = pw.get("ctx_profiled") or (pw["prompt_len"] + pw["warmup"] + pw["steps"])
             for kname, kd in prof["kernels"].items():
                 if "paged_attn_allheads_kernel" in kname:
-                    traffic = int(kd["hbm_read_bytes_corrected"] + kd["hbm_write_bytes"])
+                    traffic = int((kd["hbm_read_bytes_corrected"] + kd["hbm_write_bytes"]) * ctx_now / ctx_prof)
     except Exception:
         traffic = None
     roofline = {"bound": "hbm", "kernel": "paged_attn_allheads_kernel of one layer (split merge included)", "achieved": round(achieved, 1),

@@ -378,6 +378,11 @@ int i64h_fused_residual_norm_fp8(const float* h, const float* add, const float* 
                                  const float* norm_weight, float eps, float* normed, int64_t n, int32_t H, uint8_t* q_rows, float* q_scale,
                                  void* stream);
 int64_t i64h_fused_residual_norm_quant_rows(void);
+/* Cycles a grid barrier of a resident launch (i64h_fused_residual_norm_quant, i64h_decode_tail_run) may wait for the other
+ * workgroups before it gives up, raises the sticky error word sync[1] and goes on with results that are not to be trusted
+ * (0 = the default, about 0.25 s).  The reference has no counterpart (its kernels never wait for each other); the knob exists
+ * so that a test can see the error path; hosts read sync[1] after a step (model.I64MoEModel.check_sync). */
+int i64h_set_grid_wait_budget(int64_t cycles);
 int i64h_fused_residual_norm_quant(const float* h, const float* add, const float* moe_rows, const int32_t* moe_inv, const float* moe_shared,
                                    const float* route_weights, int32_t top_k, float routed_scale, float shared_scale, float* h_out,
                                    const float* norm_weight, float eps, int64_t n, int32_t H, const int32_t* slots, int32_t slots_per_row,

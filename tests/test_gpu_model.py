@@ -440,3 +440,51 @@ def test_prefill_with_norm_and_quantization_in_one_launch_gives_the_same_bits(de
     assert torch.equal(outs[0][0], outs[1][0])
     for a, b in zip(outs[0][1] + outs[0][2], outs[1][1] + outs[1][2]):
         assert torch.equal(a, b)
+
+
+def test_expired_grid_barrier_is_reported_by_the_decoder_and_the_engine_adapter(dev):
+    """The one-launch norm + quantization of a prefill chunk waits on a grid barrier with a wait budget.  With the budget cut to
+    one cycle the first workgroups to arrive give up at once: GreedyDecoder.prefill and EngineModel.forward must raise instead of
+    handing out logits, and the forward after the failure (default budget again) must pass - the error word is reset."""
+    from vllm_i64_amd import ops
+    from vllm_i64_amd.engine_adapter import EngineModel
+    from vllm_i64_amd.model import GreedyDecoder, I64MoEModel
+    ocfg, w, model = _model("tiny-moe", dev, max_seqs=4)
+    lens = [200, 130, 77]     # 407 rows: seven workgroups of 64 rows in the resident launch
+    assert sum(lens) > I64MoEModel.FUSE_MAX_ROWS and model.FUSE_NORM_QUANT
+    ids = M.make_token_ids(ocfg, sum(lens), seed=5)
+    prompts = [ids[:200], ids[200:330], ids[330:]]
+    dec = GreedyDecoder(model, 3, use_graph=False)
+    good = dec.prefill(prompts).clone()
+    for s in range(3):
+        model.kv.free(s)
+    ops.call("i64h_set_grid_wait_budget", 1)
+    try:
+        with pytest.raises(RuntimeError, match="wait budget"):
+            dec.prefill(prompts)
+        for s in range(3):
+            model.kv.free(s)
+        cache = _EngineLikeCache(model.cfg, 64, 4, dev)
+        cache.block_table = torch.full((4, 16), -1, dtype=torch.int32, device=dev)   # 256 positions per sequence
+        pos = torch.cat([torch.arange(t) for t in lens])
+        with pytest.raises(RuntimeError, match="wait budget"):
+            EngineModel(model)(ids, pos, cache, [0, 1, 2], lens)
+    finally:
+        ops.call("i64h_set_grid_wait_budget", 0)
+    again = dec.prefill(prompts)
+    assert torch.equal(again, good)
+
+
+def test_pair_launch_refuses_group_slots_without_the_row_slot_index(dev):
+    """a_group_slots = 2 promises that every row's slot is one of its group's two - which one is read through a_row_slot, so a
+    descriptor without it is refused on the host (a kernel that trusted it would read the index through a null pointer)."""
+    from vllm_i64_amd import _lib, ops
+    x = torch.randn(16, 64, device=dev)
+    wq = torch.zeros(1, 32, 64, dtype=torch.int8, device=dev)
+    ws = torch.ones(1, device=dev)
+    out = torch.empty(16, 32, device=dev)
+    st = ops.stats_alloc(4, dev)
+    d = ops.gemm_desc(x, wq, ws, out, a_slot_base=0, stats=st)
+    d.a_group_slots = 2
+    with pytest.raises(_lib.I64HError, match="a_row_slot"):
+        ops.gemm_i8_pair(d)

@@ -90,6 +90,7 @@ SIGNATURES: Dict[str, str] = {
     "i64h_set_gemm_os_waves": "i",
     "i64h_set_gemm_os_tall": "i",
     "i64h_debug_set_os_stamps": "p",
+    "i64h_set_grid_wait_budget": "l",
 }
 _KIND = {"p": _P, "i": _I, "l": _L, "f": _F}
 

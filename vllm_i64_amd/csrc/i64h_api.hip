@@ -11,7 +11,18 @@ void i64h_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static long long g_grid_wait_budget = 0;
+long long i64h_grid_wait_budget() { return g_grid_wait_budget > 0 ? g_grid_wait_budget : 600000000ll; }
+
 extern "C" {
+
+// Cycles a grid barrier of a resident launch may wait before it gives up, raises the sticky error word and goes on
+// (0 restores the default, about a quarter of a second).  A knob for tests of the error path.
+int i64h_set_grid_wait_budget(int64_t cycles) {
+    I64H_CHECK_ARG(cycles >= 0, "set_grid_wait_budget: %lld", (long long)cycles);
+    g_grid_wait_budget = cycles;
+    return 0;
+}
 
 const char* i64h_last_error(void) { return g_err; }
 

@@ -183,7 +183,9 @@ __device__ __forceinline__ uint32_t pack4_e4m3fn(float x0, float x1, float x2, f
     v = __builtin_amdgcn_cvt_pk_fp8_f32(x2, x3, v, true);
     return (uint32_t)v;
 }
-__device__ __forceinline__ float clamp448(float x) { return fminf(fmaxf(x, -448.0f), 448.0f); }
+// a NaN stays a NaN (fminf / fmaxf would turn it into -448): the reference's clamp().to(float8_e4m3fn) keeps it, and the
+// hardware conversion encodes it as the e4m3fn NaN
+__device__ __forceinline__ float clamp448(float x) { return x != x ? x : fminf(fmaxf(x, -448.0f), 448.0f); }
 
 // Device-coherent accesses for data handed from one workgroup to another inside a launch: relaxed agent-scope atomics
 // compile to sc1 stores / loads, which are coherent across CUs and XCDs without any cache write-back or invalidate.

@@ -1176,6 +1176,9 @@ static int check_desc(const i64h_gemm_desc* d, const char* who) {
     I64H_CHECK_ARG(!d->want_stats || (d->stats != nullptr && d->epilogue == EPI_SWIGLU), "%s: statistics need the SwiGLU epilogue and stat slots", who);
     I64H_CHECK_ARG(!d->b_frags || (d->a_fp32 && d->K % 64 == 0 && d->N % (d->epilogue == EPI_SWIGLU ? 32 : 16) == 0),
                    "%s: a weight fragment pack needs the fp32 operand form, K %% 64 == 0 and whole fragment columns", who);
+    // rows that pick between their group's slots do so through the per-row slot index
+    I64H_CHECK_ARG(d->a_group_slots >= 0 && (d->a_group_slots < 2 || d->a_row_slot != nullptr),
+                   "%s: a_group_slots=%d needs the per-row slot index (a_row_slot)", who, d->a_group_slots);
     return 0;
 }
 

@@ -3,6 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The wait budget the host passes to the resident launches (i64h_set_grid_wait_budget; 0 = the default).  A test lowers it to
+// see the error path; nothing else should.
+long long i64h_grid_wait_budget();
+
 namespace {
 
 // ---- grid barrier ---------------------------------------------------------------------------------------------------------
@@ -21,6 +25,7 @@ struct GridSync {
     uint32_t* w;
     int nwg;
     uint32_t epoch;  // barriers passed so far
+    long long budget = DEC_SPIN_BUDGET;  // cycles a wait may take before it gives up and raises the error flag
 };
 
 __device__ __forceinline__ void grid_barrier(GridSync& gs) {
@@ -36,7 +41,7 @@ __device__ __forceinline__ void grid_barrier(GridSync& gs) {
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
         while (__hip_atomic_load(gs.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(DEC_POLL_SLEEP);
-            if ((long long)(__builtin_amdgcn_s_memtime() - t0) > DEC_SPIN_BUDGET) {
+            if ((long long)(__builtin_amdgcn_s_memtime() - t0) > gs.budget) {
                 __hip_atomic_store(gs.w + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }

@@ -386,7 +386,7 @@ __global__ __launch_bounds__(FRQ_WAVES * 64) void fused_residual_norm_quant_kern
                                                                                     uint32_t* __restrict__ stats, int8_t* __restrict__ qa,
                                                                                     float* __restrict__ qs, const int32_t* __restrict__ g_inv,
                                                                                     int g_k, int8_t* __restrict__ ga, float* __restrict__ gs,
-                                                                                    uint32_t* sync, int n_rel) {
+                                                                                    uint32_t* sync, int n_rel, long long wait_budget) {
     __shared__ uint32_t tab_lo[I64H_STAT_TAB], tab_hi[I64H_STAT_TAB];
     for (int i = threadIdx.x; i < I64H_STAT_TAB; i += FRQ_WAVES * 64) { tab_lo[i] = I64H_ORDERED_ZERO; tab_hi[i] = I64H_ORDERED_ZERO; }
     __syncthreads();
@@ -426,6 +426,7 @@ __global__ __launch_bounds__(FRQ_WAVES * 64) void fused_residual_norm_quant_kern
     gsy.w = sync;
     gsy.nwg = gridDim.x;
     gsy.epoch = 0;
+    gsy.budget = wait_budget;
     grid_barrier(gsy);
     // The parameters of a slot take a 64-word coherent read, a wave-wide fold and the fp64 arithmetic of choose_qparams_u7: with
     // a known, small number of relative slots every wave derives a few of them ONCE into an LDS table (the rows of a workgroup
@@ -885,7 +886,7 @@ int i64h_fused_residual_norm_quant(const float* h, const float* add, const float
     const int rows_per_wg = FRQ_WAVES * FRR_RPW;
     hipLaunchKernelGGL(fused_residual_norm_quant_kernel, dim3((unsigned)((n + rows_per_wg - 1) / rows_per_wg)), dim3(FRQ_WAVES * 64), 0,
                        (hipStream_t)stream, fa, norm_weight, slots, (int)slots_per_row, (int)slot_base, stats, q_rows, q_scale, gather_inv,
-                       (int)gather_k, g_rows, g_scale, sync, slots ? (int)num_slots : 1);
+                       (int)gather_k, g_rows, g_scale, sync, slots ? (int)num_slots : 1, i64h_grid_wait_budget());
     I64H_CHECK_LAUNCH();
     return 0;
 }

@@ -100,6 +100,9 @@ class EngineModel:
         self._ensure_blocks(kv_cache, seq_ids, [max(m, 0) for m in max_pos])
         logits = r.forward(ids, pos, slots, (pos + 1).contiguous(), max_ctx_hint=max(max_pos) + 1 if max_pos else 0,
                            kv=_CacheView(kv_cache))
+        # launches that wait on a grid barrier (prefill-sized chunks) report an expired wait through a device word: read it
+        # back before the logits leave (the engine reads the logits on the host right after, so this adds no idle time)
+        r.check_sync(force=False)
         sl = kv_cache.seq_lens
         for sid, m in zip(seq_ids, max_pos):
             if m >= 0:

@@ -257,6 +257,7 @@ class I64MoEModel:
         self.stats = ops.stats_alloc(self.spl * cfg.num_layers + 1, dev)
         self._bufs: Dict[tuple, _Buffers] = {}
         self.dec_sync = ops.decode_sync_alloc(dev)
+        self._resident_used = False   # a launch with a grid barrier was issued since the last check_sync
 
     # ---- helpers ----
     def buffers(self, n: int, n_logit_rows: int) -> _Buffers:
@@ -281,11 +282,20 @@ class I64MoEModel:
             self._fq_rows_cached = ops.fused_residual_norm_quant_rows()
         return self._fq_rows_cached
 
-    def check_sync(self):
+    def check_sync(self, force: bool = True):
         """Raises if a grid barrier of a resident launch (the one-launch norm + quantization of a prefill chunk, the opt-in decode
-        tail) ever ran out of its wait budget - its results are then not to be trusted.  Synchronizes; call it off the hot path."""
+        tail) ran out of its wait budget since the last check - the results of that forward are then not to be trusted.  The error
+        word is put back to zero before raising, so one failure does not condemn the forwards after it.  Synchronizes (one word
+        read back); force=False skips the read when no resident launch was issued since the last check.  EngineModel.forward and
+        GreedyDecoder.prefill call it before they hand out logits."""
+        if not (force or self._resident_used):
+            return
+        self._resident_used = False
         if int(self.dec_sync[1].item()) != 0:
-            raise RuntimeError("a grid barrier of a resident launch exceeded its wait budget (workgroups not co-resident?)")
+            self.dec_sync[1:2].zero_()
+            raise RuntimeError("a grid barrier of a resident launch exceeded its wait budget (its workgroups were not all resident at "
+                               "once: another process or stream on the GPU, a CU mask?); the logits of this forward are invalid. "
+                               "I64H_FUSE_NORM_QUANT=0 selects the launches without a grid barrier")
 
     FUSE_MAX_ROWS = 256  # up to this many operand rows the quantizer runs inside the GEMM (one launch per Linear call)
     EP_FUSE_MAX_ROWS = 1024  # the same for the pooled expert rows of the expert-parallel runner (8 ranks x 64 sequences x top-2)
@@ -316,7 +326,9 @@ class I64MoEModel:
     def _tails(self, B: _Buffers, kvc, positions, slot_ids) -> list:
         """The prepared per-layer persistent launches for this buffer set and these external buffers (built on first use:
         set-up is synchronous, so not under graph capture - GreedyDecoder.prepare runs one eager step first)."""
-        key = (positions.data_ptr(), slot_ids.data_ptr(), kvc.block_table.data_ptr(), kvc.k[0].data_ptr(), kvc.v[0].data_ptr())
+        # everything the prepared argument blocks bake in: the addresses of every layer's cache, its dtype and geometry
+        key = (positions.data_ptr(), slot_ids.data_ptr(), kvc.block_table.data_ptr(), kvc.block_table.shape[1], kvc.k[0].dtype,
+               kvc.k[0].shape[1], tuple(t.data_ptr() for t in kvc.k), tuple(t.data_ptr() for t in kvc.v))
         if key in B.tails:
             return B.tails[key]
         if len(B.tails) >= 8:  # callers that pass fresh position / slot tensors every step: keep the cache bounded
@@ -363,7 +375,7 @@ class I64MoEModel:
                 d.max_blocks_per_seq, d.kv_dtype = kvc.block_table.shape[1], ops.KV_DTYPE_CODE[kvc.k[l + 1].dtype]
                 d.num_heads, d.num_kv_heads, d.head_dim, d.block_size = cfg.num_heads, cfg.num_kv_heads, cfg.head_dim, kvc.k[l + 1].shape[1]
                 d.q_out, d.k_cache, d.v_cache = ops.ptr(B.q), ops.ptr(kvc.k[l + 1]), ops.ptr(kvc.v[l + 1])
-            tails.append(ops.DecodeTail(d, self.device, keep=(positions, slot_ids, kvc.block_table)))
+            tails.append(ops.DecodeTail(d, self.device, keep=(positions, slot_ids, kvc.block_table, *kvc.k, *kvc.v)))
         B.tails[key] = tails
         return tails
 
@@ -448,12 +460,14 @@ class I64MoEModel:
         fq = (self.FUSE_NORM_QUANT and n > self.FUSE_MAX_ROWS and n <= self._fq_rows() and record is None and inject is None
               and self.ep is None and H <= 1024 and H % 4 == 0)
         if fq:
+            self._resident_used = True
             ops.fused_residual_norm_quant(B.h, self.layers[0]["ln1"], eps, st, self.dec_sync, B.xa, B.xs, h_out=B.h, slot_base=0)
         else:
             ops.fused_residual_norm(B.h, self.layers[0]["ln1"], eps, h_out=B.h, normed=B.normed, slot_base=0, stats=st)
         tails = None
         if fuse_rows and record is None and inject is None and self._tail_supported(n):
             tails = self._tails(B, kvc, positions, slot_ids)
+            self._resident_used = True
         for l, W in enumerate(self.layers):
             base = l * spl
             if tails is not None:
@@ -836,6 +850,7 @@ class GreedyDecoder:
         self.max_ctx_hint = max(lens) + reserve_extra
         self.host_lens = list(lens)
         ops.argmax_rows(logits, out=self.tokens)
+        m.check_sync(force=False)   # a prefill chunk's one-launch norm + quantization waits on a grid barrier: fail loudly
         return logits
 
     def set_state(self, tokens: torch.Tensor, lens: Sequence[int], reserve_extra: int = 0):
