@@ -122,8 +122,45 @@ typedef struct i64h_gemm_desc {
     const int32_t* c_row_map;     /* epilogue 0, optional: operand row r is stored as output row c_row_map[r] (e.g. expert outputs straight back in (route, token) order) */
     int32_t a_group_slots;        /* fp32 operand, optional promise (0 = none): a_row_slot[r] of every row of group g lies in [g * S, g * S + S), S = this value; lets the decode-sized kernel request the statistics without waiting for the row's slot index */
     int32_t b_frags;              /* decode-sized (fp32-operand) problems only: 1 = B points to the fragment pack of the weights (i64h_pack_weight_frags; N % 16 == 0, SwiGLU: N % 32 == 0, K % 64 == 0): every weight load of a wave is then 1 KB of consecutive bytes */
+    const float* c_residual;      /* epilogue 0, decode-sized (fp32-operand) problems only, optional: C = c_residual + product (same layout as C, may be C itself): the residual add of the decoder layer (vllm_i64/models/complexity_deep/model.py:355-357) in the projection's epilogue */
 } i64h_gemm_desc;
 int i64h_gemm_i8_pair(const i64h_gemm_desc* a, const i64h_gemm_desc* b, void* stream);
+/* RMSNorm in front of the quantizer of a decode-sized launch.  The operand rows of the problem(s) are the residual stream
+ * (fp32 [n, K], n <= 256, K % 64 == 0, K <= 1024); every workgroup normalises the rows of its tile itself (x * rsqrt(mean(x^2)
+ * + eps) * norm_weight, the arithmetic and summation order of i64h_fused_residual_norm, so the quantized operands are the
+ * bytes the two-launch form produces), and the call statistics - the (min, max) of the normalised rows per stat slot - are
+ * handed from the workgroups that own output column tile 0 of the FIRST problem (one per 16 rows; the first problem is one
+ * group over all n rows without a gather) to every other workgroup of the launch through 16-byte records in the slots' own
+ * words.  The slots slot_base .. slot_base + num_slots - 1 therefore hold records, not (min, max) shards, after the launch;
+ * they must have been reset by i64h_stats_reset / i64h_embedding_stats_reset since their last use, and only this launch may
+ * read them.  tok_slots[t * slots_per_row + j] (NULL: every row reports to relative slot 0 only) are the relative slots row t
+ * reports to, as in i64h_fused_residual_norm; the problems name the slot their rows are quantized with through a_slot_base /
+ * a_row_slot as usual (first problem: a_slot_base == slot_base, no a_row_slot).
+ * moe_rows != NULL: the token-routed layer's combine joins the residual stream in front of the norm
+ * (row = h + (routed_scale * (sum_k route_weights[k] * moe_rows[k * n + t]) + shared_scale * moe_shared[t]), the evaluation
+ * order of vllm_i64/layers/token_routed_mlp.py:156-183); the publishing workgroups store the new residual rows to h_out, which
+ * must not be the operand itself (other workgroups still read it).
+ * sync: the sync words of i64h_decode_sync_words(); a wait that runs out of its budget (i64h_set_grid_wait_budget) raises
+ * sync[1] and goes on.  Waiting workgroups never hold back the ones they wait for: publishers are the launch's first
+ * workgroups per row tile and wait for nobody before they publish.
+ * No counterpart in the reference: it stands for nn.RMSNorm followed by the quantized nn.Linear call(s) that read its output
+ * (vllm_i64/models/complexity_deep/model.py:349-369) without the kernel boundary between them. */
+typedef struct i64h_norm_prologue {
+    const float* norm_weight;     /* [K] */
+    float eps;
+    const int32_t* tok_slots;     /* [n, slots_per_row] or NULL */
+    int32_t slots_per_row;
+    int32_t num_slots;            /* relative slots 0 .. num_slots - 1 (<= 272) */
+    int32_t slot_base;
+    uint32_t* sync;
+    const float* moe_rows;        /* [top_k * n, K] in (route, token) order, or NULL */
+    const float* moe_shared;      /* [n, K] or NULL */
+    float* h_out;                 /* [n, K], required with moe_rows */
+    float route_weights[8];
+    int32_t top_k;
+    float routed_scale, shared_scale;
+} i64h_norm_prologue;
+int i64h_gemm_i8_pair_norm(const i64h_gemm_desc* a, const i64h_gemm_desc* b, const i64h_norm_prologue* np, void* stream);
 /* Decode-sized fused form (fp32 operand quantized in the kernel from its stat slot, one group, <= 512 rows, K % 64 == 0,
  * 256 <= K <= 2048): qkv projection + per-head QK RMSNorm + rotate-half RoPE + paged-KV write in one launch (arguments as
  * i64h_qk_norm_rope_kv; head_dim 64; d->C is not written).  No counterpart in the reference: it stands for the pair
@@ -133,6 +170,12 @@ int i64h_gemm_i8_qkv_rope_kv(const i64h_gemm_desc* d, const float* q_norm_w, con
                              const int32_t* positions, const int32_t* slot_ids, const int32_t* block_table, int32_t max_blocks_per_seq,
                              float* q_out, void* k_cache, void* v_cache, int32_t kv_dtype, int32_t num_heads, int32_t num_kv_heads,
                              int32_t head_dim, int32_t block_size, void* stream);
+/* The same launch with the RMSNorm prologue of i64h_gemm_i8_pair_norm (one problem): combine + residual + norm of the previous
+ * layer's output, qkv projection, QK norm, RoPE and cache write in one launch. */
+int i64h_gemm_i8_qkv_rope_kv_norm(const i64h_gemm_desc* d, const i64h_norm_prologue* np, const float* q_norm_w, const float* k_norm_w,
+                                  float qk_eps, const float* rope_tab, const int32_t* positions, const int32_t* slot_ids,
+                                  const int32_t* block_table, int32_t max_blocks_per_seq, float* q_out, void* k_cache, void* v_cache,
+                                  int32_t kv_dtype, int32_t num_heads, int32_t num_kv_heads, int32_t head_dim, int32_t block_size, void* stream);
 /* Per-token x per-output-channel rescale, C[r, c] = float(acc) * (row_scale[r] * col_scale[c]): the torch._int_mm branch of
  * int8_linear_native / int8_fused_gate_up_native (vllm_i64/core/quantization.py:119-176, 219-286). */
 int i64h_gemm_i8_colscale(const int8_t* A, const float* row_scale, const int8_t* B, const float* col_scale, int64_t M, int32_t N, int32_t K,

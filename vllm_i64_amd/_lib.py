@@ -67,6 +67,8 @@ SIGNATURES: Dict[str, str] = {
     "i64h_debug_set_attn_stamps": "p",
     "i64h_gemm_i8_pair": "ppp",
     "i64h_gemm_i8_qkv_rope_kv": "pppfpppp" + "ipppiiiiip",
+    "i64h_gemm_i8_pair_norm": "pppp",
+    "i64h_gemm_i8_qkv_rope_kv_norm": "ppppfpppp" + "ipppiiiiip",
     "i64h_gemm_i8_colscale": "ppppliipp",
     "i64h_moe_forward": "pplppplp",
     "i64h_moe_forward_static": "pplppp",
@@ -111,7 +113,14 @@ class GemmDesc(ctypes.Structure):
     _fields_ = [("A", _P), ("a_fp32", _I), ("a_src_row", _P), ("a_src_mod", _I), ("row_scale", _P), ("a_row_slot", _P),
                 ("a_slot_base", _I), ("B", _P), ("w_scale", _P), ("group_offsets", _P), ("num_groups", _I), ("M_total", _L),
                 ("N", _I), ("K", _I), ("C", _P), ("epilogue", _I), ("out_row_slot", _P), ("out_slot_base", _I), ("stats", _P),
-                ("want_stats", _I), ("col_scale", _P), ("c_row_map", _P), ("a_group_slots", _I), ("b_frags", _I)]
+                ("want_stats", _I), ("col_scale", _P), ("c_row_map", _P), ("a_group_slots", _I), ("b_frags", _I), ("c_residual", _P)]
+
+
+class NormPrologue(ctypes.Structure):
+    """Mirror of i64h_norm_prologue (include/i64h.h)."""
+    _fields_ = [("norm_weight", _P), ("eps", _F), ("tok_slots", _P), ("slots_per_row", _I), ("num_slots", _I), ("slot_base", _I),
+                ("sync", _P), ("moe_rows", _P), ("moe_shared", _P), ("h_out", _P), ("route_weights", _F * 8), ("top_k", _I),
+                ("routed_scale", _F), ("shared_scale", _F)]
 
 
 class Fp8RowsDesc(ctypes.Structure):

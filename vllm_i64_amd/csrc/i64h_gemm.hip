@@ -18,6 +18,7 @@
 // gemm_f32_kernel: C = A[M,K] @ B[N,K]^T in fp32 on v_mfma_f32_16x16x4_f32 (tied lm_head; bit-for-bit a k-ordered
 //   fmaf chain per output).  gemm_w8a32_kernel: fp32 activations x dequantised int8 weights (operator API).
 #include "i64h_gemm_dev.h"
+#include "i64h_gridsync.h"
 
 struct GemmI8Pair {
     GemmI8Args p[2];
@@ -620,8 +621,11 @@ __host__ __device__ __forceinline__ int sk_pad_tiles(int n_tiles) { return n_til
 // HW > 1: the workgroup has HW * NW waves; the extra ("helper") waves take their share of the operand rows - request, quantize,
 // park in LDS - and then only keep the barriers: the phase in front of the K loop is bound by what one wave can request and
 // quantize, not by the CU.
-template <int EPI, int NW, int HW = 1>
-__device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const int bid, char* smem, const RowTailArgs& ta) {
+// PRO: RMSNorm (optionally behind the MoE combine) of the operand rows in front of the quantizer, with the call statistics handed
+// between the workgroups of the launch (NormPro, i64h_gemm_dev.h); pub: this problem's column-tile-0 workgroups publish them.
+template <int EPI, int NW, int HW = 1, int PRO = 0>  // PRO: 0 none, 1 norm prologue, 2 norm prologue behind the MoE combine
+__device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const int bid, char* smem, const RowTailArgs& ta,
+                                                    const NormPro& np = NormPro(), const bool pub_problem = false) {
     constexpr int NF = (EPI == EPI_SWIGLU) ? 2 : 1;  // B fragments per wave per step
     // K steps (64 deep) whose B fragments are in flight together: all of K = 1024 in one batch (half with two fragments per step)
     // (with helper waves a wave streams half of K: 8 steps cover K = 1024 in one batch for either epilogue)
@@ -642,7 +646,28 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
     // workgroups are dealt to the 8 XCDs round-robin and every XCD has an L2 of its own: with the column-tile count padded to a
     // multiple of 8, the row tiles that stream the same weight slice run on ONE XCD and the slice crosses the fabric once
     const int n_tiles = (nout + BNB - 1) / BNB, n_pad = sk_pad_tiles(n_tiles);
-    const int mt = bid / n_pad, nt = bid % n_pad;
+    int mt = bid / n_pad, nt = bid % n_pad;
+    if (PRO && pub_problem) {
+        // the publishing workgroups (column tile 0 of every row tile) lead the launch: workgroups start in order, so the ones
+        // everybody waits for are resident before any workgroup that waits, however many workgroups the device holds at once.
+        // Usual case (no more row tiles than column slots): grid slot j < n_pub trades tiles with slot j * n_pad - the same grid,
+        // the publishers first.  Otherwise a padded lead of n_pub workgroups in front of the grid, whose column-tile-0 slots exit.
+        if (np.n_pub <= n_pad) {
+            if (bid < np.n_pub) { mt = bid; nt = 0; }
+            else if (nt == 0 && mt < np.n_pub) { nt = mt; mt = 0; }
+        } else {
+            const int lead = (np.n_pub + 7) & ~7;
+            if (bid < lead) {
+                if (bid >= np.n_pub) return;
+                mt = bid;
+                nt = 0;
+            } else {
+                mt = (bid - lead) / n_pad;
+                nt = (bid - lead) % n_pad;
+                if (nt == 0) return;
+            }
+        }
+    }
     if (nt >= n_tiles) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const bool helper = HW > 1 && wid >= NW;  // wave-uniform
@@ -717,7 +742,7 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
     uint4 sw[I64H_SLOT_WORDS / 4], sw1[I64H_SLOT_WORDS / 4];
     const bool by_group = p.a_row_slot != nullptr && (p.a_group_slots == 1 || p.a_group_slots == 2);
     int slot_rel = 0;
-    if (tid < rows) {
+    if (!PRO && tid < rows) {
         if (by_group) {
             stat_load_raw(p.stats, p.a_slot_base + g * p.a_group_slots, sw);
             if (p.a_group_slots == 2) {
@@ -737,6 +762,17 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
             for (int reg = 0; reg < 4; ++reg) {
                 const int r = i * 16 + fq * 4 + reg;
                 c_row[i][reg] = (p.c_row_map && r < rows && !helper) ? p.c_row_map[row0 + r] : row0 + r;
+            }
+    }
+    // residual form (C = c_add + product): the lane's four addends are requested now, far ahead of the epilogue
+    float c_res[SK_MF][4];
+    if (EPI == EPI_STORE) {
+#pragma unroll
+        for (int i = 0; i < SK_MF; ++i)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = i * 16 + fq * 4 + reg;
+                c_res[i][reg] = (p.c_add && r < rows && col_ok) ? p.c_add[(int64_t)c_row[i][reg] * p.N + col] : 0.0f;
             }
     }
     // SwiGLU with statistics: the slot of each of this lane's four output rows, requested now (the epilogue would otherwise
@@ -801,38 +837,237 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
             for (int e = 0; e < 4; ++e) f[u][e] = *(const float4*)(ap + e * 4);
         }
     };
-    a_issue(tid);
-    if (s_end > s_begin) bload(s_begin);
-    SK_STAMP(1);
-    if (tid < SK_BM) {
-        QParams q;
-        q.scale = 0.0f; q.inv_scale = 0.0f; q.zp = 0;
-        if (tid < rows) {
-            float lo, hi;
-            if (by_group && slot_rel == 1) stat_fold_raw(sw1, lo, hi);
-            else stat_fold_raw(sw, lo, hi);
-            q = choose_qparams_u7(lo, hi);
-        }
-        q_inv[tid] = q.inv_scale; q_scale[tid] = q.scale; q_zp[tid] = q.zp;
-    }
-    __syncthreads();
-    SK_STAMP(2);
-    for (int c0 = tid; c0 < total_chunks; c0 += NT * CPT) {
-#pragma unroll
-        for (int u = 0; u < CPT; ++u) {
-            const int c = c0 + u * NT;
-            if (c >= total_chunks) continue;
+    if constexpr (!PRO) {
+        a_issue(tid);
+        if (s_end > s_begin) bload(s_begin);
+        SK_STAMP(1);
+        if (tid < SK_BM) {
             QParams q;
-            q.inv_scale = q_inv[rr[u]]; q.zp = q_zp[rr[u]]; q.scale = 0.0f;
-            uint32_t w[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) w[e] = aok[u] ? quantize4_u7_signed(f[u][e], q) : 0u;
-            *(uint4*)(smem + rr[u] * LDA + kc[u] * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+            q.scale = 0.0f; q.inv_scale = 0.0f; q.zp = 0;
+            if (tid < rows) {
+                float lo, hi;
+                if (by_group && slot_rel == 1) stat_fold_raw(sw1, lo, hi);
+                else stat_fold_raw(sw, lo, hi);
+                q = choose_qparams_u7(lo, hi);
+            }
+            q_inv[tid] = q.inv_scale; q_scale[tid] = q.scale; q_zp[tid] = q.zp;
         }
-        if (c0 + NT * CPT < total_chunks) a_issue(c0 + NT * CPT);
+        __syncthreads();
+        SK_STAMP(2);
+        for (int c0 = tid; c0 < total_chunks; c0 += NT * CPT) {
+    #pragma unroll
+            for (int u = 0; u < CPT; ++u) {
+                const int c = c0 + u * NT;
+                if (c >= total_chunks) continue;
+                QParams q;
+                q.inv_scale = q_inv[rr[u]]; q.zp = q_zp[rr[u]]; q.scale = 0.0f;
+                uint32_t w[4];
+    #pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = aok[u] ? quantize4_u7_signed(f[u][e], q) : 0u;
+                *(uint4*)(smem + rr[u] * LDA + kc[u] * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            if (c0 + NT * CPT < total_chunks) a_issue(c0 + NT * CPT);
+        }
+        __syncthreads();
+        SK_STAMP(3);
+    } else {
+        static_assert(!PRO || (NW == 4 && HW == 2 && SK_BM == 16), "the norm prologue is laid out for eight waves and one row fragment");
+        // wave wid holds rows wid and wid + 8 of the tile, lane l elements [16 l, 16 l + 16) of each (K <= 1024: launcher)
+        const bool lane_in = lane < cpr;
+        const int kq = lane_in ? lane : 0;
+        const bool pub = pub_problem && nt == 0;  // uniform over the workgroup
+        int src[2];
+        bool rok[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int r = wid + 8 * u;
+            rok[u] = r < rows;
+            src[u] = row0 + (rok[u] ? r : 0);
+        }
+        if (p.a_src_row) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) src[u] = p.a_src_row[src[u]];
+        }
+        if (p.a_src_mod > 0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) src[u] = (int)((uint32_t)src[u] % (uint32_t)p.a_src_mod);
+        }
+        // consumer side (wave 0): the stat slot of row (lane & 15); publisher side: the relative slots of this wave's two rows
+        // (lane j: the row's j-th slot) - both requested now, ahead of the rows
+        int my_slot = p.a_slot_base;
+        if (wid == 0 && p.a_row_slot && (lane & 15) < rows) my_slot += p.a_row_slot[row0 + (lane & 15)];
+        const int ns = np.tok_slots ? np.spr : 1;
+        int ts[2] = {0, 0};
+        if (pub && np.tok_slots && lane < ns) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) ts[u] = np.tok_slots[(int64_t)src[u] * np.spr + lane];
+        }
+        float4 gw[4], x[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[u][e] = ((const float4*)((const float*)p.A + (int64_t)src[u] * K + kq * 16))[e];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gw[e] = ((const float4*)(np.w + kq * 16))[e];
+        // the token-routed layer's output joins the residual stream first: all of its rows are requested now, together with the
+        // residual rows, and the weight fragments behind them
+        float4 r0[2][4], r1[2][4], sh[2][4];
+        if constexpr (PRO == 2) {
+            const int k1 = np.top_k > 1 ? 1 : 0;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int64_t t = src[u];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    r0[u][e] = ((const float4*)(np.mc_rows + t * K + kq * 16))[e];
+                    r1[u][e] = ((const float4*)(np.mc_rows + ((int64_t)k1 * np.n + t) * K + kq * 16))[e];
+                    sh[u][e] = np.mc_shared ? ((const float4*)(np.mc_shared + t * K + kq * 16))[e] : make_float4(0, 0, 0, 0);
+                }
+            }
+        }
+        if (s_end > s_begin) bload(s_begin);
+        if constexpr (PRO == 2) {
+            // the reference's evaluation order: routed = w0 R0; routed += wk Rk; m = routed_scale routed (+ shared_scale shared);
+            // row = h + m  (separate multiplies and adds)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int64_t t = src[u];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float4 o = make_float4(np.wk[0] * r0[u][e].x, np.wk[0] * r0[u][e].y, np.wk[0] * r0[u][e].z, np.wk[0] * r0[u][e].w);
+                    if (np.top_k > 1) {
+                        o.x = o.x + np.wk[1] * r1[u][e].x; o.y = o.y + np.wk[1] * r1[u][e].y;
+                        o.z = o.z + np.wk[1] * r1[u][e].z; o.w = o.w + np.wk[1] * r1[u][e].w;
+                    }
+                    for (int k = 2; k < np.top_k; ++k) {
+                        const float4 rk = ((const float4*)(np.mc_rows + ((int64_t)k * np.n + t) * K + kq * 16))[e];
+                        o.x = o.x + np.wk[k] * rk.x; o.y = o.y + np.wk[k] * rk.y;
+                        o.z = o.z + np.wk[k] * rk.z; o.w = o.w + np.wk[k] * rk.w;
+                    }
+                    if (np.mc_shared) {
+                        o.x = np.routed_scale * o.x + np.shared_scale * sh[u][e].x; o.y = np.routed_scale * o.y + np.shared_scale * sh[u][e].y;
+                        o.z = np.routed_scale * o.z + np.shared_scale * sh[u][e].z; o.w = np.routed_scale * o.w + np.shared_scale * sh[u][e].w;
+                    } else {
+                        o.x = np.routed_scale * o.x; o.y = np.routed_scale * o.y; o.z = np.routed_scale * o.z; o.w = np.routed_scale * o.w;
+                    }
+                    float4 a = x[u][e];
+                    a.x = a.x + o.x; a.y = a.y + o.y; a.z = a.z + o.z; a.w = a.w + o.w;
+                    x[u][e] = a;
+                    if (pub && np.h_out && rok[u] && lane_in) ((float4*)(np.h_out + t * K + kq * 16))[e] = a;
+                }
+            }
+        }
+        SK_STAMP(1);
+        uint32_t* tab_lo = (uint32_t*)smem;  // publishers: (min, max) per relative slot over the tile's rows, in the operand area
+        uint32_t* tab_hi = tab_lo + I64H_STAT_TAB;
+        if (pub) {
+            for (int i = tid; i < np.n_rel; i += NT) { tab_lo[i] = I64H_ORDERED_ZERO; tab_hi[i] = I64H_ORDERED_ZERO; }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            // sum of squares in the row kernel's order: its thread 4 l + e holds float4 e of this lane (an fma chain over the four
+            // components), its waves are this wave's rows of 16 lanes, its butterfly (thread ^ 32, 16, 8, 4, 2, 1) is lane ^ 8, 4, 2, 1
+            // and then e ^ 2, e ^ 1 inside the lane; the four wave sums are added in order
+            float sq[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float4 a = x[u][e];
+                float ss = __builtin_fmaf(a.x, a.x, 0.0f);
+                ss = __builtin_fmaf(a.y, a.y, ss);
+                ss = __builtin_fmaf(a.z, a.z, ss);
+                ss = __builtin_fmaf(a.w, a.w, ss);
+                ss = lane_in ? ss : 0.0f;
+                ss += I64H_DPPF(ss, 0x128);
+                ss += I64H_DPPF(ss, 0x124);
+                ss += I64H_DPPF(ss, 0x4E);
+                ss += I64H_DPPF(ss, 0xB1);
+                sq[e] = ss;
+            }
+            const float part = (sq[0] + sq[2]) + (sq[1] + sq[3]);
+            const float w0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 0));
+            const float w1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 16));
+            const float w2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 32));
+            const float w3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 48));
+            const float rr = rsqrtf((w0 + w1 + w2 + w3) / (float)K + np.eps);
+            float lo = 0.0f, hi = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float4 a = x[u][e];
+                const float4 g = gw[e];
+                a.x = a.x * rr * g.x; a.y = a.y * rr * g.y; a.z = a.z * rr * g.z; a.w = a.w * rr * g.w;
+                x[u][e] = a;
+                if (lane_in) {
+                    lo = fminf(lo, fminf(fminf(a.x, a.y), fminf(a.z, a.w)));
+                    hi = fmaxf(hi, fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)));
+                }
+            }
+            if (pub) {
+                lo = wave_min(lo);
+                hi = wave_max(hi);
+                if (rok[u] && lane < ns) {
+                    atomicMin(&tab_lo[ts[u]], f32_to_ordered(lo));
+                    atomicMax(&tab_hi[ts[u]], f32_to_ordered(hi));
+                }
+            }
+        }
+        if (pub) {
+            __syncthreads();
+            if (tid < np.n_rel) {
+                v4u rec;
+                rec.x = tab_lo[tid]; rec.y = tab_hi[tid]; rec.z = 1u; rec.w = 0u;
+                st16_sys(np.stats + (int64_t)(np.slot_base + tid) * I64H_SLOT_WORDS + 4 * mt, rec);
+            }
+        }
+        // every workgroup: wave 0 collects the records of its rows' slots (lane = row + 16 q looks at publishers q, q + 4, ...)
+        if (wid == 0) {
+            uint32_t mn = 0xffffffffu, mx = 0u;
+            if ((lane & 15) < rows) {
+                const uint32_t* rec = np.stats + (int64_t)my_slot * I64H_SLOT_WORDS;
+                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                for (int j = lane >> 4; j < np.n_pub; j += 4) {
+                    v4u v;
+                    for (;;) {
+                        v = ld16_sys(rec + 4 * j);
+                        if (v.z == 1u) break;
+                        __builtin_amdgcn_s_sleep(2);
+                        if ((long long)(__builtin_amdgcn_s_memtime() - t0) > np.budget) {
+                            __hip_atomic_store(np.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                    mn = min(mn, v.x);
+                    mx = max(mx, v.y);
+                }
+            }
+            mn = min(mn, (uint32_t)__shfl_xor((int)mn, 16));
+            mx = max(mx, (uint32_t)__shfl_xor((int)mx, 16));
+            mn = min(mn, (uint32_t)__shfl_xor((int)mn, 32));
+            mx = max(mx, (uint32_t)__shfl_xor((int)mx, 32));
+            if (lane < SK_BM) {
+                QParams q;
+                q.scale = 0.0f; q.inv_scale = 0.0f; q.zp = 0;
+                if (lane < rows) q = choose_qparams_u7(ordered_to_f32(mn), ordered_to_f32(mx));
+                q_inv[lane] = q.inv_scale; q_scale[lane] = q.scale; q_zp[lane] = q.zp;
+            }
+        }
+        __syncthreads();
+        SK_STAMP(2);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int r = wid + 8 * u;
+            QParams q;
+            q.inv_scale = q_inv[r]; q.zp = q_zp[r]; q.scale = 0.0f;
+            if (lane_in) {
+                uint32_t w[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = rok[u] ? quantize4_u7_signed(x[u][e], q) : 0u;
+                *(uint4*)(smem + r * LDA + lane * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+        __syncthreads();
+        SK_STAMP(3);
     }
-    __syncthreads();
-    SK_STAMP(3);
 
     v4i acc[SK_MF][NF];
 #pragma unroll
@@ -883,7 +1118,10 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int r = i * 16 + fq * 4 + reg;
-                if (r < rows && col_ok) p.C[(int64_t)c_row[i][reg] * p.N + col] = (float)acc[i][0][reg] * (q_scale[r] * ws);
+                if (r < rows && col_ok) {
+                    const float v = (float)acc[i][0][reg] * (q_scale[r] * ws);
+                    p.C[(int64_t)c_row[i][reg] * p.N + col] = p.c_add ? c_res[i][reg] + v : v;
+                }
             }
     } else if constexpr (EPI == EPI_QKR) {
         // The workgroup's 64 columns are exactly one head (launcher: head_dim == 64 == NW * 16), so the per-head RMSNorm, the
@@ -986,6 +1224,14 @@ __global__ __launch_bounds__(NW * HW * 64) void gemm_i8_skinny_kernel(GemmI8Pair
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if ((int)blockIdx.x < pp.nblk0) gemm_i8_skinny_body<EPI, NW, HW>(pp.p[0], blockIdx.x, smem, ta);
     else gemm_i8_skinny_body<EPI, NW, HW>(pp.p[1], blockIdx.x - pp.nblk0, smem, ta);
+}
+
+// The same with the RMSNorm prologue (NormPro): the first problem's column-tile-0 workgroups publish the call statistics.
+template <int EPI, int PRO>
+__global__ __launch_bounds__(512) void gemm_i8_skinny_norm_kernel(GemmI8Pair pp, RowTailArgs ta, NormPro np) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if ((int)blockIdx.x < pp.nblk0) gemm_i8_skinny_body<EPI, 4, 2, PRO>(pp.p[0], blockIdx.x, smem, ta, np, true);
+    else gemm_i8_skinny_body<EPI, 4, 2, PRO>(pp.p[1], blockIdx.x - pp.nblk0, smem, ta, np, false);
 }
 
 // ---- fp32 GEMM on the f32 matrix cores: C[M,N] = A[M,K] @ B[N,K]^T ------------------------------------------------
@@ -1163,6 +1409,24 @@ struct i64h_gemm_desc {
     const int32_t* c_row_map;
     int32_t a_group_slots;
     int32_t b_frags;
+    const float* c_residual;
+};
+
+// mirrors i64h_norm_prologue in include/i64h.h
+struct i64h_norm_prologue {
+    const float* norm_weight;
+    float eps;
+    const int32_t* tok_slots;
+    int32_t slots_per_row;
+    int32_t num_slots;
+    int32_t slot_base;
+    uint32_t* sync;
+    const float* moe_rows;
+    const float* moe_shared;
+    float* h_out;
+    float route_weights[8];
+    int32_t top_k;
+    float routed_scale, shared_scale;
 };
 
 static int check_desc(const i64h_gemm_desc* d, const char* who) {
@@ -1176,6 +1440,8 @@ static int check_desc(const i64h_gemm_desc* d, const char* who) {
     I64H_CHECK_ARG(!d->want_stats || (d->stats != nullptr && d->epilogue == EPI_SWIGLU), "%s: statistics need the SwiGLU epilogue and stat slots", who);
     I64H_CHECK_ARG(!d->b_frags || (d->a_fp32 && d->K % 64 == 0 && d->N % (d->epilogue == EPI_SWIGLU ? 32 : 16) == 0),
                    "%s: a weight fragment pack needs the fp32 operand form, K %% 64 == 0 and whole fragment columns", who);
+    I64H_CHECK_ARG(d->c_residual == nullptr || (d->epilogue == EPI_STORE && d->a_fp32 && ((uintptr_t)d->c_residual % 4) == 0),
+                   "%s: the residual form needs the plain epilogue and the fp32 operand form", who);
     // rows that pick between their group's slots do so through the per-row slot index
     I64H_CHECK_ARG(d->a_group_slots >= 0 && (d->a_group_slots < 2 || d->a_row_slot != nullptr),
                    "%s: a_group_slots=%d needs the per-row slot index (a_row_slot)", who, d->a_group_slots);
@@ -1195,6 +1461,7 @@ static GemmI8Args to_args(const i64h_gemm_desc* d) {
     p.c_row_map = d->c_row_map;
     p.a_group_slots = d->a_group_slots;
     p.b_frags = d->b_frags;
+    p.c_add = d->c_residual;
     return p;
 }
 
@@ -1319,6 +1586,61 @@ static bool skinny_ok(const i64h_gemm_desc* d) {
     return d->a_fp32 && d->K % 64 == 0 && d->K <= SK_MAX_K && d->M_total <= SK_MAX_ROWS;
 }
 
+// ---- decode-sized launches with the RMSNorm of the residual stream in front of the quantizer ----------------------------------
+#define NORM_MAX_ROWS 256  // 16 publishers: a slot's 64 words hold 16 records
+#define NORM_MAX_K 1024    // a lane holds 16 elements of each of its two rows
+
+static int check_norm(const i64h_gemm_desc* a, const i64h_gemm_desc* b, const i64h_norm_prologue* np, const char* who) {
+    I64H_CHECK_ARG(np && np->norm_weight && np->sync, "%s: norm weight and sync words are required", who);
+    I64H_CHECK_ARG(skinny_ok(a) && a->group_offsets == nullptr && a->a_src_row == nullptr && a->a_row_slot == nullptr && a->M_total <= NORM_MAX_ROWS &&
+                       a->K <= NORM_MAX_K && a->stats != nullptr,
+                   "%s: the first problem must be one group over all rows (fp32 operand, no gather, at most %d rows, K %% 64 == 0, K <= %d)", who,
+                   NORM_MAX_ROWS, NORM_MAX_K);
+    I64H_CHECK_ARG(!b || (skinny_ok(b) && b->K == a->K && b->A == a->A && b->stats == a->stats && b->M_total <= SK_MAX_ROWS),
+                   "%s: the second problem must read the same rows (same operand, K and stat slots)", who);
+    I64H_CHECK_ARG(np->num_slots >= 1 && np->num_slots <= I64H_STAT_TAB && (np->tok_slots == nullptr || (np->slots_per_row >= 1 && np->slots_per_row <= 64)),
+                   "%s: num_slots=%d / slots_per_row=%d unsupported", who, np->num_slots, np->slots_per_row);
+    I64H_CHECK_ARG(np->slot_base == a->a_slot_base && (!b || b->a_slot_base >= np->slot_base), "%s: relative slot 0 is the first problem's slot", who);
+    I64H_CHECK_ARG(np->moe_rows == nullptr || (np->top_k >= 1 && np->top_k <= 8 && np->h_out != nullptr && (const void*)np->h_out != a->A),
+                   "%s: the combine needs 1..8 routes and an h_out that is not the operand (other workgroups still read it)", who);
+    I64H_CHECK_ARG((((uintptr_t)a->A | (uintptr_t)np->norm_weight | (uintptr_t)np->moe_rows | (uintptr_t)np->moe_shared | (uintptr_t)np->h_out) % 16) == 0,
+                   "%s: rows must be 16-byte aligned", who);
+    return 0;
+}
+
+template <int EPI>
+static int launch_skinny_norm(const i64h_gemm_desc* a, const i64h_gemm_desc* b, const i64h_norm_prologue* np, hipStream_t st,
+                              const RowTailArgs* tail = nullptr) {
+    RowTailArgs ta;
+    if (tail) ta = *tail; else memset(&ta, 0, sizeof(ta));
+    NormPro pr;
+    memset(&pr, 0, sizeof(pr));
+    pr.w = np->norm_weight; pr.eps = np->eps; pr.tok_slots = np->tok_slots; pr.spr = np->slots_per_row; pr.n_rel = np->num_slots;
+    pr.slot_base = np->slot_base; pr.n_pub = (int)((a->M_total + SK_BM - 1) / SK_BM); pr.stats = a->stats; pr.err = np->sync + 1;
+    pr.budget = i64h_grid_wait_budget();
+    pr.mc_rows = np->moe_rows; pr.mc_shared = np->moe_shared; pr.h_out = np->h_out; pr.top_k = np->top_k; pr.n = (int)a->M_total;
+    for (int k = 0; k < 8; ++k) pr.wk[k] = np->route_weights[k];
+    pr.routed_scale = np->routed_scale; pr.shared_scale = np->shared_scale;
+    GemmI8Pair pp;
+    pp.p[0] = to_args(a);
+    pp.p[1] = b ? to_args(b) : pp.p[0];
+    const int nout_a = a->epilogue == EPI_SWIGLU ? a->N / 2 : a->N;
+    // the publishing workgroups lead the launch: inside the grid where its column slots allow the trade, else as extra workgroups
+    pp.nblk0 = skinny_blocks(a, 64) + (pr.n_pub <= sk_pad_tiles((nout_a + 63) / 64) ? 0 : ((pr.n_pub + 7) & ~7));
+    const int total = pp.nblk0 + (b ? skinny_blocks(b, 64) : 0);
+    if (g_stamps && g_stamp_cur + total <= g_stamp_cap) {
+        pp.p[0].stamps = pp.p[1].stamps = g_stamps + g_stamp_cur * 8;
+        g_stamp_cur += total;
+    }
+    size_t area = (size_t)SK_BM * (a->K + 32);
+    if (area < SK_AREA_MIN) area = SK_AREA_MIN;
+    const size_t lds = area + 16 + 3 * SK_BM * 4;
+    if (np->moe_rows) hipLaunchKernelGGL((gemm_i8_skinny_norm_kernel<EPI, 2>), dim3((unsigned)total), dim3(512), lds, st, pp, ta, pr);
+    else hipLaunchKernelGGL((gemm_i8_skinny_norm_kernel<EPI, 1>), dim3((unsigned)total), dim3(512), lds, st, pp, ta, pr);
+    I64H_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" {
 
 // tuning knob: 1 (default) = the decode-sized kernel's four-wave workgroups get four helper waves for the operand rows
@@ -1389,6 +1711,9 @@ int i64h_gemm_i8_pair(const i64h_gemm_desc* a, const i64h_gemm_desc* b, void* st
     hipStream_t st = (hipStream_t)stream;
     I64H_CHECK_ARG(!(a->b_frags || (b && b->b_frags)) || (skinny_ok(a) && (!b || skinny_ok(b))),
                    "gemm_i8_pair: a weight fragment pack is read by the decode-sized kernel only (every problem of the launch: fp32 operand, at most %d rows, K %% 64 == 0, K <= %d)",
+                   SK_MAX_ROWS, SK_MAX_K);
+    I64H_CHECK_ARG(!(a->c_residual || (b && b->c_residual)) || (skinny_ok(a) && (!b || skinny_ok(b))),
+                   "gemm_i8_pair: the residual form is served by the decode-sized kernel only (fp32 operand, at most %d rows, K %% 64 == 0, K <= %d)",
                    SK_MAX_ROWS, SK_MAX_K);
     const bool mapped = a->c_row_map != nullptr || (b && b->c_row_map != nullptr);
     I64H_CHECK_ARG(!mapped || a->epilogue == EPI_STORE, "gemm_i8_pair: an output row map needs the plain epilogue");
@@ -1468,6 +1793,41 @@ int i64h_gemm_i8_qkv_rope_kv(const i64h_gemm_desc* d, const float* q_norm_w, con
     ta.rope_tab = rope_tab; ta.qw = q_norm_w; ta.kw = k_norm_w; ta.qk_eps = qk_eps; ta.q_out = q_out; ta.k_cache = k_cache; ta.v_cache = v_cache;
     ta.kv_dtype = kv_dtype; ta.nh = num_heads; ta.kvh = num_kv_heads; ta.block = block_size;
     return launch_skinny<EPI_QKR, 4>(d, nullptr, (hipStream_t)stream, &ta);
+}
+
+// i64h_gemm_i8_pair with the RMSNorm of the operand rows (and optionally the token-routed layer's combine) in front of the
+// quantizer: one launch for "residual + norm" and the Linear call(s) that read the normalised rows.
+int i64h_gemm_i8_pair_norm(const i64h_gemm_desc* a, const i64h_gemm_desc* b, const i64h_norm_prologue* np, void* stream) {
+    I64H_CHECK_ARG(a != nullptr, "gemm_i8_pair_norm: first problem missing");
+    if (check_desc(a, "gemm_i8_pair_norm[0]")) return 1;
+    if (b && check_desc(b, "gemm_i8_pair_norm[1]")) return 1;
+    I64H_CHECK_ARG(!b || a->epilogue == b->epilogue, "gemm_i8_pair_norm: problems must share the epilogue");
+    if (int rc = check_norm(a, b, np, "gemm_i8_pair_norm")) return rc;
+    I64H_CHECK_ARG(!(a->c_row_map || (b && b->c_row_map)) || a->epilogue == EPI_STORE, "gemm_i8_pair_norm: an output row map needs the plain epilogue");
+    if (a->M_total == 0) return 0;
+    return a->epilogue == EPI_STORE ? launch_skinny_norm<EPI_STORE>(a, b, np, (hipStream_t)stream)
+                                    : launch_skinny_norm<EPI_SWIGLU>(a, b, np, (hipStream_t)stream);
+}
+
+// i64h_gemm_i8_qkv_rope_kv with the same prologue: combine + residual + norm + qkv projection + QK norm + RoPE + cache write.
+int i64h_gemm_i8_qkv_rope_kv_norm(const i64h_gemm_desc* d, const i64h_norm_prologue* np, const float* q_norm_w, const float* k_norm_w, float qk_eps,
+                                  const float* rope_tab, const int32_t* positions, const int32_t* slot_ids, const int32_t* block_table,
+                                  int32_t max_blocks_per_seq, float* q_out, void* k_cache, void* v_cache, int32_t kv_dtype, int32_t num_heads,
+                                  int32_t num_kv_heads, int32_t head_dim, int32_t block_size, void* stream) {
+    if (int rc = check_fused(d, "gemm_i8_qkv_rope_kv_norm")) return rc;
+    if (int rc = check_norm(d, nullptr, np, "gemm_i8_qkv_rope_kv_norm")) return rc;
+    I64H_CHECK_ARG(head_dim == 64 && d->N == (num_heads + 2 * num_kv_heads) * 64 && d->K >= 256,
+                   "gemm_i8_qkv_rope_kv_norm: head_dim %d / N %d / K %d unsupported (head_dim 64, N = (heads + 2 kv heads) * 64, K >= 256)", head_dim,
+                   d->N, d->K);
+    I64H_CHECK_ARG(kv_dtype >= 0 && kv_dtype <= 4 && block_size > 0, "gemm_i8_qkv_rope_kv_norm: bad kv dtype / block size");
+    I64H_CHECK_ARG(positions && slot_ids && block_table && rope_tab && q_out && k_cache && v_cache, "gemm_i8_qkv_rope_kv_norm: null argument");
+    if (d->M_total == 0) return 0;
+    RowTailArgs ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.positions = positions; ta.slot_ids = slot_ids; ta.block_table = block_table; ta.max_blocks_per_seq = max_blocks_per_seq;
+    ta.rope_tab = rope_tab; ta.qw = q_norm_w; ta.kw = k_norm_w; ta.qk_eps = qk_eps; ta.q_out = q_out; ta.k_cache = k_cache; ta.v_cache = v_cache;
+    ta.kv_dtype = kv_dtype; ta.nh = num_heads; ta.kvh = num_kv_heads; ta.block = block_size;
+    return launch_skinny_norm<EPI_QKR>(d, nullptr, np, (hipStream_t)stream, &ta);
 }
 
 int i64h_gemm_f32(const float* A, const int32_t* a_rows, const float* B, float* C, int64_t M, int32_t N, int32_t K, void* stream) {

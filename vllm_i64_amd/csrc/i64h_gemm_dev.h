@@ -26,6 +26,7 @@ struct GemmI8Args {
     const float* w_scale;      // [G]
     const float* col_scale;    // EPI_STORE, optional: per-output-channel scale [G][N] used instead of w_scale[g]
     const int32_t* c_row_map;  // EPI_STORE, optional: operand row r is stored as output row c_row_map[r] (not in the row-streaming kernel)
+    const float* c_add;        // EPI_STORE, decode-sized kernel, optional: C = c_add + product (same layout as C; may be C itself)
     int b_frags;               // decode-sized kernel: B is the fragment pack of the weights
     int a_group_slots;         // a_fp32, optional promise: a_row_slot[r] of a row of group g lies in [g * S, g * S + S) (S = this value)
     const int32_t* group_off;  // [G+1] device, or nullptr => one group [0, M_total)
@@ -53,6 +54,46 @@ struct RowTailArgs {
     void* v_cache;
     int kv_dtype, nh, kvh, block;
 };
+// RMSNorm in front of the quantizer of the decode-sized kernel (i64h_gemm_i8_pair_norm): the operand rows of the problem are
+// the residual stream; every workgroup normalises the rows of its tile itself (the arithmetic of fused_residual_norm_kernel,
+// same order, same bits), the workgroups of the launch's FIRST problem that own output column tile 0 ("publishers": one per
+// 16-row tile, the first problem covers every token once) hand the (min, max) of the normalised rows per stat slot to all
+// other workgroups through one 16-byte record each, and every workgroup waits for the records of its rows' slots only.
+// Record j (publisher j = row tile j) of slot s: words [4 j, 4 j + 4) of the slot's 64 = (ordered min, ordered max, 1, 0),
+// written by ONE 16-byte write-through store and polled by 16-byte loads that bypass the caches; the slot words start the
+// step as I64H_ORDERED_ZERO (the step's stat reset), so word 2 == 1 says "published".  At most 16 publishers (256 rows).
+struct NormPro {
+    const float* w;            // norm weight [K]
+    float eps;
+    const int32_t* tok_slots;  // [n, spr] relative slots of token t (nullptr: slot 0 only)
+    int spr;
+    int n_rel;                 // relative slots 0 .. n_rel - 1 get a record from every publisher
+    int slot_base;             // record slot = slot_base + relative slot
+    int n_pub;                 // publishers = row tiles of the first problem
+    uint32_t* stats;
+    uint32_t* err;             // sticky error word: a wait ran out of its budget
+    long long budget;
+    // optional MoE combine in front of the norm (token-routed layer output): row value = h + (routed_scale * (sum_k wk * R_k) +
+    // shared_scale * shared); publishers store it to h_out
+    const float* mc_rows;      // [top_k * n, K] routed outputs in (route, token) order (nullptr: the row value is the operand row)
+    const float* mc_shared;    // [n, K] or nullptr
+    float* h_out;
+    float wk[8];
+    int top_k, n;
+    float routed_scale, shared_scale;
+};
+
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+// 16 bytes past every cache level, in one access (system-scope store: write-through, the line leaves the L2; system-scope load)
+__device__ __forceinline__ void st16_sys(uint32_t* p, v4u v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ v4u ld16_sys(const uint32_t* p) {
+    v4u r;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+
 // Wave-wide search for m-tile mt of a grouped problem: lane i looks at group c0 + i, 64 groups per pass; writes
 // (group or -1, first row, rows in the tile) to s_info.  The grid is an upper bound on the number of m-tiles.
 template <int BM>

@@ -149,6 +149,7 @@ class _Buffers:
         i8 = dict(dtype=torch.int8, device=device)
         kvw = cfg.num_kv_heads * cfg.head_dim
         self.h = torch.empty(n, H, **f32)
+        self.h2 = torch.empty(n, H, **f32) if n <= 256 else None   # decode-sized steps: the residual stream alternates between the two
         self.normed = torch.empty(n, H, **f32)
         self.qkv = torch.empty(n, H + 2 * kvw, **f32)
         self.q = torch.empty(n, cfg.num_heads, cfg.head_dim, **f32)
@@ -297,6 +298,14 @@ class I64MoEModel:
                                "once: another process or stream on the GPU, a CU mask?); the logits of this forward are invalid. "
                                "I64H_FUSE_NORM_QUANT=0 selects the launches without a grid barrier")
 
+    # decode-sized steps: the two residual + norm launches of a layer ride in the launches around them - the residual add in the
+    # epilogue of the o projection (dense model: of the down projection too), the norm (and the token-routed layer's combine) in
+    # front of the quantizer of the gate_up launch and of the next layer's qkv launch: 5 instead of 7 launches per layer, same bits
+    FUSE_DECODE_NORM = os.environ.get("I64H_FUSE_DECODE_NORM", "1") != "0"
+    # ... the qkv half of it.  Default (None): on for the dense model, off for token-routed layers - there every workgroup of the
+    # qkv launch has to re-form the combine from four row streams, which measured slower than the launch it replaces (17.6 against
+    # 8.2 + 4.9 us per layer at batch 64); "1" / "0" in the environment force it
+    FUSE_DECODE_QKV_NORM = {"1": True, "0": False}.get(os.environ.get("I64H_FUSE_DECODE_QKV_NORM", ""), None)
     FUSE_MAX_ROWS = 256  # up to this many operand rows the quantizer runs inside the GEMM (one launch per Linear call)
     EP_FUSE_MAX_ROWS = 1024  # the same for the pooled expert rows of the expert-parallel runner (8 ranks x 64 sequences x top-2)
     fuse_qkr = True   # decode-sized steps: QK norm / RoPE / cache write inside the qkv GEMM
@@ -468,6 +477,13 @@ class I64MoEModel:
         if fuse_rows and record is None and inject is None and self._tail_supported(n):
             tails = self._tails(B, kvc, positions, slot_ids)
             self._resident_used = True
+        if (self.FUSE_DECODE_NORM and fuse_rows and tails is None and record is None and inject is None and self.ep is None and self.fuse_qkr
+                and cfg.head_dim == 64 and 256 <= H <= 1024 and H % 64 == 0
+                and (not cfg.is_moe or (cfg.shared_intermediate_size and 0 < B.plan.rows <= self.FUSE_MAX_ROWS))):
+            self._layers_norm_fused(B, kvc, positions, slot_ids, ctx_len, splits, rows_are_slots)
+            ops.call("i64h_gemm_f32", ops.ptr(B.normed), ops.ptr(logit_rows), ops.ptr(self.embed), ops.ptr(B.logits), B.logits.shape[0],
+                     cfg.vocab_size, H, ops._stream())
+            return B.logits
         for l, W in enumerate(self.layers):
             base = l * spl
             if tails is not None:
@@ -572,6 +588,75 @@ class I64MoEModel:
         ops.call("i64h_gemm_f32", ops.ptr(B.normed), ops.ptr(logit_rows), ops.ptr(self.embed), ops.ptr(B.logits), B.logits.shape[0],
                  cfg.vocab_size, H, ops._stream())
         return B.logits
+
+    def _layers_norm_fused(self, B: _Buffers, kvc, positions, slot_ids, ctx_len, splits: int, rows_are_slots: bool):
+        """The layers of a decode-sized step with five launches each: qkv projection (+ QK norm, RoPE, cache write; from the second
+        layer on with the previous layer's combine + residual + norm in front of its quantizer), attention, o projection with the
+        residual add in its epilogue, the gate_up launch with residual norm in front of its quantizer, the down launch.  Enters with
+        layer 0's normalised rows in B.normed and its statistics in slot 0; leaves the final norm's rows in B.normed.  Every value
+        has the bits of the seven-launch form (tests/test_gpu_decode_norm.py)."""
+        cfg, st, spl, nbk = self.cfg, self.stats, self.spl, self.nb
+        H, eps, rw, L = cfg.hidden_size, cfg.rms_eps, cfg.route_weights, cfg.num_layers
+        n = B.h.shape[0]
+        hbuf, halt = B.h, B.h2
+        S = cfg.shared_intermediate_size if cfg.is_moe else 0
+        qkv_norm = (not cfg.is_moe) if self.FUSE_DECODE_QKV_NORM is None else self.FUSE_DECODE_QKV_NORM
+        self._resident_used = True
+        for l, W in enumerate(self.layers):
+            base = l * spl
+            qkr = (W["q_norm"], W["k_norm"], 1e-6, self.rope, positions, slot_ids, kvc.block_table, kvc.k[l], kvc.v[l], B.q,
+                   cfg.num_heads, cfg.num_kv_heads, cfg.head_dim)
+            if l == 0 or not qkv_norm:
+                ops.gemm_i8_qkv_rope_kv(ops.gemm_desc(B.normed, W["qkv"].w_q, W["qkv"].w_s, B.qkv, a_slot_base=base, stats=st, w_frags=self._wf(W["qkv"])), *qkr)
+            else:
+                d = ops.gemm_desc(hbuf, W["qkv"].w_q, W["qkv"].w_s, B.qkv, a_slot_base=base, stats=st, w_frags=self._wf(W["qkv"]))
+                if cfg.is_moe:   # the previous layer's routed + shared outputs join the residual stream here
+                    Wp = self.layers[l - 1]
+                    pro = ops.norm_prologue(W["ln1"], eps, self.dec_sync, slot_base=base, moe_rows=B.e_out, moe_shared=B.sh_out if S else None,
+                                            h_out=halt, route_weights=rw, routed_scale=Wp["routed_scale"], shared_scale=Wp["shared_scale"])
+                    ops.gemm_i8_qkv_rope_kv_norm(d, pro, *qkr)
+                    hbuf, halt = halt, hbuf
+                else:
+                    ops.gemm_i8_qkv_rope_kv_norm(d, ops.norm_prologue(W["ln1"], eps, self.dec_sync, slot_base=base), *qkr)
+            ops.paged_attn(B.q, kvc.k[l], kvc.v[l], kvc.block_table, ctx_len, slot_ids=None if rows_are_slots else slot_ids,
+                           softmax_scale=1.0 / math.sqrt(cfg.head_dim), splits=splits, out=B.attn, workspace=B.attn_ws,
+                           stats=st, stat_slot=base + 1)
+            # h += o_proj(attn): the add rides in the projection's epilogue
+            ops.gemm_i8_pair(ops.gemm_desc(B.attn.view(n, H), W["o"].w_q, W["o"].w_s, hbuf, a_slot_base=base + 1, stats=st, w_frags=self._wf(W["o"]),
+                                           c_residual=hbuf))
+            if cfg.is_moe:
+                plan = B.plan
+                R = plan.rows
+                s_gu = ops.gemm_desc(hbuf, W["sh_gu"].w_q, W["sh_gu"].w_s, B.sh_inter, a_slot_base=base + 2, epilogue=ops.EPI_SWIGLU,
+                                     out_slot_base=base + 3 + nbk, stats=st, want_stats=True, w_frags=self._wf(W["sh_gu"], ops.EPI_SWIGLU, W["exp_gu"]))
+                e_gu = ops.gemm_desc(hbuf, W["exp_gu"].w_q, W["exp_gu"].w_s, B.e_inter, a_src_row=plan.perm[l], a_src_mod=n,
+                                     a_row_slot=plan.sorted_bucket[l], a_slot_base=base + 3, group_offsets=plan.expert_offsets[l],
+                                     epilogue=ops.EPI_SWIGLU, out_row_slot=plan.sorted_bucket[l], out_slot_base=base + 4 + nbk, stats=st,
+                                     want_stats=True, m_total=R, w_frags=self._wf(W["exp_gu"], ops.EPI_SWIGLU, W["sh_gu"]))
+                ops.gemm_i8_pair_norm(s_gu, e_gu, ops.norm_prologue(W["ln2"], eps, self.dec_sync, slot_base=base + 2, tok_slots=plan.tok_slots[l],
+                                                                    num_slots=1 + nbk))
+                e_dn = ops.gemm_desc(B.e_inter, W["exp_dn"].w_q, W["exp_dn"].w_s, B.e_out, a_row_slot=plan.sorted_bucket[l],
+                                     a_slot_base=base + 4 + nbk, group_offsets=plan.expert_offsets[l], stats=st, m_total=R,
+                                     c_row_map=plan.perm[l], a_group_slots=cfg.top_k, w_frags=self._wf(W["exp_dn"], partner=W["sh_dn"]))
+                s_dn = ops.gemm_desc(B.sh_inter, W["sh_dn"].w_q, W["sh_dn"].w_s, B.sh_out, a_slot_base=base + 3 + nbk, stats=st,
+                                     w_frags=self._wf(W["sh_dn"], partner=W["exp_dn"]))
+                ops.gemm_i8_pair(s_dn, e_dn)
+            else:
+                gu = ops.gemm_desc(hbuf, W["gu"].w_q, W["gu"].w_s, B.d_inter, a_slot_base=base + 2, epilogue=ops.EPI_SWIGLU,
+                                   out_slot_base=base + 3, stats=st, want_stats=True, w_frags=self._wf(W["gu"], ops.EPI_SWIGLU))
+                ops.gemm_i8_pair_norm(gu, None, ops.norm_prologue(W["ln2"], eps, self.dec_sync, slot_base=base + 2))
+                ops.gemm_i8_pair(ops.gemm_desc(B.d_inter, W["dn"].w_q, W["dn"].w_s, hbuf, a_slot_base=base + 3, stats=st, w_frags=self._wf(W["dn"]),
+                                               c_residual=hbuf))
+            if l + 1 < L and not qkv_norm:   # the layer's closing combine + norm as a launch of its own
+                mk = dict(moe_rows=B.e_out, moe_inv=None, moe_shared=B.sh_out if S else None, route_weights=rw, routed_scale=W["routed_scale"],
+                          shared_scale=W["shared_scale"]) if cfg.is_moe else {}
+                ops.fused_residual_norm(hbuf, self.layers[l + 1]["ln1"], eps, normed=B.normed, h_out=hbuf, slot_base=base + spl, stats=st, **mk)
+        Wl = self.layers[L - 1]
+        if cfg.is_moe:
+            ops.fused_residual_norm(hbuf, self.final_norm, eps, normed=B.normed, moe_rows=B.e_out, moe_inv=None, moe_shared=B.sh_out if S else None,
+                                    route_weights=rw, routed_scale=Wl["routed_scale"], shared_scale=Wl["shared_scale"], h_out=B.h)
+        else:
+            ops.fused_residual_norm(hbuf, self.final_norm, eps, normed=B.normed, h_out=B.h)
 
     def _forward_fp8(self, token_ids, positions, slot_ids, ctx_len, logit_rows, kvc, record, max_ctx_hint, rows_are_slots):
         """The forward with every Linear an fp8_linear (vllm_i64/core/fp8.py:137-194, its torch._scaled_mm branch): activations are

@@ -248,7 +248,7 @@ def gemm_i8_frags(a: torch.Tensor, row_scale: torch.Tensor, w_frags: torch.Tenso
 def gemm_desc(a: torch.Tensor, w: torch.Tensor, w_scale: torch.Tensor, out: torch.Tensor, *, row_scale=None, a_src_row=None,
               a_src_mod: int = 0, a_row_slot=None, a_slot_base: int = 0, group_offsets=None, epilogue: int = EPI_STORE,
               out_row_slot=None, out_slot_base: int = 0, stats=None, want_stats: bool = False, m_total: Optional[int] = None,
-              c_row_map=None, a_group_slots: int = 0, w_frags: Optional[torch.Tensor] = None):
+              c_row_map=None, a_group_slots: int = 0, w_frags: Optional[torch.Tensor] = None, c_residual=None):
     """Build an i64h_gemm_desc.  a is int8 [M, K] (with row_scale) or fp32 [*, K] (quantized on the fly from the stat slots).
     w_frags: the fragment pack of w (pack_weight_frags), read instead of w by the decode-sized kernel."""
     if w.dim() == 2:
@@ -264,6 +264,7 @@ def gemm_desc(a: torch.Tensor, w: torch.Tensor, w_scale: torch.Tensor, out: torc
     d.N, d.K, d.C, d.epilogue = N, K, ptr(out), epilogue
     d.out_row_slot, d.out_slot_base, d.stats, d.want_stats = ptr(out_row_slot), out_slot_base, ptr(stats), int(want_stats)
     d.c_row_map, d.a_group_slots = ptr(c_row_map), a_group_slots
+    d.c_residual = ptr(c_residual)   # decode-sized problems, plain epilogue: out = c_residual + product
     return d
 
 
@@ -352,6 +353,35 @@ def gemm_i8_qkv_rope_kv(desc, q_norm_w, k_norm_w, qk_eps, rope_tab, positions, s
     call("i64h_gemm_i8_qkv_rope_kv", ctypes.addressof(desc), ptr(q_norm_w), ptr(k_norm_w), float(qk_eps), ptr(rope_tab), ptr(positions),
          ptr(slot_ids), ptr(block_table), block_table.shape[1], ptr(q_out), ptr(k_cache), ptr(v_cache), KV_DTYPE_CODE[k_cache.dtype],
          num_heads, num_kv_heads, head_dim, k_cache.shape[1], _stream())
+    return q_out
+
+
+def norm_prologue(norm_weight, eps: float, sync, *, slot_base: int, tok_slots=None, num_slots: int = 1, moe_rows=None, moe_shared=None,
+                  h_out=None, route_weights=(), routed_scale: float = 1.0, shared_scale: float = 1.0):
+    """Build an i64h_norm_prologue: the RMSNorm (behind the token-routed layer's combine when moe_rows is given) that a decode-sized
+    launch runs in front of its quantizer (gemm_i8_pair_norm, gemm_i8_qkv_rope_kv_norm)."""
+    p = _lib.NormPrologue()
+    p.norm_weight, p.eps, p.sync, p.slot_base = ptr(norm_weight), float(eps), ptr(sync), slot_base
+    p.tok_slots = ptr(tok_slots)
+    p.slots_per_row = tok_slots.shape[-1] if tok_slots is not None else 1
+    p.num_slots = num_slots
+    p.moe_rows, p.moe_shared, p.h_out = ptr(moe_rows), ptr(moe_shared), ptr(h_out)
+    for k, wk in enumerate(route_weights):
+        p.route_weights[k] = float(wk)
+    p.top_k, p.routed_scale, p.shared_scale = len(route_weights), float(routed_scale), float(shared_scale)
+    return p
+
+
+def gemm_i8_pair_norm(a_desc, b_desc, pro):
+    call("i64h_gemm_i8_pair_norm", ctypes.addressof(a_desc), ctypes.addressof(b_desc) if b_desc is not None else 0, ctypes.addressof(pro), _stream())
+
+
+def gemm_i8_qkv_rope_kv_norm(desc, pro, q_norm_w, k_norm_w, qk_eps, rope_tab, positions, slot_ids, block_table, k_cache, v_cache, q_out,
+                             num_heads: int, num_kv_heads: int, head_dim: int):
+    """gemm_i8_qkv_rope_kv with the RMSNorm prologue: the previous layer's combine + residual + norm ride in the same launch."""
+    call("i64h_gemm_i8_qkv_rope_kv_norm", ctypes.addressof(desc), ctypes.addressof(pro), ptr(q_norm_w), ptr(k_norm_w), float(qk_eps), ptr(rope_tab),
+         ptr(positions), ptr(slot_ids), ptr(block_table), block_table.shape[1], ptr(q_out), ptr(k_cache), ptr(v_cache),
+         KV_DTYPE_CODE[k_cache.dtype], num_heads, num_kv_heads, head_dim, k_cache.shape[1], _stream())
     return q_out
 
 
