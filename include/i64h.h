@@ -136,10 +136,6 @@ int i64h_gemm_i8_pair(const i64h_gemm_desc* a, const i64h_gemm_desc* b, void* st
  * read them.  tok_slots[t * slots_per_row + j] (NULL: every row reports to relative slot 0 only) are the relative slots row t
  * reports to, as in i64h_fused_residual_norm; the problems name the slot their rows are quantized with through a_slot_base /
  * a_row_slot as usual (first problem: a_slot_base == slot_base, no a_row_slot).
- * moe_rows != NULL: the token-routed layer's combine joins the residual stream in front of the norm
- * (row = h + (routed_scale * (sum_k route_weights[k] * moe_rows[k * n + t]) + shared_scale * moe_shared[t]), the evaluation
- * order of vllm_i64/layers/token_routed_mlp.py:156-183); the publishing workgroups store the new residual rows to h_out, which
- * must not be the operand itself (other workgroups still read it).
  * sync: the sync words of i64h_decode_sync_words(); a wait that runs out of its budget (i64h_set_grid_wait_budget) raises
  * sync[1] and goes on.  Waiting workgroups never hold back the ones they wait for: publishers are the launch's first
  * workgroups per row tile and wait for nobody before they publish.
@@ -153,12 +149,6 @@ typedef struct i64h_norm_prologue {
     int32_t num_slots;            /* relative slots 0 .. num_slots - 1 (<= 272) */
     int32_t slot_base;
     uint32_t* sync;
-    const float* moe_rows;        /* [top_k * n, K] in (route, token) order, or NULL */
-    const float* moe_shared;      /* [n, K] or NULL */
-    float* h_out;                 /* [n, K], required with moe_rows */
-    float route_weights[8];
-    int32_t top_k;
-    float routed_scale, shared_scale;
 } i64h_norm_prologue;
 int i64h_gemm_i8_pair_norm(const i64h_gemm_desc* a, const i64h_gemm_desc* b, const i64h_norm_prologue* np, void* stream);
 /* Decode-sized fused form (fp32 operand quantized in the kernel from its stat slot, one group, <= 512 rows, K % 64 == 0,
@@ -170,8 +160,8 @@ int i64h_gemm_i8_qkv_rope_kv(const i64h_gemm_desc* d, const float* q_norm_w, con
                              const int32_t* positions, const int32_t* slot_ids, const int32_t* block_table, int32_t max_blocks_per_seq,
                              float* q_out, void* k_cache, void* v_cache, int32_t kv_dtype, int32_t num_heads, int32_t num_kv_heads,
                              int32_t head_dim, int32_t block_size, void* stream);
-/* The same launch with the RMSNorm prologue of i64h_gemm_i8_pair_norm (one problem): combine + residual + norm of the previous
- * layer's output, qkv projection, QK norm, RoPE and cache write in one launch. */
+/* The same launch with the RMSNorm prologue of i64h_gemm_i8_pair_norm (one problem): the norm of the residual stream, the qkv
+ * projection, QK norm, RoPE and cache write in one launch. */
 int i64h_gemm_i8_qkv_rope_kv_norm(const i64h_gemm_desc* d, const i64h_norm_prologue* np, const float* q_norm_w, const float* k_norm_w,
                                   float qk_eps, const float* rope_tab, const int32_t* positions, const int32_t* slot_ids,
                                   const int32_t* block_table, int32_t max_blocks_per_seq, float* q_out, void* k_cache, void* v_cache,

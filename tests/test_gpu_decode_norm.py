@@ -1,6 +1,6 @@
 """Decode-sized steps with the residual + norm launches folded into the launches around them (residual add in the epilogue of
-the o / dense down projection, RMSNorm - behind the token-routed layer's combine - in front of the quantizer of the gate_up and
-qkv launches, call statistics handed between the workgroups of a launch) against the seven-launches-per-layer form on the
+the o / dense down projection, RMSNorm in front of the quantizer of the gate_up launch and, dense model, of the qkv launch, call
+statistics handed between the workgroups of a launch) against the seven-launches-per-layer form on the
 same state: logits and cache contents must be bit-identical, at the real dimensions of the three BASELINE configurations
 (two- and three-layer cuts), on ragged and skewed batches, eagerly and under a HIP graph."""
 import dataclasses
@@ -32,7 +32,6 @@ def _model(dev, name, kv_dtype, batch, layers=3):
 def _decode(model, dec_state, steps, fused, kv_snapshot, use_graph=False):
     from vllm_i64_amd.model import GreedyDecoder
     model.FUSE_DECODE_NORM = fused
-    model.FUSE_DECODE_QKV_NORM = True   # both halves of the fusion, whatever the runner's default for the configuration
     for l in range(model.cfg.num_layers):
         model.kv.k[l].copy_(kv_snapshot[0][l])
         model.kv.v[l].copy_(kv_snapshot[1][l])
@@ -147,7 +146,6 @@ def test_norm_fused_small_shapes_more_row_tiles_than_column_tiles(dev, kind, bat
     torch.cuda.synchronize()
     snap = ([k.clone() for k in model.kv.k], [v.clone() for v in model.kv.v])
     state = (dec.tokens.clone(), lens)
-    model.FUSE_DECODE_QKV_NORM = True
     a, ka, va = _decode(model, state, 3, True, snap)
     b, kb, vb = _decode(model, state, 3, False, snap)
     for i, (x, y) in enumerate(zip(a, b)):

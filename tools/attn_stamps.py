@@ -1,11 +1,11 @@
-"""Phase timing inside the decode attention kernel (s_memtime stamps): batch 64, 2048-token contexts, bf16 cache."""
+"""Phase timing inside the decode attention kernel (s_memtime stamps), bf16 cache: python tools/attn_stamps.py [ctx] [splits] [batch]."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vllm_i64_amd import ops
 
 dev = torch.device("cuda:0")
-B, ctx, nh, kvh, hd = 64, int(sys.argv[1]) if len(sys.argv) > 1 else 2048, 16, 4, 64
+B, ctx, nh, kvh, hd = int(sys.argv[3]) if len(sys.argv) > 3 else 64, int(sys.argv[1]) if len(sys.argv) > 1 else 2048, 16, 4, 64
 splits = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 nblk = B * (ctx // 16 + 2)
 kc = torch.randn(nblk, 16, kvh, hd, device=dev).to(torch.bfloat16)
@@ -27,7 +27,7 @@ ops.call("i64h_debug_set_attn_stamps", 0)
 st = buf.view(B * splits, 8).cpu().double()
 names = ["entry -> first rows requested", "-> token loop done", "-> partials written", "-> arrival counted"]
 d = st[:, 1:5] - st[:, 0:4]
-print(f"ctx {ctx}: workgroup lifetime median {(st[:, 4] - st[:, 0]).median():.0f} max {(st[:, 4] - st[:, 0]).max():.0f} ticks; "
+print(f"batch {B} splits {splits} ctx {ctx}: workgroup lifetime median {(st[:, 4] - st[:, 0]).median():.0f} max {(st[:, 4] - st[:, 0]).max():.0f} ticks; "
       + ", ".join(f"{n} {d[:, j].median():.0f}" for j, n in enumerate(names)))
 last = st[:, 5] > 0
 print(f"last-arriving workgroups: {int(last.sum())}; merge phase median {(st[last, 5] - st[last, 4]).median():.0f} ticks")

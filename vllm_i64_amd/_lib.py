@@ -119,8 +119,7 @@ class GemmDesc(ctypes.Structure):
 class NormPrologue(ctypes.Structure):
     """Mirror of i64h_norm_prologue (include/i64h.h)."""
     _fields_ = [("norm_weight", _P), ("eps", _F), ("tok_slots", _P), ("slots_per_row", _I), ("num_slots", _I), ("slot_base", _I),
-                ("sync", _P), ("moe_rows", _P), ("moe_shared", _P), ("h_out", _P), ("route_weights", _F * 8), ("top_k", _I),
-                ("routed_scale", _F), ("shared_scale", _F)]
+                ("sync", _P)]
 
 
 class Fp8RowsDesc(ctypes.Structure):

@@ -716,6 +716,38 @@ __device__ __forceinline__ void attn_merge_row(const float* part_o, const float*
                     ot.z = __builtin_fmaf(f, pb[s].x, ot.z); ot.w = __builtin_fmaf(f, pb[s].y, ot.w);
                 }
             }
+        } else if (COH && splits <= 32) {
+            // 9 .. 32 splits (few rows, long contexts): the same two passes with every load of a pass in flight together - all (m, l)
+            // pairs at once, the partial rows sixteen splits at a time - instead of one dependent round trip per split; the
+            // operations and their order are those of the loop below, so the bits are too
+            float2 msl[32];
+#pragma unroll
+            for (int s = 0; s < 32; ++s) msl[s] = ld_agent2(ml + 2 * (s < splits ? s : 0));
+#pragma unroll
+            for (int s = 0; s < 32; ++s)
+                if (s < splits) mm = fmaxf(mm, msl[s].x);
+            if (mm != -INFINITY) {
+#pragma unroll
+                for (int s0 = 0; s0 < 32; s0 += 16) {
+                    if (s0 >= splits) break;
+                    float2 pa[16], pb[16];
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) {
+                        const float* pp = part_o + (head * splits + (s0 + s < splits ? s0 + s : 0)) * HD + d;
+                        pa[s] = ld_agent2(pp);
+                        pb[s] = ld_agent2(pp + 2);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) {
+                        if (s0 + s >= splits) break;
+                        const float ms = msl[s0 + s].x;
+                        const float f = (ms == -INFINITY) ? 0.0f : (base2 ? exp2f(ms - mm) : expf(ms - mm));
+                        lt = __builtin_fmaf(f, msl[s0 + s].y, lt);
+                        ot.x = __builtin_fmaf(f, pa[s].x, ot.x); ot.y = __builtin_fmaf(f, pa[s].y, ot.y);
+                        ot.z = __builtin_fmaf(f, pb[s].x, ot.z); ot.w = __builtin_fmaf(f, pb[s].y, ot.w);
+                    }
+                }
+            }
         } else {
         for (int s = 0; s < splits; ++s) mm = fmaxf(mm, COH ? ld_agent(ml + 2 * s) : ml[2 * s]);  // (m, l) pairs, 8-byte aligned
         if (mm != -INFINITY) {

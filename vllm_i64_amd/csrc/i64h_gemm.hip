@@ -621,9 +621,53 @@ __host__ __device__ __forceinline__ int sk_pad_tiles(int n_tiles) { return n_til
 // HW > 1: the workgroup has HW * NW waves; the extra ("helper") waves take their share of the operand rows - request, quantize,
 // park in LDS - and then only keep the barriers: the phase in front of the K loop is bound by what one wave can request and
 // quantize, not by the CU.
-// PRO: RMSNorm (optionally behind the MoE combine) of the operand rows in front of the quantizer, with the call statistics handed
+// ---- pieces of the norm prologue -------------------------------------------------------------------------------------------
+// One row of K <= 1024 elements held by a wave, lane l elements [16 l, 16 l + 16) as four float4 (lanes past the row hold
+// nothing: lane_in).  x <- x * rsqrt(mean(x^2) + eps) * g in the arithmetic of fused_residual_norm_kernel: its thread 4 l + e holds
+// float4 e of this lane (an fma chain over the four components), its waves are this wave's rows of 16 lanes, its butterfly
+// (thread ^ 32, 16, 8, 4, 2, 1) is lane ^ 8, 4, 2, 1 and then e ^ 2, e ^ 1 inside the lane; the four wave sums are added in order.
+// lo / hi: this lane's share of the row's (min, max) including 0.
+__device__ __forceinline__ void pro_norm_row(float4 (&x)[4], const float4 (&gw)[4], const bool lane_in, const int K, const float eps, float& lo,
+                                             float& hi) {
+    float sq[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float4 a = x[e];
+        float ss = __builtin_fmaf(a.x, a.x, 0.0f);
+        ss = __builtin_fmaf(a.y, a.y, ss);
+        ss = __builtin_fmaf(a.z, a.z, ss);
+        ss = __builtin_fmaf(a.w, a.w, ss);
+        ss = lane_in ? ss : 0.0f;
+        ss += I64H_DPPF(ss, 0x128);
+        ss += I64H_DPPF(ss, 0x124);
+        ss += I64H_DPPF(ss, 0x4E);
+        ss += I64H_DPPF(ss, 0xB1);
+        sq[e] = ss;
+    }
+    const float part = (sq[0] + sq[2]) + (sq[1] + sq[3]);
+    const float w0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 0));
+    const float w1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 16));
+    const float w2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 32));
+    const float w3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 48));
+    const float rr = rsqrtf((w0 + w1 + w2 + w3) / (float)K + eps);
+    lo = 0.0f;
+    hi = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float4 a = x[e];
+        const float4 g = gw[e];
+        a.x = a.x * rr * g.x; a.y = a.y * rr * g.y; a.z = a.z * rr * g.z; a.w = a.w * rr * g.w;
+        x[e] = a;
+        if (lane_in) {
+            lo = fminf(lo, fminf(fminf(a.x, a.y), fminf(a.z, a.w)));
+            hi = fmaxf(hi, fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)));
+        }
+    }
+}
+
+// PRO: RMSNorm of the operand rows in front of the quantizer, with the call statistics handed
 // between the workgroups of the launch (NormPro, i64h_gemm_dev.h); pub: this problem's column-tile-0 workgroups publish them.
-template <int EPI, int NW, int HW = 1, int PRO = 0>  // PRO: 0 none, 1 norm prologue, 2 norm prologue behind the MoE combine
+template <int EPI, int NW, int HW = 1, int PRO = 0>  // PRO: 0 none, 1 norm prologue
 __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const int bid, char* smem, const RowTailArgs& ta,
                                                     const NormPro& np = NormPro(), const bool pub_problem = false) {
     constexpr int NF = (EPI == EPI_SWIGLU) ? 2 : 1;  // B fragments per wave per step
@@ -909,54 +953,7 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
             for (int e = 0; e < 4; ++e) x[u][e] = ((const float4*)((const float*)p.A + (int64_t)src[u] * K + kq * 16))[e];
 #pragma unroll
         for (int e = 0; e < 4; ++e) gw[e] = ((const float4*)(np.w + kq * 16))[e];
-        // the token-routed layer's output joins the residual stream first: all of its rows are requested now, together with the
-        // residual rows, and the weight fragments behind them
-        float4 r0[2][4], r1[2][4], sh[2][4];
-        if constexpr (PRO == 2) {
-            const int k1 = np.top_k > 1 ? 1 : 0;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int64_t t = src[u];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    r0[u][e] = ((const float4*)(np.mc_rows + t * K + kq * 16))[e];
-                    r1[u][e] = ((const float4*)(np.mc_rows + ((int64_t)k1 * np.n + t) * K + kq * 16))[e];
-                    sh[u][e] = np.mc_shared ? ((const float4*)(np.mc_shared + t * K + kq * 16))[e] : make_float4(0, 0, 0, 0);
-                }
-            }
-        }
         if (s_end > s_begin) bload(s_begin);
-        if constexpr (PRO == 2) {
-            // the reference's evaluation order: routed = w0 R0; routed += wk Rk; m = routed_scale routed (+ shared_scale shared);
-            // row = h + m  (separate multiplies and adds)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int64_t t = src[u];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float4 o = make_float4(np.wk[0] * r0[u][e].x, np.wk[0] * r0[u][e].y, np.wk[0] * r0[u][e].z, np.wk[0] * r0[u][e].w);
-                    if (np.top_k > 1) {
-                        o.x = o.x + np.wk[1] * r1[u][e].x; o.y = o.y + np.wk[1] * r1[u][e].y;
-                        o.z = o.z + np.wk[1] * r1[u][e].z; o.w = o.w + np.wk[1] * r1[u][e].w;
-                    }
-                    for (int k = 2; k < np.top_k; ++k) {
-                        const float4 rk = ((const float4*)(np.mc_rows + ((int64_t)k * np.n + t) * K + kq * 16))[e];
-                        o.x = o.x + np.wk[k] * rk.x; o.y = o.y + np.wk[k] * rk.y;
-                        o.z = o.z + np.wk[k] * rk.z; o.w = o.w + np.wk[k] * rk.w;
-                    }
-                    if (np.mc_shared) {
-                        o.x = np.routed_scale * o.x + np.shared_scale * sh[u][e].x; o.y = np.routed_scale * o.y + np.shared_scale * sh[u][e].y;
-                        o.z = np.routed_scale * o.z + np.shared_scale * sh[u][e].z; o.w = np.routed_scale * o.w + np.shared_scale * sh[u][e].w;
-                    } else {
-                        o.x = np.routed_scale * o.x; o.y = np.routed_scale * o.y; o.z = np.routed_scale * o.z; o.w = np.routed_scale * o.w;
-                    }
-                    float4 a = x[u][e];
-                    a.x = a.x + o.x; a.y = a.y + o.y; a.z = a.z + o.z; a.w = a.w + o.w;
-                    x[u][e] = a;
-                    if (pub && np.h_out && rok[u] && lane_in) ((float4*)(np.h_out + t * K + kq * 16))[e] = a;
-                }
-            }
-        }
         SK_STAMP(1);
         uint32_t* tab_lo = (uint32_t*)smem;  // publishers: (min, max) per relative slot over the tile's rows, in the operand area
         uint32_t* tab_hi = tab_lo + I64H_STAT_TAB;
@@ -966,42 +963,8 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            // sum of squares in the row kernel's order: its thread 4 l + e holds float4 e of this lane (an fma chain over the four
-            // components), its waves are this wave's rows of 16 lanes, its butterfly (thread ^ 32, 16, 8, 4, 2, 1) is lane ^ 8, 4, 2, 1
-            // and then e ^ 2, e ^ 1 inside the lane; the four wave sums are added in order
-            float sq[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float4 a = x[u][e];
-                float ss = __builtin_fmaf(a.x, a.x, 0.0f);
-                ss = __builtin_fmaf(a.y, a.y, ss);
-                ss = __builtin_fmaf(a.z, a.z, ss);
-                ss = __builtin_fmaf(a.w, a.w, ss);
-                ss = lane_in ? ss : 0.0f;
-                ss += I64H_DPPF(ss, 0x128);
-                ss += I64H_DPPF(ss, 0x124);
-                ss += I64H_DPPF(ss, 0x4E);
-                ss += I64H_DPPF(ss, 0xB1);
-                sq[e] = ss;
-            }
-            const float part = (sq[0] + sq[2]) + (sq[1] + sq[3]);
-            const float w0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 0));
-            const float w1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 16));
-            const float w2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 32));
-            const float w3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, part), 48));
-            const float rr = rsqrtf((w0 + w1 + w2 + w3) / (float)K + np.eps);
-            float lo = 0.0f, hi = 0.0f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float4 a = x[u][e];
-                const float4 g = gw[e];
-                a.x = a.x * rr * g.x; a.y = a.y * rr * g.y; a.z = a.z * rr * g.z; a.w = a.w * rr * g.w;
-                x[u][e] = a;
-                if (lane_in) {
-                    lo = fminf(lo, fminf(fminf(a.x, a.y), fminf(a.z, a.w)));
-                    hi = fmaxf(hi, fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)));
-                }
-            }
+            float lo, hi;
+            pro_norm_row(x[u], gw, lane_in, K, np.eps, lo, hi);
             if (pub) {
                 lo = wave_min(lo);
                 hi = wave_max(hi);
@@ -1230,8 +1193,9 @@ __global__ __launch_bounds__(NW * HW * 64) void gemm_i8_skinny_kernel(GemmI8Pair
 template <int EPI, int PRO>
 __global__ __launch_bounds__(512) void gemm_i8_skinny_norm_kernel(GemmI8Pair pp, RowTailArgs ta, NormPro np) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if ((int)blockIdx.x < pp.nblk0) gemm_i8_skinny_body<EPI, 4, 2, PRO>(pp.p[0], blockIdx.x, smem, ta, np, true);
-    else gemm_i8_skinny_body<EPI, 4, 2, PRO>(pp.p[1], blockIdx.x - pp.nblk0, smem, ta, np, false);
+    const int bid = blockIdx.x;
+    if (bid < pp.nblk0) gemm_i8_skinny_body<EPI, 4, 2, PRO>(pp.p[0], bid, smem, ta, np, true);
+    else gemm_i8_skinny_body<EPI, 4, 2, PRO>(pp.p[1], bid - pp.nblk0, smem, ta, np, false);
 }
 
 // ---- fp32 GEMM on the f32 matrix cores: C[M,N] = A[M,K] @ B[N,K]^T ------------------------------------------------
@@ -1421,12 +1385,6 @@ struct i64h_norm_prologue {
     int32_t num_slots;
     int32_t slot_base;
     uint32_t* sync;
-    const float* moe_rows;
-    const float* moe_shared;
-    float* h_out;
-    float route_weights[8];
-    int32_t top_k;
-    float routed_scale, shared_scale;
 };
 
 static int check_desc(const i64h_gemm_desc* d, const char* who) {
@@ -1601,10 +1559,7 @@ static int check_norm(const i64h_gemm_desc* a, const i64h_gemm_desc* b, const i6
     I64H_CHECK_ARG(np->num_slots >= 1 && np->num_slots <= I64H_STAT_TAB && (np->tok_slots == nullptr || (np->slots_per_row >= 1 && np->slots_per_row <= 64)),
                    "%s: num_slots=%d / slots_per_row=%d unsupported", who, np->num_slots, np->slots_per_row);
     I64H_CHECK_ARG(np->slot_base == a->a_slot_base && (!b || b->a_slot_base >= np->slot_base), "%s: relative slot 0 is the first problem's slot", who);
-    I64H_CHECK_ARG(np->moe_rows == nullptr || (np->top_k >= 1 && np->top_k <= 8 && np->h_out != nullptr && (const void*)np->h_out != a->A),
-                   "%s: the combine needs 1..8 routes and an h_out that is not the operand (other workgroups still read it)", who);
-    I64H_CHECK_ARG((((uintptr_t)a->A | (uintptr_t)np->norm_weight | (uintptr_t)np->moe_rows | (uintptr_t)np->moe_shared | (uintptr_t)np->h_out) % 16) == 0,
-                   "%s: rows must be 16-byte aligned", who);
+    I64H_CHECK_ARG((((uintptr_t)a->A | (uintptr_t)np->norm_weight) % 16) == 0, "%s: rows must be 16-byte aligned", who);
     return 0;
 }
 
@@ -1618,9 +1573,6 @@ static int launch_skinny_norm(const i64h_gemm_desc* a, const i64h_gemm_desc* b, 
     pr.w = np->norm_weight; pr.eps = np->eps; pr.tok_slots = np->tok_slots; pr.spr = np->slots_per_row; pr.n_rel = np->num_slots;
     pr.slot_base = np->slot_base; pr.n_pub = (int)((a->M_total + SK_BM - 1) / SK_BM); pr.stats = a->stats; pr.err = np->sync + 1;
     pr.budget = i64h_grid_wait_budget();
-    pr.mc_rows = np->moe_rows; pr.mc_shared = np->moe_shared; pr.h_out = np->h_out; pr.top_k = np->top_k; pr.n = (int)a->M_total;
-    for (int k = 0; k < 8; ++k) pr.wk[k] = np->route_weights[k];
-    pr.routed_scale = np->routed_scale; pr.shared_scale = np->shared_scale;
     GemmI8Pair pp;
     pp.p[0] = to_args(a);
     pp.p[1] = b ? to_args(b) : pp.p[0];
@@ -1635,8 +1587,7 @@ static int launch_skinny_norm(const i64h_gemm_desc* a, const i64h_gemm_desc* b, 
     size_t area = (size_t)SK_BM * (a->K + 32);
     if (area < SK_AREA_MIN) area = SK_AREA_MIN;
     const size_t lds = area + 16 + 3 * SK_BM * 4;
-    if (np->moe_rows) hipLaunchKernelGGL((gemm_i8_skinny_norm_kernel<EPI, 2>), dim3((unsigned)total), dim3(512), lds, st, pp, ta, pr);
-    else hipLaunchKernelGGL((gemm_i8_skinny_norm_kernel<EPI, 1>), dim3((unsigned)total), dim3(512), lds, st, pp, ta, pr);
+    hipLaunchKernelGGL((gemm_i8_skinny_norm_kernel<EPI, 1>), dim3((unsigned)total), dim3(512), lds, st, pp, ta, pr);
     I64H_CHECK_LAUNCH();
     return 0;
 }

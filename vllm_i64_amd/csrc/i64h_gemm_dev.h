@@ -73,14 +73,6 @@ struct NormPro {
     uint32_t* stats;
     uint32_t* err;             // sticky error word: a wait ran out of its budget
     long long budget;
-    // optional MoE combine in front of the norm (token-routed layer output): row value = h + (routed_scale * (sum_k wk * R_k) +
-    // shared_scale * shared); publishers store it to h_out
-    const float* mc_rows;      // [top_k * n, K] routed outputs in (route, token) order (nullptr: the row value is the operand row)
-    const float* mc_shared;    // [n, K] or nullptr
-    float* h_out;
-    float wk[8];
-    int top_k, n;
-    float routed_scale, shared_scale;
 };
 
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));

@@ -149,7 +149,6 @@ class _Buffers:
         i8 = dict(dtype=torch.int8, device=device)
         kvw = cfg.num_kv_heads * cfg.head_dim
         self.h = torch.empty(n, H, **f32)
-        self.h2 = torch.empty(n, H, **f32) if n <= 256 else None   # decode-sized steps: the residual stream alternates between the two
         self.normed = torch.empty(n, H, **f32)
         self.qkv = torch.empty(n, H + 2 * kvw, **f32)
         self.q = torch.empty(n, cfg.num_heads, cfg.head_dim, **f32)
@@ -302,13 +301,21 @@ class I64MoEModel:
     # epilogue of the o projection (dense model: of the down projection too), the norm (and the token-routed layer's combine) in
     # front of the quantizer of the gate_up launch and of the next layer's qkv launch: 5 instead of 7 launches per layer, same bits
     FUSE_DECODE_NORM = os.environ.get("I64H_FUSE_DECODE_NORM", "1") != "0"
-    # ... the qkv half of it.  Default (None): on for the dense model, off for token-routed layers - there every workgroup of the
-    # qkv launch has to re-form the combine from four row streams, which measured slower than the launch it replaces (17.6 against
-    # 8.2 + 4.9 us per layer at batch 64); "1" / "0" in the environment force it
-    FUSE_DECODE_QKV_NORM = {"1": True, "0": False}.get(os.environ.get("I64H_FUSE_DECODE_QKV_NORM", ""), None)
+    # ... the qkv half of it, for the dense model (the residual add of its down projection rides in that projection's epilogue).  A
+    # token-routed layer ends with the combine of its routed and shared outputs, which stays a launch of its own: re-forming it in
+    # every workgroup of the qkv launch (four row streams) and forming it in producer workgroups in front of that launch both
+    # measured slower than the launch they replace
+    FUSE_DECODE_QKV_NORM = os.environ.get("I64H_FUSE_DECODE_QKV_NORM", "1") != "0"
     FUSE_MAX_ROWS = 256  # up to this many operand rows the quantizer runs inside the GEMM (one launch per Linear call)
     EP_FUSE_MAX_ROWS = 1024  # the same for the pooled expert rows of the expert-parallel runner (8 ranks x 64 sequences x top-2)
     fuse_qkr = True   # decode-sized steps: QK norm / RoPE / cache write inside the qkv GEMM
+    # decode attention: at most this many splits per row.  The row's last-arriving workgroup merges the splits, and in-kernel stamps
+    # (tools/attn_stamps.py) put that merge at 4-6 k cycles up to 8 splits but 17 k at 16 and 34 k at 32 (the partial rows come
+    # back through cache-bypassing 8-byte loads), more than the shorter token loops of the extra splits save: batch 16 x 2048
+    # tokens 20.8 -> 18.7 us per launch, batch 1: 17.8 -> 16.8 us (with 32 splits, the earlier cap: 21-23 us).  Eight-wave
+    # workgroups for launches that fill only half the CUs were measured too: the token loop shortens (30 k -> 23 k cycles) but the
+    # waves then wait longer for each other at the end (18.9 against 19.2 us at 2048 tokens, slower at 512): not kept
+    attn_max_splits = int(os.environ.get("I64H_ATTN_MAX_SPLITS", "8"))
     attn_target_wgs = int(os.environ.get("I64H_ATTN_WGS", "256"))  # decode attention: rows x splits aimed at = one 4-wave workgroup per CU (measured: 256 beats 512 and 1024 at batch 64, ctx 2048)
 
     # decode-sized steps: everything between two attention calls (o projection ... next layer's qkv projection) as one
@@ -460,7 +467,7 @@ class I64MoEModel:
         # attention splits: enough workgroups to fill the chip when few rows carry long contexts (decode)
         splits = 1
         if max_ctx_hint >= 256 and n <= 256:
-            splits = max(1, min(32, self.attn_target_wgs // n, max_ctx_hint // 64))
+            splits = max(1, min(self.attn_max_splits, self.attn_target_wgs // n, max_ctx_hint // 64))
         if splits > 1 and (B.attn_ws is None or B.attn_splits != splits):
             B.attn_ws = ops.attn_workspace(n, cfg.num_heads, cfg.head_dim, splits, self.device)
             B.attn_splits = splits
@@ -598,9 +605,9 @@ class I64MoEModel:
         cfg, st, spl, nbk = self.cfg, self.stats, self.spl, self.nb
         H, eps, rw, L = cfg.hidden_size, cfg.rms_eps, cfg.route_weights, cfg.num_layers
         n = B.h.shape[0]
-        hbuf, halt = B.h, B.h2
+        hbuf = B.h
         S = cfg.shared_intermediate_size if cfg.is_moe else 0
-        qkv_norm = (not cfg.is_moe) if self.FUSE_DECODE_QKV_NORM is None else self.FUSE_DECODE_QKV_NORM
+        qkv_norm = self.FUSE_DECODE_QKV_NORM and not cfg.is_moe
         self._resident_used = True
         for l, W in enumerate(self.layers):
             base = l * spl
@@ -610,14 +617,7 @@ class I64MoEModel:
                 ops.gemm_i8_qkv_rope_kv(ops.gemm_desc(B.normed, W["qkv"].w_q, W["qkv"].w_s, B.qkv, a_slot_base=base, stats=st, w_frags=self._wf(W["qkv"])), *qkr)
             else:
                 d = ops.gemm_desc(hbuf, W["qkv"].w_q, W["qkv"].w_s, B.qkv, a_slot_base=base, stats=st, w_frags=self._wf(W["qkv"]))
-                if cfg.is_moe:   # the previous layer's routed + shared outputs join the residual stream here
-                    Wp = self.layers[l - 1]
-                    pro = ops.norm_prologue(W["ln1"], eps, self.dec_sync, slot_base=base, moe_rows=B.e_out, moe_shared=B.sh_out if S else None,
-                                            h_out=halt, route_weights=rw, routed_scale=Wp["routed_scale"], shared_scale=Wp["shared_scale"])
-                    ops.gemm_i8_qkv_rope_kv_norm(d, pro, *qkr)
-                    hbuf, halt = halt, hbuf
-                else:
-                    ops.gemm_i8_qkv_rope_kv_norm(d, ops.norm_prologue(W["ln1"], eps, self.dec_sync, slot_base=base), *qkr)
+                ops.gemm_i8_qkv_rope_kv_norm(d, ops.norm_prologue(W["ln1"], eps, self.dec_sync, slot_base=base), *qkr)
             ops.paged_attn(B.q, kvc.k[l], kvc.v[l], kvc.block_table, ctx_len, slot_ids=None if rows_are_slots else slot_ids,
                            softmax_scale=1.0 / math.sqrt(cfg.head_dim), splits=splits, out=B.attn, workspace=B.attn_ws,
                            stats=st, stat_slot=base + 1)
@@ -675,7 +675,7 @@ class I64MoEModel:
         ops.embedding(token_ids, self.embed, out=B.h)
         splits = 1
         if max_ctx_hint >= 256 and n <= 256:
-            splits = max(1, min(32, self.attn_target_wgs // n, max_ctx_hint // 64))
+            splits = max(1, min(self.attn_max_splits, self.attn_target_wgs // n, max_ctx_hint // 64))
         if splits > 1 and (B.attn_ws is None or B.attn_splits != splits):
             B.attn_ws = ops.attn_workspace(n, cfg.num_heads, cfg.head_dim, splits, self.device)
             B.attn_splits = splits

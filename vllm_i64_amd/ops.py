@@ -356,19 +356,14 @@ def gemm_i8_qkv_rope_kv(desc, q_norm_w, k_norm_w, qk_eps, rope_tab, positions, s
     return q_out
 
 
-def norm_prologue(norm_weight, eps: float, sync, *, slot_base: int, tok_slots=None, num_slots: int = 1, moe_rows=None, moe_shared=None,
-                  h_out=None, route_weights=(), routed_scale: float = 1.0, shared_scale: float = 1.0):
-    """Build an i64h_norm_prologue: the RMSNorm (behind the token-routed layer's combine when moe_rows is given) that a decode-sized
-    launch runs in front of its quantizer (gemm_i8_pair_norm, gemm_i8_qkv_rope_kv_norm)."""
+def norm_prologue(norm_weight, eps: float, sync, *, slot_base: int, tok_slots=None, num_slots: int = 1):
+    """Build an i64h_norm_prologue: the RMSNorm that a decode-sized launch runs in front of its quantizer (gemm_i8_pair_norm,
+    gemm_i8_qkv_rope_kv_norm)."""
     p = _lib.NormPrologue()
     p.norm_weight, p.eps, p.sync, p.slot_base = ptr(norm_weight), float(eps), ptr(sync), slot_base
     p.tok_slots = ptr(tok_slots)
     p.slots_per_row = tok_slots.shape[-1] if tok_slots is not None else 1
     p.num_slots = num_slots
-    p.moe_rows, p.moe_shared, p.h_out = ptr(moe_rows), ptr(moe_shared), ptr(h_out)
-    for k, wk in enumerate(route_weights):
-        p.route_weights[k] = float(wk)
-    p.top_k, p.routed_scale, p.shared_scale = len(route_weights), float(routed_scale), float(shared_scale)
     return p
 
 
@@ -378,7 +373,7 @@ def gemm_i8_pair_norm(a_desc, b_desc, pro):
 
 def gemm_i8_qkv_rope_kv_norm(desc, pro, q_norm_w, k_norm_w, qk_eps, rope_tab, positions, slot_ids, block_table, k_cache, v_cache, q_out,
                              num_heads: int, num_kv_heads: int, head_dim: int):
-    """gemm_i8_qkv_rope_kv with the RMSNorm prologue: the previous layer's combine + residual + norm ride in the same launch."""
+    """gemm_i8_qkv_rope_kv with the RMSNorm prologue: the norm of the residual stream rides in the same launch."""
     call("i64h_gemm_i8_qkv_rope_kv_norm", ctypes.addressof(desc), ctypes.addressof(pro), ptr(q_norm_w), ptr(k_norm_w), float(qk_eps), ptr(rope_tab),
          ptr(positions), ptr(slot_ids), ptr(block_table), block_table.shape[1], ptr(q_out), ptr(k_cache), ptr(v_cache),
          KV_DTYPE_CODE[k_cache.dtype], num_heads, num_kv_heads, head_dim, k_cache.shape[1], _stream())
