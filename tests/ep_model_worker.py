@@ -73,7 +73,8 @@ def main():
     if mode == "cpu":
         kv = M.PagedKV(ocfg, nblk, nseq)
         for step, (sids, spos, stps) in enumerate(steps):
-            lg = ep_oracle.rank_step(ocfg, bank, comm, sids[rank], spos[rank], kv, list(range(nseq)), stps[rank])
+            step_fn = ep_oracle.rank_step_a2a if os.environ.get("EP_TEST_EXCHANGE", "fixed") == "a2a" else ep_oracle.rank_step
+            lg = step_fn(ocfg, bank, comm, sids[rank], spos[rank], kv, list(range(nseq)), stps[rank])
             if step == 0:
                 lg = lg[torch.cumsum(torch.tensor(lens[rank]), 0) - 1]
             worst = max(worst, float((lg - ref[step][rank]).abs().max()))

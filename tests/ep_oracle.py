@@ -92,6 +92,43 @@ def rank_step(ocfg, bank, comm, ids, positions, kv, seq_ids: Sequence[int], toke
     return F.linear(M.rmsnorm(h, bank.w["final_norm"], ocfg.rms_eps), bank.w["embed"])
 
 
+def rank_step_a2a(ocfg, bank, comm, ids, positions, kv, seq_ids: Sequence[int], tokens_per_seq: Sequence[int]) -> torch.Tensor:
+    """The same step with the prefill-sized exchange of the HIP runner (I64MoEModel._moe_ep_a2a): plans of all layers from one
+    gather of the ids (ep.build_plans), every (route, token) row sent to the rank that owns its expert and back by variable-split
+    all-to-alls (EPComm.all_to_all_v), the owner running each (route, local expert) bucket over all the rows it received."""
+    from vllm_i64_amd import ep
+    world, rank = comm.world, comm.rank
+    n, top_k = len(ids), ocfg.top_k
+    le = ocfg.num_experts // world
+    ids_all = comm.all_gather(ids)
+    tables = torch.stack([bank.w[f"l{l}.table"] for l in range(ocfg.num_layers)])
+    plans = ep.build_plans(ids_all, tables, [n] * world, rank, ocfg.num_experts)
+    h = F.embedding(ids, bank.w["embed"])
+    w = [ocfg.primary_weight] + [(1.0 - ocfg.primary_weight) / max(1, top_k - 1)] * (top_k - 1)
+    for l in range(ocfg.num_layers):
+        p, plan = f"l{l}.", plans[l]
+        h, x2 = shard_step(ocfg, bank, l, h, positions, kv, seq_ids, tokens_per_seq)
+        send = x2[(plan.perm.long() % max(n, 1))]
+        recv = comm.all_to_all_v(send, plan.send_splits, plan.recv_splits)
+        rows = recv[plan.recv_perm.long()]
+        out_sorted = torch.empty_like(rows)
+        lb = plan.local_bucket.long()
+        for b in lb.unique().tolist():
+            sel = lb == b
+            e = rank * le + b // top_k
+            out_sorted[sel] = bank(p + "exp_down", M.silu_mul(bank(p + "exp_gate_up", rows[sel], idx=e)), idx=e)
+        back = comm.all_to_all_v(out_sorted[plan.recv_inv.long()], plan.recv_splits, plan.send_splits)
+        mine = back[plan.inv.long()].view(top_k, n, -1)
+        out = None
+        for k in range(top_k):
+            out = w[k] * mine[k] if out is None else out + w[k] * mine[k]
+        m = ocfg.routed_scale * out
+        if ocfg.shared_intermediate_size:
+            m = m + ocfg.shared_scale * shared_expert(ocfg, bank, l, x2)
+        h = h + m
+    return F.linear(M.rmsnorm(h, bank.w["final_norm"], ocfg.rms_eps), bank.w["embed"])
+
+
 def make_case(ocfg, world: int, seed: int = 5, big: bool = False, batch: int = 0):
     """Per-rank prompts with the SAME token count on every rank (the exchange has fixed shapes), ragged inside a rank.
     big: enough pooled expert rows (world x 300 tokens x top_k) for the prefill-sized expert path; batch: that many one-token
@@ -99,6 +136,7 @@ def make_case(ocfg, world: int, seed: int = 5, big: bool = False, batch: int = 0
     if batch:
         lens = [[1] * batch for _ in range(world)]
         return lens, [[M.make_token_ids(ocfg, n, seed=seed + 1000 * r + j) for j, n in enumerate(ls)] for r, ls in enumerate(lens)]
-    lens = ([[180, 120], [75, 225], [299, 1], [150, 150]] if big else [[12, 8], [5, 15], [19, 1], [10, 10]])[:world]
+    lens = ([[180, 120], [75, 225], [299, 1], [150, 150], [100, 200], [290, 10], [33, 267], [149, 151]] if big
+            else [[12, 8], [5, 15], [19, 1], [10, 10], [3, 17], [9, 11], [18, 2], [7, 13]])[:world]
     prompts = [[M.make_token_ids(ocfg, n, seed=seed + 10 * r + j) for j, n in enumerate(ls)] for r, ls in enumerate(lens)]
     return lens, prompts

@@ -9,7 +9,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,port", [(2, 29541), (4, 29542)])
+@pytest.mark.parametrize("world,port", [(2, 29541), (4, 29542), (8, 29545)])
 def test_expert_parallel_layer_equals_single_process_oracle(world, port):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
@@ -32,6 +32,22 @@ def test_expert_parallel_whole_model_fixed_shape_exchange(world, port):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
                         "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "ep_model_worker.py"), "cpu"],
                        capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("EP_MODEL_RESULT")][0].split()
+    assert int(line[2]) == world
+    assert float(line[3]) == 0.0, f"expert-parallel logits differ from the single-process statement by {line[3]}"
+
+
+@pytest.mark.parametrize("world,port,exchange", [(2, 29546, "a2a"), (4, 29547, "a2a"), (8, 29548, "a2a"), (8, 29549, "fixed")])
+def test_expert_parallel_whole_model_eight_ranks_and_owner_dispatch(world, port, exchange):
+    """The whole model again: "a2a" - the prefill-sized exchange of the HIP runner (plans of all layers from one gather of the ids,
+    every (route, token) row sent to the rank that owns its expert and back by variable-split all-to-alls) at 2, 4 and 8 ranks;
+    "fixed" - the fixed-shape exchange of the decode-sized steps at 8 ranks (one expert per rank).  Exact against the
+    single-process statement."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", EP_TEST_EXCHANGE=exchange)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "ep_model_worker.py"), "cpu"],
+                       capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("EP_MODEL_RESULT")][0].split()
     assert int(line[2]) == world

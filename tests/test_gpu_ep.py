@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("world,port,force,case", [(2, 29551, "0", "small"), (4, 29552, "0", "small"), (1, 29553, "1", "small"),
-                                                   (2, 29554, "0", "big"), (2, 29555, "0", "real2"), (4, 29556, "0", "real64")])
+                                                   (2, 29554, "0", "big"), (2, 29555, "0", "real2"), (4, 29556, "0", "real64"),
+                                                   (8, 29557, "0", "small"), (4, 29558, "0", "big"), (2, 29559, "0", "big-gathered")])
 def test_expert_parallel_runner_against_single_process_oracle(world, port, force, case):
     """Prefill (ragged prompts, equal token count per rank) and two greedy decode steps.  Bound: the quantization-noise scale
     of the model tests (a flipped 7-bit activation LSB moves a logit by ~1e-2); greedy tokens identical.  world 1 with forced
@@ -21,10 +22,15 @@ def test_expert_parallel_runner_against_single_process_oracle(world, port, force
     rank, i.e. 1200 pooled expert rows in the prefill step (the separately quantized, prefill-sized expert path); "real2": a
     two-layer cut of the benchmark model at its real dimensions (four local experts per rank); "real64": the same cut with the
     benchmark's 64 sequences per rank on 4 ranks - 512 pooled expert rows in every step (the fused expert launches between 257
-    and 1024 pooled rows)."""
+    and 1024 pooled rows).  8 ranks "small": one expert per rank, the node's rank count, eight processes on the one card.  The
+    prefill step of "big" (1200 / 2400 pooled rows) takes the owner-dispatch form - every (route, token) row travels to the rank of its
+    expert and back by variable-split all-to-alls, plans from the gathered ids; "big-gathered" forces the all-gather form of the
+    decode-sized steps onto that prefill as well."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="8" if case == "real64" else "2", I64H_EP_FORCE_COLLECTIVES=force)
+    if case == "big-gathered":
+        case, env["I64H_EP_A2A_PREFILL"] = "big", "0"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
                         "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "ep_model_worker.py"), "gpu", case],
                        capture_output=True, text=True, env=env, timeout=170)

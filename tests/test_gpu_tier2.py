@@ -26,6 +26,9 @@ def setup():
     return cfg, w
 
 
+_ORACLE_RUNS = {}   # kv dtype -> the oracle's logits per step (the fp32-cache run is the reference's own configuration)
+
+
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("kv", ["fp32", "bf16"])
 def test_full_model_logits_inside_the_reference_noise_band(setup, golden_dir, kv):
@@ -39,8 +42,13 @@ def test_full_model_logits_inside_the_reference_noise_band(setup, golden_dir, kv
     prompts = [ids[i * plen:(i + 1) * plen] for i in range(nseq)]
     kv_dtype = torch.float32 if kv == "fp32" else torch.bfloat16
     torch.set_num_threads(min(16, os.cpu_count() or 1))
-    eng = M.OracleEngine(ocfg, w, mode="int8_torch", max_seqs=nseq, num_blocks=64, kv_dtype=kv_dtype)
-    ref = [eng.prefill(prompts).numpy()] + [eng.decode(torch.from_numpy(t)).numpy() for t in toks[:-1]]
+    def oracle_run(dt):
+        key = str(dt)
+        if key not in _ORACLE_RUNS:
+            eng = M.OracleEngine(ocfg, w, mode="int8_torch", max_seqs=nseq, num_blocks=64, kv_dtype=dt)
+            _ORACLE_RUNS[key] = [eng.prefill(prompts).numpy()] + [eng.decode(torch.from_numpy(t)).numpy() for t in toks[:-1]]
+        return _ORACLE_RUNS[key]
+    ref = oracle_run(kv_dtype)
     if kv == "fp32":                         # the oracle with the reference's cache dtype is the reference (0.0 when captured)
         assert all(np.array_equal(r.argmax(-1), t) for r, t in zip(ref, z["ref_top1"]))
     dev = torch.device("cuda:0")
@@ -56,6 +64,16 @@ def test_full_model_logits_inside_the_reference_noise_band(setup, golden_dir, kv
     print(f"\n[tier 2, KV {kv}] GPU vs oracle per step: max {np.round(d_max, 3)} mean {np.round(d_mean, 4)} greedy agreement {agree}")
     print(f"[tier 2] reference vs itself at eps=1e-7 : max {np.round(z['pert_max'], 3)} mean {np.round(z['pert_mean'], 4)} "
           f"greedy agreement {z['pert_agree']}  (logit absmax {np.round(z['logit_absmax'].max(), 2)})")
+    if kv == "bf16":
+        # the benchmark's configuration (bf16 cache) against the REFERENCE's configuration: its CPU engine keeps the cache in the
+        # model's dtype, fp32 (vllm_i64/engine/i64_engine.py:243); the oracle with that cache reproduces the reference at 0.0
+        ref32 = oracle_run(torch.float32)
+        r_max = np.array([np.abs(a - b).max() for a, b in zip(out, ref32)])
+        r_mean = np.array([np.abs(a - b).mean() for a, b in zip(out, ref32)])
+        r_agree = np.array([(a.argmax(-1) == b.argmax(-1)).mean() for a, b in zip(out, ref32)])
+        print(f"[tier 2, KV bf16] GPU vs the oracle with the reference's fp32 cache: max {np.round(r_max, 3)} mean {np.round(r_mean, 4)} "
+              f"greedy agreement {r_agree}")
+        assert r_max.max() <= 2.0 * z["pert_max"].max() and r_mean.max() <= 2.0 * z["pert_mean"].max()
     # inside the band the reference moves in against itself (the band's own run-to-run spread is about 1.5x)
     assert d_max.max() <= 2.0 * z["pert_max"].max(), (d_max, z["pert_max"])
     assert d_mean.max() <= 2.0 * z["pert_mean"].max(), (d_mean, z["pert_mean"])

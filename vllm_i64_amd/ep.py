@@ -383,6 +383,25 @@ class EPComm:
         return recv
 
 
+    def all_to_all_v(self, send: torch.Tensor, send_splits: Sequence[int], recv_splits: Sequence[int]) -> torch.Tensor:
+        """Variable-split all-to-all of rows (the dispatch / combine of the reference's expert-parallel layer,
+        vllm_i64/layers/token_routed_i64/layer.py:253-259, 286-292): rows [sum(send_splits), ...] grouped by destination rank ->
+        rows [sum(recv_splits), ...] grouped by source rank.  The splits are host integers (prefill-sized steps, which are not
+        captured into a graph, derive them once per step from the gathered token ids: build_plans)."""
+        recv = send.new_empty((int(sum(recv_splits)),) + tuple(send.shape[1:]))
+        if not self.active:
+            recv.copy_(send)
+            return recv
+        send = send.contiguous()
+        if self.direct or not send.is_cuda:
+            dist.all_to_all_single(recv, send, output_split_sizes=list(recv_splits), input_split_sizes=list(send_splits), group=self.group)
+        else:
+            host = torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_to_all_single(host, send.cpu(), output_split_sizes=list(recv_splits), input_split_sizes=list(send_splits), group=self.group)
+            recv.copy_(host)
+        return recv
+
+
 def exchange_row_map(perm: torch.Tensor, n: int, world: int, top_k: int) -> torch.Tensor:
     """perm[..., j] = k * (world * n) + t, the global (route, token) source row of bucket-ordered row j (i64h_moe_plan over the
     gathered ids) -> the row of the exchange buffer [world, top_k * n, H] it belongs to: rank d = t // n owns token t, and

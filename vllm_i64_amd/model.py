@@ -263,7 +263,10 @@ class I64MoEModel:
     def buffers(self, n: int, n_logit_rows: int) -> _Buffers:
         key = (n, n_logit_rows)
         if key not in self._bufs:
-            self._bufs[key] = _Buffers(self.cfg, n, n_logit_rows, self.device, ep_world=self.ep.world if self.ep is not None else 0)
+            ep_world = self.ep.world if self.ep is not None else 0
+            if ep_world and self.EP_A2A_PREFILL and n * ep_world * self.cfg.top_k > self.EP_FUSE_MAX_ROWS:
+                ep_world = 0   # prefill-sized step of the expert-parallel runner: rows travel by all-to-all, no pooled buffers
+            self._bufs[key] = _Buffers(self.cfg, n, n_logit_rows, self.device, ep_world=ep_world)
         return self._bufs[key]
 
     # e4m3 runner, prefill chunks: residual + norm + per-token quantization in one pass.  Off by default: the pass itself is faster
@@ -308,6 +311,10 @@ class I64MoEModel:
     FUSE_DECODE_QKV_NORM = os.environ.get("I64H_FUSE_DECODE_QKV_NORM", "1") != "0"
     FUSE_MAX_ROWS = 256  # up to this many operand rows the quantizer runs inside the GEMM (one launch per Linear call)
     EP_FUSE_MAX_ROWS = 1024  # the same for the pooled expert rows of the expert-parallel runner (8 ranks x 64 sequences x top-2)
+    # expert-parallel runner, steps with more pooled expert rows than that (prefill chunks): dispatch every (route, token) row to the
+    # rank that owns its expert and return the result by variable-split all-to-alls (each rank quantizes and multiplies only the rows of
+    # its own experts); "0" keeps the fixed-shape all-gather form of the decode-sized steps for every step
+    EP_A2A_PREFILL = os.environ.get("I64H_EP_A2A_PREFILL", "1") != "0"
     fuse_qkr = True   # decode-sized steps: QK norm / RoPE / cache write inside the qkv GEMM
     # decode attention: at most this many splits per row.  The row's last-arriving workgroup merges the splits, and in-kernel stamps
     # (tools/attn_stamps.py) put that merge at 4-6 k cycles up to 8 splits but 17 k at 16 and 34 k at 32 (the partial rows come
@@ -455,12 +462,20 @@ class I64MoEModel:
         eps = cfg.rms_eps
         fuse_rows = n <= self.FUSE_MAX_ROWS
         rw = cfg.route_weights
+        ep_plans = None
         if self.ep is not None:
             # the routing is a pure function of the token id: every rank gathers every rank's ids once per step and derives the
-            # same global plan on the device (no count exchange, nothing returns to the host)
-            B.plan.run(self.ep.all_gather(token_ids), self.tables)
-            B.row_map = self._ep.exchange_row_map(B.plan.perm, n, self.ep.world, cfg.top_k)
-            B.recv_map = self._ep.owner_row_map(B.plan.keys, n, self.ep.rank, self.ep.world, cfg.top_k, self.ep_le)
+            # same global plan on the device (no count exchange)
+            ids_all = self.ep.all_gather(token_ids)
+            if self.EP_A2A_PREFILL and n * self.ep.world * cfg.top_k > self.EP_FUSE_MAX_ROWS:
+                # prefill-sized step: every (route, token) row travels to the one rank that owns its expert and back (one
+                # variable-split all-to-all each way per layer); the split sizes of all layers come to the host in ONE transfer
+                ep_plans = self._ep.build_plans(ids_all, self.tables, [n] * self.ep.world, self.ep.rank, cfg.num_experts)
+            else:
+                # decode-sized step: fixed shapes, nothing returns to the host (the step replays as one HIP graph)
+                B.plan.run(ids_all, self.tables)
+                B.row_map = self._ep.exchange_row_map(B.plan.perm, n, self.ep.world, cfg.top_k)
+                B.recv_map = self._ep.owner_row_map(B.plan.keys, n, self.ep.rank, self.ep.world, cfg.top_k, self.ep_le)
         elif cfg.is_moe:
             B.plan.run(token_ids, self.tables)
         ops.embedding(token_ids, self.embed, out=B.h, reset_stats=st)  # + the reset of the step's stat slots
@@ -561,7 +576,9 @@ class I64MoEModel:
             if cfg.is_moe:
                 if record is not None:
                     record[f"l{l}.mlp_in"] = B.normed.clone()
-                if self.ep is not None:
+                if ep_plans is not None:
+                    moe_rows, moe_inv = self._moe_ep_a2a(B, W, l, base, ep_plans[l])
+                elif self.ep is not None:
                     moe_rows, moe_inv = self._moe_ep(B, W, l, base)
                 else:
                     moe_rows, moe_inv = B.e_out, self._moe(B, W, l, base, prequantized=fq)
@@ -881,6 +898,40 @@ class I64MoEModel:
             ops.gemm_i8_pair(ops.gemm_desc(B.eia, W["exp_dn"].w_q, W["exp_dn"].w_s, out_buf, row_scale=B.eis, group_offsets=eo, m_total=R,
                                            c_row_map=c_map))
         return ep.exchange(B.xsend, recv=B.xrecv).view(-1, H), B.recv_map[l]
+
+    def _moe_ep_a2a(self, B: _Buffers, W: dict, l: int, base: int, plan) -> tuple:
+        """Expert-parallel MoE layer of a prefill-sized step in the reference's own shape (dispatch and combine by variable-split
+        all-to-all, vllm_i64/layers/token_routed_i64/layer.py:227-292) with the plan derived from the gathered token ids instead of
+        a count exchange (ep.build_plans).  This rank's (route, token) rows in bucket order are already grouped by owning rank: one
+        gather builds the send buffer; the owner sorts what it receives into (route, local expert) bucket order, so that each bucket
+        call sees ALL of its rows and its activation range is exact without a statistics exchange, runs its experts over them and
+        sends every result row back to where its input came from.  Only the rows of a rank's own experts are quantized and
+        multiplied there.  The shared expert is a call of this rank's engine on its own tokens.  Returns (rows, map) for the combine."""
+        cfg, st, nbk, ep, spl = self.cfg, self.stats, self.nb, self.ep, self.spl
+        n, H = B.h.shape[0], cfg.hidden_size
+        x = B.normed
+        src_tok = (plan.perm.to(torch.int64) % max(n, 1)).to(torch.int32)
+        recv = ep.all_to_all_v(ops.gather_rows(x, src_tok), plan.send_splits, plan.recv_splits)
+        if cfg.shared_intermediate_size:
+            self._linear(x, W["sh_gu"], base + spl - 1, B.xa, B.xs, B.sh_inter, epilogue=ops.EPI_SWIGLU, stats_slot=base + 3 + nbk)
+            self._linear(B.sh_inter, W["sh_dn"], base + 3 + nbk, B.sha, B.shs, B.sh_out)
+        R = recv.shape[0]
+        if R == 0:
+            e_back = recv
+        else:
+            rows = ops.gather_rows(recv, plan.recv_perm)                     # (route, local expert) bucket order
+            sb_in, sb_mid = base + 3 + self.ep_e0 * cfg.top_k, base + 4 + nbk + self.ep_e0 * cfg.top_k   # this rank's buckets' slots
+            ops.rows_minmax(rows, st, slots=plan.local_bucket, slot_base=sb_in)
+            a, a_s = ops.quantize_dynamic(rows, st, slot_base=sb_in, row_slot=plan.local_bucket)
+            inter = torch.empty(R, cfg.expert_inter, dtype=torch.float32, device=x.device)
+            self._gemm_i8(a, a_s, W["exp_gu"], inter, group_offsets=plan.expert_offsets, epilogue=ops.EPI_SWIGLU, row_slot=plan.local_bucket,
+                          slot_base=sb_mid, stats=st)
+            a2, a2_s = ops.quantize_dynamic(inter, st, slot_base=sb_mid, row_slot=plan.local_bucket)
+            e_sorted = torch.empty(R, H, dtype=torch.float32, device=x.device)
+            self._gemm_i8(a2, a2_s, W["exp_dn"], e_sorted, group_offsets=plan.expert_offsets)
+            e_back = ops.gather_rows(e_sorted, plan.recv_inv)                # back into received order
+        back = ep.all_to_all_v(e_back, plan.recv_splits, plan.send_splits)   # this rank's rows, in its bucket order
+        return back, plan.inv
 
     # ---- stand-alone MoE layer (operator form of TokenRoutedMLP.forward) ----
     def moe_layer(self, l: int, x: torch.Tensor, token_ids: torch.Tensor) -> torch.Tensor:
