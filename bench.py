@@ -178,8 +178,9 @@ def main():
                                    f"batch {B} per GPU, {P}-token prompts{' (synthetic KV)' if args.synthetic_kv else ' (real prefill)'} + greedy "
                                    f"decode, KV cache {args.kv_dtype}",
                        "global_batch": B * world, "seq_len": P,
-                       "parallelism": (f"ep{world} (experts sharded over the ranks; per MoE layer one all-gather of the input rows and one "
-                                       f"equal-split all-to-all of the expert rows, RCCL)" if ep_mode else
+                       "parallelism": (f"ep{world} (experts sharded over the ranks, RCCL; decode steps: per MoE layer one all-gather of the "
+                                       f"input rows and one equal-split all-to-all of the expert rows inside the step's graph; prefill chunks: "
+                                       f"each (route, token) row to its expert's rank and back by variable-split all-to-alls)" if ep_mode else
                                        f"dp{world} (independent replicas, no collective)" if world > 1 else "single GPU"),
                        "kv_dtype": args.kv_dtype, "hip_graph": used_graph,
                        "prompt_ids": f"zipf({args.zipf})" if args.zipf > 0 else "uniform"},

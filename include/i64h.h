@@ -220,6 +220,13 @@ int i64h_gemm_f32(const float* A, const int32_t* a_rows, const float* B, float* 
 int i64h_gemm_f32_grouped(const float* A, const int32_t* a_src_row, const void* B, int32_t b_int8, const float* b_row_scale,
                           const int32_t* group_offsets, int32_t num_groups, int64_t M, int32_t N, int32_t K, float* C,
                           const int32_t* c_row_map, int32_t epilogue, void* stream);
+/* The same grouped contraction with fp16 (dtype 1) or bf16 (dtype 2) operands and output, as the reference's fp16 expert path holds
+ * them (csrc/i64_expert_dispatch.cu:144-233: cublasHgemm on half operands; vllm_i64/kernels/fused_experts.py:65-150): A [*, K],
+ * B [E][K][N] and C in that type - consumed in place, no fp32 copies -, fp32 accumulation on v_mfma_f32_16x16x32_{f16,bf16}, the
+ * SwiGLU epilogue evaluated in fp32 and rounded once. */
+int i64h_gemm_h16_grouped(const void* A, const int32_t* a_src_row, const void* B, int32_t dtype, const int32_t* group_offsets,
+                          int32_t num_groups, int64_t M, int32_t N, int32_t K, void* C, const int32_t* c_row_map, int32_t epilogue,
+                          void* stream);
 /* fp32 activations x int8 weights with per-output-channel scale: I64_gemm_dequant_int8 / I64_gemm_silu_int8
  * (csrc/I64_gemm.cu:40-126). */
 int i64h_gemm_w8a32(const float* x, const int8_t* w, const float* w_scale, float* out, int64_t M, int32_t N, int32_t K, void* stream);

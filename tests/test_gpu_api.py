@@ -118,6 +118,41 @@ def test_grouped_float_expert_mlp_odd_shapes_and_empty_experts(dev, N, H, I, E):
     torch.testing.assert_close(out8.cpu().double(), ref_of(gq.float() * gs[..., None], dq.float() * ds[..., None]), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("N,H,I,E", [(300, 72, 50, 5), (1, 64, 48, 4), (1000, 128, 33, 16), (130, 30, 7, 3), (513, 1024, 448, 8)])
+def test_grouped_expert_mlp_on_16_bit_operands(dev, dtype, N, H, I, E):
+    """fp16 / bf16 activations and weights go to the 16-bit matrix cores as they are (no fp32 copies; the SwiGLU intermediate and the
+    output are 16-bit too): odd sizes, an empty expert, several row tiles per expert and the benchmark model's expert shape.
+    Reference: the per-expert loop in float64 on the 16-bit operand VALUES with the intermediate rounded to the operand type, as the
+    kernel stores it; the bound is a few units of the type's last place on the output's scale."""
+    from vllm_i64_amd import kernels as K
+    g = torch.Generator().manual_seed(N + H)
+    x = torch.randn(N, H, generator=g).to(dtype)
+    gu = (torch.randn(E, H, 2 * I, generator=g) * 0.1).to(dtype)
+    dn = (torch.randn(E, I, H, generator=g) * 0.1).to(dtype)
+    eid = torch.randint(0, E, (N,), generator=g)
+    eid[eid == 1] = 0
+    ref = torch.zeros(N, H, dtype=torch.float64)
+    for e in range(E):
+        m = eid == e
+        t = x[m].double() @ gu[e].double()
+        inter = (torch.nn.functional.silu(t[:, :I]) * t[:, I:]).to(dtype).double()
+        ref[m] = inter @ dn[e].double()
+    out = K.fused_token_routed_forward(x.to(dev), gu.to(dev), dn.to(dev), eid.to(dev), E, I)
+    assert out.dtype == dtype
+    ulp = 2.0 ** (-10 if dtype == torch.float16 else -7)
+    err = (out.cpu().double() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    print(f"{dtype} N={N} H={H} I={I}: max error {err:.3e} on outputs up to {scale:.3f}")
+    assert err <= 2.0 * ulp * max(scale, 1e-3)
+    # rows already grouped by expert (i64_expert_forward): same kernels, offsets and counts from the device
+    order = torch.sort(eid, stable=True).indices
+    counts = torch.bincount(eid, minlength=E).to(torch.int32)
+    offs = (torch.cumsum(counts, 0) - counts).to(torch.int32)
+    out2 = K.i64_expert_forward(x[order].to(dev), gu.to(dev), dn.to(dev), offs.to(dev), counts.to(dev), E)
+    assert out2.dtype == dtype and torch.equal(out2.cpu(), out.cpu()[order])
+
+
 def test_grouped_float_expert_mlp_never_reads_back_to_the_host(dev):
     """The whole operator (grouping + two launches) is captured into a HIP graph: any device-to-host read would fail the
     capture.  Replayed on new inputs of the same shape it gives the new answer."""

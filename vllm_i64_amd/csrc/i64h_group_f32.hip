@@ -172,7 +172,179 @@ __global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(const float* __re
         }
 }
 
+// ---- the same contraction for fp16 / bf16 operands on v_mfma_f32_16x16x32_{f16,bf16} ------------------------------------------------
+// A [*, K], W [E][K][N] and C in the 16-bit type the caller holds (no fp32 copies of the operands), fp32 accumulation, SwiGLU in
+// fp32, one rounding on the way out.  The matrix core wants 8 consecutive k per lane for both operands; the weights are stored
+// [K][N] with N contiguous, so the weight tile is transposed while it is staged ([column][k] in LDS) and both operand fragments are
+// single 16-byte LDS reads.  Tile 64 x 64 (EPI: 32 gate columns + their 32 up partners), K steps of 32, 4 waves (2 x 2).
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef __bf16 v8b __attribute__((ext_vector_type(8)));
+#define GH_LD 40  // LDS row stride in elements: 80 bytes, 16-byte aligned, rows spread over the banks
+
+template <int BF> __device__ __forceinline__ uint16_t gh_from_f32(float v) {
+    if (BF) {  // round to nearest even (finite values; NaN stays NaN through the quiet bit)
+        uint32_t u = __float_as_uint(v);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (uint16_t)(u >> 16);
+    }
+    const _Float16 h = (_Float16)v;
+    return __builtin_bit_cast(uint16_t, h);
+}
+
+template <int EPI, int BF>
+__global__ __launch_bounds__(256) void gemm_h16_grouped_kernel(const uint16_t* __restrict__ A, const int32_t* __restrict__ a_src_row,
+                                                               const uint16_t* __restrict__ Bw, const int32_t* __restrict__ group_off, int G,
+                                                               int M, int N, int K, uint16_t* __restrict__ C,
+                                                               const int32_t* __restrict__ c_row_map) {
+    __shared__ __attribute__((aligned(16))) uint16_t sA[2][GF_BM][GH_LD];
+    __shared__ __attribute__((aligned(16))) uint16_t sB[2][GF_BN][GH_LD];  // [tile column][k]
+    __shared__ int s_info[4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1, fr = lane & 15, fq = lane >> 4;
+    const int I = N / 2;
+    const int n_tiles = EPI ? (I + GF_BN / 2 - 1) / (GF_BN / 2) : (N + GF_BN - 1) / GF_BN;
+    const int mt = blockIdx.x / n_tiles, nt = blockIdx.x % n_tiles;
+    if (tid == 0) {
+        int g = -1, row0 = 0, rows = 0, base = 0;
+        const int ng = group_off ? G : 1;
+        for (int i = 0; i < ng; ++i) {
+            const int b = group_off ? group_off[i] : 0, e = group_off ? group_off[i + 1] : M;
+            const int tiles = (e - b + GF_BM - 1) / GF_BM;
+            if (mt < base + tiles) { g = i; row0 = b + (mt - base) * GF_BM; rows = min(GF_BM, e - row0); break; }
+            base += tiles;
+        }
+        s_info[0] = g; s_info[1] = row0; s_info[2] = rows;
+    }
+    __syncthreads();
+    const int g = s_info[0], row0 = s_info[1], rows = s_info[2];
+    if (g < 0) return;
+    const uint16_t* Bg = Bw + (int64_t)g * K * N;
+    // staging of A: thread -> 8 consecutive k of tile row ar
+    const int ar = tid >> 2, ak = (tid & 3) * 8;
+    const bool aok = ar < rows;
+    const uint16_t* ap = A + (int64_t)(aok ? (a_src_row ? a_src_row[row0 + ar] : row0 + ar) : 0) * K + ak;
+    // staging of B: thread -> 8 consecutive tile columns bc of k row bk; tile column -> weight column
+    const int bk = tid >> 3, bc = (tid & 7) * 8;
+    int bcol, blim;
+    if (EPI) {
+        const int j = nt * (GF_BN / 2) + (bc >> 5) * 16 + (bc & 15);
+        const bool up = (bc >> 4) & 1;
+        bcol = up ? I + j : j;
+        blim = up ? N : I;
+        if (j >= I) blim = 0;  // past the last output: nothing valid
+    } else {
+        bcol = nt * GF_BN + bc;
+        blim = N;
+    }
+    const bool vec_a = (K % 8 == 0) && ((uintptr_t)A % 16 == 0);
+    const bool vec_b = (N % 8 == 0) && (!EPI || I % 8 == 0) && ((uintptr_t)Bw % 16 == 0);
+    uint4 ra, rb;
+    auto gload = [&](int k0) {
+        const int ka = k0 + ak;
+        if (aok && vec_a && ka + 7 < K) {
+            ra = *(const uint4*)(ap + k0);
+        } else {
+            uint16_t t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = (aok && ka + e < K) ? ap[k0 + e] : (uint16_t)0;
+            ra = make_uint4(t[0] | ((uint32_t)t[1] << 16), t[2] | ((uint32_t)t[3] << 16), t[4] | ((uint32_t)t[5] << 16), t[6] | ((uint32_t)t[7] << 16));
+        }
+        const int kb = k0 + bk;
+        const bool kin = kb < K;
+        const uint16_t* p = Bg + (int64_t)(kin ? kb : 0) * N + bcol;
+        if (kin && vec_b && bcol + 7 < blim) {
+            rb = *(const uint4*)p;
+        } else {
+            uint16_t t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = (kin && bcol + e < blim) ? p[e] : (uint16_t)0;
+            rb = make_uint4(t[0] | ((uint32_t)t[1] << 16), t[2] | ((uint32_t)t[3] << 16), t[4] | ((uint32_t)t[5] << 16), t[6] | ((uint32_t)t[7] << 16));
+        }
+    };
+    auto lstore = [&](int buf) {
+        *(uint4*)&sA[buf][ar][ak] = ra;
+        const uint32_t w[4] = {rb.x, rb.y, rb.z, rb.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sB[buf][bc + e][bk] = (uint16_t)(w[e >> 1] >> ((e & 1) * 16));
+    };
+    v4f acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+    const int KT = (K + GF_BK - 1) / GF_BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < KT) gload((kt + 1) * GF_BK);
+        uint4 a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = *(const uint4*)&sA[cur][wm * 32 + i * 16 + fr][fq * 8];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = *(const uint4*)&sB[cur][wn * 32 + j * 16 + fr][fq * 8];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (BF) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(v8b, a[i]), __builtin_bit_cast(v8b, b[j]), acc[i][j], 0, 0, 0);
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(v8h, a[i]), __builtin_bit_cast(v8h, b[j]), acc[i][j], 0, 0, 0);
+            }
+        if (kt + 1 < KT) lstore(cur ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int r = wm * 32 + i * 16 + fq * 4 + reg;
+            if (r >= rows) continue;
+            const int64_t crow = c_row_map ? c_row_map[row0 + r] : row0 + r;
+            if (EPI) {
+                const int c = nt * (GF_BN / 2) + wn * 16 + fr;
+                if (c < I) {
+                    const float gate = acc[i][0][reg], up = acc[i][1][reg];
+                    C[crow * I + c] = gh_from_f32<BF>((gate / (1.0f + expf(-gate))) * up);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int c = nt * GF_BN + wn * 32 + j * 16 + fr;
+                    if (c < N) C[crow * N + c] = gh_from_f32<BF>(acc[i][j][reg]);
+                }
+            }
+        }
+}
+
 extern "C" {
+
+// fp16 (dtype 1) / bf16 (dtype 2) operands and output, fp32 accumulation on the 16-bit matrix cores; arguments as
+// i64h_gemm_f32_grouped without the weight-only int8 form.
+int i64h_gemm_h16_grouped(const void* A, const int32_t* a_src_row, const void* B, int32_t dtype, const int32_t* group_offsets,
+                          int32_t num_groups, int64_t M, int32_t N, int32_t K, void* C, const int32_t* c_row_map, int32_t epilogue,
+                          void* stream) {
+    I64H_CHECK_ARG(M >= 0 && M < (1ll << 31) && N > 0 && K > 0, "gemm_h16_grouped: bad sizes");
+    I64H_CHECK_ARG(num_groups >= 1 && num_groups <= 4096 && (group_offsets != nullptr || num_groups == 1), "gemm_h16_grouped: bad grouping");
+    I64H_CHECK_ARG(epilogue == 0 || (epilogue == 1 && N % 2 == 0), "gemm_h16_grouped: bad epilogue %d / N=%d", epilogue, N);
+    I64H_CHECK_ARG(dtype == 1 || dtype == 2, "gemm_h16_grouped: dtype must be 1 (fp16) or 2 (bf16)");
+    I64H_CHECK_ARG(((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) % 2 == 0, "gemm_h16_grouped: misaligned operand");
+    if (M == 0) return 0;
+    const int G = group_offsets ? num_groups : 1;
+    const int n_tiles = epilogue ? (N / 2 + GF_BN / 2 - 1) / (GF_BN / 2) : (N + GF_BN - 1) / GF_BN;
+    const int64_t m_tiles = (M + GF_BM - 1) / GF_BM + G;
+    I64H_CHECK_ARG(m_tiles * n_tiles < (1ll << 31), "gemm_h16_grouped: grid too large");
+    const dim3 grid((unsigned)(m_tiles * n_tiles));
+    hipStream_t st = (hipStream_t)stream;
+#define GH_LAUNCH(E, T) hipLaunchKernelGGL((gemm_h16_grouped_kernel<E, T>), grid, dim3(256), 0, st, (const uint16_t*)A, a_src_row, (const uint16_t*)B, \
+                                           group_offsets, G, (int)M, N, K, (uint16_t*)C, c_row_map)
+    if (epilogue) { if (dtype == 2) GH_LAUNCH(1, 1); else GH_LAUNCH(1, 0); }
+    else { if (dtype == 2) GH_LAUNCH(0, 1); else GH_LAUNCH(0, 0); }
+#undef GH_LAUNCH
+    I64H_CHECK_LAUNCH();
+    return 0;
+}
 
 int i64h_gemm_f32_grouped(const float* A, const int32_t* a_src_row, const void* B, int32_t b_int8, const float* b_row_scale,
                           const int32_t* group_offsets, int32_t num_groups, int64_t M, int32_t N, int32_t K, float* C,

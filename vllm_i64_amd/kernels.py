@@ -208,6 +208,30 @@ def _grouped_f32(a: torch.Tensor, w: torch.Tensor, offsets: torch.Tensor, out: t
     return out
 
 
+_H16 = {torch.float16: 1, torch.bfloat16: 2}
+
+
+def _native_h16(x, *weights) -> bool:
+    """fp16 / bf16 activations with weights of the same type: the 16-bit matrix cores take them as they are."""
+    return x.dtype in _H16 and all(w.dtype == x.dtype for w in weights)
+
+
+def _expert_mlp_grouped_h16(x, gate_up, down, offsets, perm, inter_size, scatter_back=True):
+    """The two grouped launches on fp16 / bf16 operands (i64h_gemm_h16_grouped): nothing is converted or copied, the SwiGLU
+    intermediate and the output are in the operands' type."""
+    n = perm.numel() if perm is not None else x.shape[0]
+    assert gate_up.shape[2] == 2 * inter_size and down.shape[1] == inter_size
+    code = _H16[x.dtype]
+    E, K, N = gate_up.shape
+    inter = torch.empty(n, inter_size, dtype=x.dtype, device=x.device)
+    ops.call("i64h_gemm_h16_grouped", ops.ptr(x), ops.ptr(perm), ops.ptr(gate_up), code, ops.ptr(offsets), E, n, N, K, ops.ptr(inter), 0, 1,
+             ops._stream())
+    out = torch.empty(n, down.shape[2], dtype=x.dtype, device=x.device)
+    ops.call("i64h_gemm_h16_grouped", ops.ptr(inter), 0, ops.ptr(down), code, ops.ptr(offsets), E, n, down.shape[2], down.shape[1], ops.ptr(out),
+             ops.ptr(perm if scatter_back else None), 0, ops._stream())
+    return out
+
+
 def _expert_mlp_grouped(xf, gate_up, down, offsets, perm, inter_size, gu_scale=None, dn_scale=None, scatter_back=True):
     n = perm.numel() if perm is not None else xf.shape[0]
     assert gate_up.shape[2] == 2 * inter_size and down.shape[1] == inter_size
@@ -220,13 +244,16 @@ def _expert_mlp_grouped(xf, gate_up, down, offsets, perm, inter_size, gu_scale=N
 def fused_token_routed_forward(x: torch.Tensor, gate_up_proj: torch.Tensor, down_proj: torch.Tensor, expert_ids: torch.Tensor,
                                num_experts: int, intermediate_per_tp: int, bmm_threshold: int = 64) -> torch.Tensor:
     """Float expert MLP grouped by expert (fused_experts.py:29-150): x [N,H], gate_up_proj [E,H,2I], down_proj [E,I,H],
-    expert_ids long [N].  fp32 math on the f32 matrix cores: one stable grouping on the device, then TWO launches for all
-    experts - the gather into expert order rides in the first (with the SwiGLU), the scatter back in the second.  Nothing is
-    read back to the host; the weights are used in the layout they arrive in."""
+    expert_ids long [N].  One stable grouping on the device, then TWO launches for all experts - the gather into expert order
+    rides in the first (with the SwiGLU), the scatter back in the second.  Nothing is read back to the host; the weights are used
+    in the layout they arrive in.  fp16 / bf16 operands (activations and weights of one type) run on the 16-bit matrix cores as they
+    are, fp32 accumulation; anything else is computed in fp32 on the f32 matrix cores."""
     n = x.shape[0]
     if n == 0:
         return x
     offsets, perm, _, _ = ops.bucketize(expert_ids.to(torch.int32).contiguous(), num_experts)
+    if _native_h16(x, gate_up_proj, down_proj):   # fp16 / bf16 end to end on the 16-bit matrix cores, weights used where they lie
+        return _expert_mlp_grouped_h16(x.contiguous(), gate_up_proj.contiguous(), down_proj.contiguous(), offsets, perm, intermediate_per_tp)
     out = _expert_mlp_grouped(_f32(x), _f32(gate_up_proj), _f32(down_proj), offsets, perm, intermediate_per_tp)
     return out.to(x.dtype)
 
@@ -303,6 +330,16 @@ def i64_expert_forward(scattered: torch.Tensor, gate_up_weights: torch.Tensor, d
     start = expert_offsets.to(torch.int32).reshape(-1)[:num_experts]
     off = torch.cat([start, (start[-1:] + expert_counts.to(torch.int32).reshape(-1)[num_experts - 1:num_experts])]).contiguous()
     ei = down_weights.shape[1]
+    if _native_h16(scattered, gate_up_weights, down_weights):   # the reference's own operand type (half): 16-bit matrix cores, no copies
+        code, E = _H16[scattered.dtype], gate_up_weights.shape[0]
+        x, gu, dn = scattered.contiguous(), gate_up_weights.contiguous(), down_weights.contiguous()
+        inter = torch.zeros(n, ei, dtype=x.dtype, device=x.device)
+        ops.call("i64h_gemm_h16_grouped", ops.ptr(x), 0, ops.ptr(gu), code, ops.ptr(off), E, n, gu.shape[2], gu.shape[1], ops.ptr(inter), 0, 1,
+                 ops._stream())
+        out = torch.zeros(n, dn.shape[2], dtype=x.dtype, device=x.device)
+        ops.call("i64h_gemm_h16_grouped", ops.ptr(inter), 0, ops.ptr(dn), code, ops.ptr(off), E, n, dn.shape[2], dn.shape[1], ops.ptr(out), 0, 0,
+                 ops._stream())
+        return out
     inter = torch.zeros(n, ei, dtype=torch.float32, device=scattered.device)
     _grouped_f32(_f32(scattered), _f32(gate_up_weights), off, inter, swiglu=True)
     out = torch.zeros(n, down_weights.shape[2], dtype=torch.float32, device=scattered.device)
