@@ -210,6 +210,13 @@ int i64h_set_skinny_waves(int32_t waves); /* tuning knob of the decode-sized (we
 int i64h_set_skinny_helpers(int32_t on);  /* tuning knob of the same kernel: 1 (default) = its four-wave workgroups get four more waves that only request and quantize operand rows */
 /* C[M, N] = A[a_rows ? a_rows[m] : m, :K] . B[N, K]^T in fp32 (tied lm_head, vllm_i64/models/complexity_deep/model.py:436-437). */
 int i64h_gemm_f32(const float* A, const int32_t* a_rows, const float* B, float* C, int64_t M, int32_t N, int32_t K, void* stream);
+/* The tied fp32 lm_head (F.linear(hidden.float(), embed.weight.float()), vllm_i64/models/complexity_deep/model.py:436-437) on the
+ * bf16 matrix cores: every fp32 operand value is cut into three bf16 terms that sum to it exactly, and six of the nine partial
+ * products (all whose weight is at least 2^-16 of the leading one) are accumulated in fp32 - the dropped ones are below the
+ * rounding of one fp32 multiply.  Same arguments as i64h_gemm_f32 plus a workspace of i64h_lm_head_workspace_bytes(M, K) bytes
+ * (16-byte aligned) for the activation rows' three planes.  K % 32 == 0. */
+int64_t i64h_lm_head_workspace_bytes(int64_t M, int32_t K);
+int i64h_lm_head(const float* A, const int32_t* a_rows, const float* B, float* C, int64_t M, int32_t N, int32_t K, void* workspace, void* stream);
 /* Grouped float expert contraction in one launch: C[r, :] = A[a_src_row ? a_src_row[r] : r, :K] @ B[g][:K, :N] for the rows
  * r in [group_offsets[g], group_offsets[g + 1]) (device offsets, NULL = one group), stored at row c_row_map ? c_row_map[r] : r.
  * B in the reference's expert layout [E][K][N] (gate_up_proj [E, H, 2I], down_proj [E, I, H]), fp32 (b_int8 = 0) or int8 with

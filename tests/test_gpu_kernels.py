@@ -362,6 +362,26 @@ def test_w8a32_gemm(dev):
                                O.gemm_silu_int8(x, w, s, w2, s2), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 32000, 1024), (5, 777, 128), (130, 512, 96), (1, 32000, 1024)])
+def test_lm_head_three_term_bf16_form_is_as_accurate_as_the_f32_matrix_cores(dev, M, N, K):
+    """The tied lm_head on the bf16 matrix cores (each fp32 value cut into three exact bf16 terms, six partial products) against a
+    float64 product: its error must not exceed that of the f32 matrix-core kernel (a k-ordered fp32 chain) by more than a rounding,
+    with and without the row selection, on a vocabulary that is no multiple of the tile."""
+    from vllm_i64_amd import ops
+    g = torch.Generator().manual_seed(M + K)
+    a = torch.randn(M + 3, K, generator=g)
+    b = torch.randn(N, K, generator=g) * 0.02
+    rows = torch.randperm(M + 3, generator=g)[:M].to(torch.int32)
+    want = a[rows.long()].double() @ b.double().t()
+    got = ops.lm_head(a.to(dev), b.to(dev), a_rows=rows.to(dev)).cpu().double()
+    f32 = ops.gemm_f32(a.to(dev), b.to(dev), a_rows=rows.to(dev)).cpu().double()
+    e_new, e_f32 = (got - want).abs().max().item(), (f32 - want).abs().max().item()
+    print(f"lm_head {M}x{N}x{K}: three-term bf16 max error {e_new:.3e}, f32 matrix cores {e_f32:.3e} (|logit| max {want.abs().max():.2f})")
+    assert e_new <= max(1.5 * e_f32, 2e-7 * want.abs().max().item())
+    plain = ops.lm_head(a[rows.long()].contiguous().to(dev), b.to(dev)).cpu().double()
+    assert torch.equal(plain, got)
+
+
 def test_gemm_f32(dev):
     ops = _ops()
     g = torch.Generator().manual_seed(22)

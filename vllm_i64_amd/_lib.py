@@ -32,6 +32,7 @@ SIGNATURES: Dict[str, str] = {
     "i64h_rmsnorm_quant": "ppfpplip",
     "i64h_gemm_i8": "pppppiliipipipp",
     "i64h_gemm_f32": "pppplii" + "p",
+    "i64h_lm_head": "pppplii" + "pp",
     "i64h_gemm_w8a32": "pppplii" + "p",
     "i64h_gemm_w8a32_swiglu": "ppppppliip",
     "i64h_kv_write_decode": "pppppippiliiipp",
@@ -106,7 +107,7 @@ class I64HError(RuntimeError):
 
 def exported_symbols():
     return ["i64h_last_error", "i64h_version", "i64h_device_check", "i64h_bucketize_workspace_bytes",
-            "i64h_paged_attn_workspace_floats", "i64h_stats_words_per_slot", "i64h_moe_forward_workspace_bytes", "i64h_moe_forward_static_max_bytes", "i64h_decode_sync_words", "i64h_decode_tail_args_bytes", "i64h_debug_stamp_cursor", "i64h_fused_residual_norm_quant_rows", *SIGNATURES.keys()]
+            "i64h_paged_attn_workspace_floats", "i64h_stats_words_per_slot", "i64h_moe_forward_workspace_bytes", "i64h_moe_forward_static_max_bytes", "i64h_decode_sync_words", "i64h_decode_tail_args_bytes", "i64h_debug_stamp_cursor", "i64h_fused_residual_norm_quant_rows", "i64h_lm_head_workspace_bytes", *SIGNATURES.keys()]
 
 
 class GemmDesc(ctypes.Structure):
@@ -180,6 +181,8 @@ def load() -> ctypes.CDLL:
         getattr(lib, name).restype = _L
         getattr(lib, name).argtypes = []
     lib.i64h_moe_forward_static_max_bytes.argtypes = []
+    lib.i64h_lm_head_workspace_bytes.restype = _L
+    lib.i64h_lm_head_workspace_bytes.argtypes = [_L, _I]
     lib.i64h_moe_forward_workspace_bytes.restype = _L
     lib.i64h_moe_forward_workspace_bytes.argtypes = [_L, _P]
     for name, sig in SIGNATURES.items():

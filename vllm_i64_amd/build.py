@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libi64hip.so")
-SOURCES = ["i64h_api.hip", "i64h_route.hip", "i64h_quant.hip", "i64h_norm.hip", "i64h_gemm.hip", "i64h_gemm_os.hip", "i64h_attn.hip", "i64h_moe.hip", "i64h_fp8.hip", "i64h_kv.hip", "i64h_decode.hip", "i64h_variants.hip", "i64h_group_f32.hip"]
+SOURCES = ["i64h_api.hip", "i64h_route.hip", "i64h_quant.hip", "i64h_norm.hip", "i64h_gemm.hip", "i64h_gemm_os.hip", "i64h_attn.hip", "i64h_moe.hip", "i64h_fp8.hip", "i64h_kv.hip", "i64h_decode.hip", "i64h_variants.hip", "i64h_group_f32.hip", "i64h_lmhead.hip"]
 # -ffp-contract=off: a*b+c stays two roundings unless the source says fmaf, so fp32 element-wise math has the
 # same rounding steps as the reference's CPU ops.
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function",

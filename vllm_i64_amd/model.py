@@ -184,6 +184,7 @@ class _Buffers:
             self.ds = torch.empty(n, **f32)
             self.d_out = torch.empty(n, H, **f32)
         self.logits = torch.empty(n_logit_rows, cfg.vocab_size, **f32)
+        self.lm_ws: Optional[torch.Tensor] = None     # activation planes of the lm_head (allocated on first use)
         self.attn_ws: Optional[torch.Tensor] = None
         self.attn_splits = 1
         self.tails: Dict[tuple, list] = {}   # prepared persistent-launch descriptions per set of external buffers
@@ -258,6 +259,21 @@ class I64MoEModel:
         self._bufs: Dict[tuple, _Buffers] = {}
         self.dec_sync = ops.decode_sync_alloc(dev)
         self._resident_used = False   # a launch with a grid barrier was issued since the last check_sync
+
+    # the tied fp32 lm_head on the bf16 matrix cores through the exact three-term split (48 -> 27 us at batch 64; "0": the f32
+    # matrix-core kernel, whose results are bit for bit a k-ordered fp32 chain)
+    LM_HEAD_BF16X3 = os.environ.get("I64H_LM_HEAD_BF16X3", "1") != "0"
+
+    def _lm_head(self, B: "_Buffers", logit_rows):
+        M, H = B.logits.shape[0], self.cfg.hidden_size
+        if self.LM_HEAD_BF16X3 and H % 32 == 0:
+            if B.lm_ws is None:
+                B.lm_ws = torch.empty(max(16, ops.lm_head_workspace_bytes(M, H)), dtype=torch.uint8, device=self.device)
+            ops.lm_head(B.normed, self.embed, a_rows=logit_rows, out=B.logits, workspace=B.lm_ws)
+        else:
+            ops.call("i64h_gemm_f32", ops.ptr(B.normed), ops.ptr(logit_rows), ops.ptr(self.embed), ops.ptr(B.logits), M, self.cfg.vocab_size, H,
+                     ops._stream())
+        return B.logits
 
     # ---- helpers ----
     def buffers(self, n: int, n_logit_rows: int) -> _Buffers:
@@ -503,8 +519,7 @@ class I64MoEModel:
                 and cfg.head_dim == 64 and 256 <= H <= 1024 and H % 64 == 0
                 and (not cfg.is_moe or (cfg.shared_intermediate_size and 0 < B.plan.rows <= self.FUSE_MAX_ROWS))):
             self._layers_norm_fused(B, kvc, positions, slot_ids, ctx_len, splits, rows_are_slots)
-            ops.call("i64h_gemm_f32", ops.ptr(B.normed), ops.ptr(logit_rows), ops.ptr(self.embed), ops.ptr(B.logits), B.logits.shape[0],
-                     cfg.vocab_size, H, ops._stream())
+            self._lm_head(B, logit_rows)
             return B.logits
         for l, W in enumerate(self.layers):
             base = l * spl
@@ -609,8 +624,7 @@ class I64MoEModel:
                                             stats=None if last else st)
                 if record is not None:
                     record[f"l{l}.out"] = B.h.clone()
-        ops.call("i64h_gemm_f32", ops.ptr(B.normed), ops.ptr(logit_rows), ops.ptr(self.embed), ops.ptr(B.logits), B.logits.shape[0],
-                 cfg.vocab_size, H, ops._stream())
+        self._lm_head(B, logit_rows)
         return B.logits
 
     def _layers_norm_fused(self, B: _Buffers, kvc, positions, slot_ids, ctx_len, splits: int, rows_are_slots: bool):
@@ -795,8 +809,7 @@ class I64MoEModel:
                     ops.fused_residual_norm(B.h, nxt, eps, add=B.d_out, h_out=B.h, normed=B.normed)
             if record is not None:
                 record[f"l{l}.out"] = B.h.clone()
-        ops.call("i64h_gemm_f32", ops.ptr(B.normed), ops.ptr(logit_rows), ops.ptr(self.embed), ops.ptr(B.logits), B.logits.shape[0],
-                 cfg.vocab_size, H, ops._stream())
+        self._lm_head(B, logit_rows)
         return B.logits
 
     def _moe(self, B: _Buffers, W: dict, l: int, base: int, prequantized: bool = False):

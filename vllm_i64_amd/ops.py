@@ -389,6 +389,29 @@ def gemm_f32(a: torch.Tensor, b: torch.Tensor, a_rows: Optional[torch.Tensor] = 
     return out
 
 
+def lm_head(a: torch.Tensor, b: torch.Tensor, a_rows: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+            workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M, N] = a[a_rows] @ b^T, fp32 operands: on the bf16 matrix cores through the exact three-term split when K is a multiple
+    of 32 (i64h_lm_head), else the f32 matrix-core kernel.  workspace: uint8 buffer of lm_head_workspace_bytes(M, K) bytes."""
+    _chk(a, torch.float32, "a"), _chk(b, torch.float32, "b")
+    M = a_rows.numel() if a_rows is not None else a.shape[0]
+    N, K = b.shape
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    if K % 32 != 0:
+        call("i64h_gemm_f32", ptr(a), ptr(a_rows), ptr(b), ptr(out), M, N, K, _stream())
+        return out
+    need = lm_head_workspace_bytes(M, K)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=a.device)
+    call("i64h_lm_head", ptr(a), ptr(a_rows), ptr(b), ptr(out), M, N, K, ptr(workspace), _stream())
+    return out
+
+
+def lm_head_workspace_bytes(M: int, K: int) -> int:
+    return int(_lib.load().i64h_lm_head_workspace_bytes(M, K))
+
+
 def gemm_w8a32(x: torch.Tensor, w: torch.Tensor, w_scale: torch.Tensor) -> torch.Tensor:
     _chk(x, torch.float32, "x"), _chk(w, torch.int8, "w"), _chk(w_scale, torch.float32, "w_scale")
     M, K = x.shape
