@@ -20,7 +20,7 @@ for _ in range(3):
     ops.paged_attn(q, kc, vc, bt, cl, splits=splits, out=out, workspace=ws)
 buf = torch.zeros(B * splits * 8, dtype=torch.int64, device=dev)
 ops.call("i64h_debug_set_attn_stamps", ops.ptr(buf))
-junk.fill_(1)            # cold caches, like inside a decode step
+junk.view(torch.int64).sum()   # cold caches by reading (a write flush leaves dirty lines to evict under the launch)
 ops.paged_attn(q, kc, vc, bt, cl, splits=splits, out=out, workspace=ws)
 torch.cuda.synchronize()
 ops.call("i64h_debug_set_attn_stamps", 0)

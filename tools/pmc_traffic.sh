@@ -19,7 +19,7 @@ for pas in ("fetch", "write"):
         for (k, c), v in agg.items():
             res.setdefault(k, {})[c] = {"launches": len(v), "mean": sum(v) / len(v), "last_mean": sum(v[-24:]) / len(v[-24:])}
 json.dump(res, open("$OUT/summary.json", "w"), indent=1)
-# the per-kernel form bench.py reads (copy to profiles/r02_pmc_traffic.json).  "workload" names the run the passes were taken
+# the per-kernel form bench.py reads (copy to profiles/, under the name bench.py's PMC_PROFILE holds).  "workload" names the run the passes were taken
 # on: bench.py reports the traffic figure only for a run of exactly that workload (defaults of bench.py, read from its line)
 line = [l for l in open("$OUT/fetch.log") if l.startswith("{")][-1]
 b = json.loads(line)
@@ -35,7 +35,7 @@ for k, d in res.items():
     fk, wk = d["FETCH_SIZE"]["last_mean"], d["WRITE_SIZE"]["last_mean"]
     out["kernels"][k.split("(")[0]] = {"fetch_size_kb": fk, "write_size_kb": wk, "hbm_read_bytes_corrected": int(2 * fk * 1024),
                                        "hbm_write_bytes": int(wk * 1024), "launches": d["FETCH_SIZE"]["launches"]}
-json.dump(out, open("$OUT/r02_pmc_traffic.json", "w"), indent=1)
+json.dump(out, open("$OUT/pmc_traffic.json", "w"), indent=1)
 for k, d in sorted(res.items(), key=lambda kv: -sum(x["mean"] * x["launches"] for x in kv[1].values()))[:14]:
     print(k[:90], {c: (round(x["last_mean"], 1), x["launches"]) for c, x in d.items()})
 PY
