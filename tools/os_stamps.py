@@ -28,9 +28,9 @@ torch.cuda.synchronize()
 ops.call("i64h_debug_set_os_stamps", 0)
 st = buf.view(256, 16, 8)[:, :waves].cpu().double()
 t0 = st[:, :, 0].min()
-names = ["start", "located", "image filled", "first block: K loop done", "first block: epilogue issued", "-",
+names = ["start", "located", "image filled", "first block: K loop done", "first block: epilogue issued", "first block: epilogue, one row fragment stored (variant builds)",
          "all blocks done", "tile done"]
-order = [0, 1, 2, 3, 4, 6, 7]
+order = [0, 1, 2, 3, 5, 4, 6, 7]
 print(f"depth {depth}; s_memtime ticks relative to the workgroup's earliest wave start (medians / maxima over waves)")
 t0 = st[:, :, 0].min(dim=1, keepdim=True).values
 for i in order:
@@ -40,4 +40,13 @@ for wg in (0, 9):
     print(f"workgroup {wg}: per wave: filled | first block K loop done | first block epilogue issued | all blocks done | tile done")
     for wv in range(waves):
         r = st[wg, wv] - st[wg, :, 0].min()
-        print(f"  wave {wv}: {r[2]:7.0f} {r[3]:7.0f} {r[4]:7.0f} {r[6]:7.0f} {r[7]:7.0f}")
+        print(f"  wave {wv}: {r[2]:7.0f} {r[3]:7.0f} {r[4]:7.0f} {r[6]:7.0f} {r[7]:7.0f}   (stamp 5: {r[5]:7.0f})")
+# the same launch by HIP events (no stamps): ticks per nanosecond = the clock the kernel ran at
+ts = []
+for _ in range(8):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); ops.gemm_i8_frags(a, rs, wf, ws, N, group_offsets=off, epilogue=epi, out=out); e1.record(); torch.cuda.synchronize()
+    ts.append(e0.elapsed_time(e1) * 1e3)
+us = sorted(ts)[len(ts) // 2]
+life = float((st[:, :, 7] - t0).flatten().median())
+print(f"launch by events: median {us:.1f} us (launch overhead included); tile life {life:.0f} ticks -> at least {life / us / 1e3:.2f} ticks per ns")

@@ -37,6 +37,10 @@ __device__ __forceinline__ void os_glds16(const void* g, void* lds_base) {
 #define I64H_OS_PF_SHARES 8  // ... one share of this many per workgroup
 #endif
 
+typedef float os_v2f __attribute__((ext_vector_type(2)));
+// min / max of three in one instruction; the NaN and signed-zero rules are those of two v_min_f32 / v_max_f32 in a row
+__device__ __forceinline__ float os_min3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float os_max3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float os_silu(float g) {
     const float e = __builtin_amdgcn_exp2f(g * -1.44269504088896341f);
     return g * __builtin_amdgcn_rcpf(1.0f + e);
@@ -280,11 +284,21 @@ __device__ __forceinline__ void os_block(const GemmI8Args& p, const char* Bg, co
         }
     } else {
         float ra = 0.0f, rb = 0.0f, ra1 = 0.0f, rb1 = 0.0f;  // ranges of what this lane stored, per slot (tiles whose rows share one or two slots)
+        // the row scales (and slots) of all row fragments in one batch of LDS reads on clamped rows: behind a per-lane condition each
+        // read sits in a branch of its own and every fragment starts with an LDS round trip under the other waves' operand reads
+        float mrow[MFR];
+        int relrow[MFR];
+#pragma unroll
+        for (int i = 0; i < MFR; ++i) {
+            const int rc = min(i * 16 + fr, rows - 1);
+            mrow[i] = s_rs[rc];
+            relrow[i] = s_rel[rc];
+        }
 #pragma unroll
         for (int i = 0; i < MFR; ++i) {
             const int rr = i * 16 + fr;
             const bool rok = rr < rows;
-            const float m = rok ? s_rs[rr] * ws : 0.0f;
+            const float m = rok ? mrow[i] * ws : 0.0f;
             float* crow = p.C + (int64_t)(row0 + (rok ? rr : 0)) * I;
             float a = 0.0f, bb = 0.0f;
 #pragma unroll
@@ -294,31 +308,42 @@ __device__ __forceinline__ void os_block(const GemmI8Args& p, const char* Bg, co
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     if constexpr (F8) {  // per-output-channel weight scales; the expression of the tiled e4m3 kernel
-                        const float qs = rok ? s_rs[rr] : 0.0f;
+                        const float qs = rok ? mrow[i] : 0.0f;
                         const float gate = (float)acc[i][j][reg] * (qs * p.col_scale[(int64_t)g * p.N + c0 + reg]);
                         const float up = (float)acc[i][j + W][reg] * (qs * p.col_scale[(int64_t)g * p.N + I + c0 + reg]);
                         v[reg] = (gate / (1.0f + expf(-gate))) * up;
-                    } else {
-                        const float gate = (float)acc[i][j][reg] * m;
-                        const float up = (float)acc[i][j + W][reg] * m;
-                        v[reg] = os_silu(gate) * up;
+                    }
+                }
+                if constexpr (!F8) {
+                    // two outputs per instruction where the ISA has a packed fp32 form (multiplies, the + 1); the same IEEE operations in
+                    // the same order as os_silu(gate) * up, so the bits are those of the scalar form.  Next to a wave that is in its K
+                    // loop an epilogue instruction costs 20-25 cycles of the SIMD, so the count is what matters here.
+#pragma unroll
+                    for (int rp = 0; rp < 2; ++rp) {
+                        const os_v2f g2 = (os_v2f){(float)acc[i][j][2 * rp], (float)acc[i][j][2 * rp + 1]} * (os_v2f){m, m};
+                        const os_v2f u2 = (os_v2f){(float)acc[i][j + W][2 * rp], (float)acc[i][j + W][2 * rp + 1]} * (os_v2f){m, m};
+                        const os_v2f t2 = g2 * (os_v2f){-1.44269504088896341f, -1.44269504088896341f};
+                        const os_v2f d2 = (os_v2f){1.0f, 1.0f} + (os_v2f){__builtin_amdgcn_exp2f(t2.x), __builtin_amdgcn_exp2f(t2.y)};
+                        const os_v2f o2 = (g2 * (os_v2f){__builtin_amdgcn_rcpf(d2.x), __builtin_amdgcn_rcpf(d2.y)}) * u2;
+                        v[2 * rp] = o2.x;
+                        v[2 * rp + 1] = o2.y;
                     }
                 }
                 if (rok) {
                     *(float4*)(crow + c0) = make_float4(v[0], v[1], v[2], v[3]);
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) { a = fminf(a, v[reg]); bb = fmaxf(bb, v[reg]); }
+                    a = os_min3(a, v[0], v[1]); a = os_min3(a, v[2], v[3]);
+                    bb = os_max3(bb, v[0], v[1]); bb = os_max3(bb, v[2], v[3]);
                 }
             }
             if (st && uni) {  // the tile's rows report to one or two slots: their ranges are carried over the row fragments in registers
-                const bool second = rok && s_rel[rr] != sl0;
+                const bool second = rok && relrow[i] != sl0;
                 ra = fminf(ra, second ? 0.0f : a); rb = fmaxf(rb, second ? 0.0f : bb);
                 ra1 = fminf(ra1, second ? a : 0.0f); rb1 = fmaxf(rb1, second ? bb : 0.0f);
             } else if (st) {
                 a = fminf(a, lane_xor(a, 16)); bb = fmaxf(bb, lane_xor(bb, 16));
                 a = fminf(a, lane_xor(a, 32)); bb = fmaxf(bb, lane_xor(bb, 32));
                 if (fq == 0 && rok) {
-                    const int sl = s_rel[rr];
+                    const int sl = relrow[i];
                     if (sl >= 0 && sl < I64H_STAT_TAB) {
                         atomicMin(&tab_lo[sl], f32_to_ordered(a));
                         atomicMax(&tab_hi[sl], f32_to_ordered(bb));
