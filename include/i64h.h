@@ -54,6 +54,16 @@ int i64h_moe_plan(const int64_t* token_ids, const int64_t* tables, int64_t table
                   int32_t* tok_slots, int32_t* offsets, int32_t* expert_offsets, int32_t* perm, int32_t* inv, int32_t* sorted_bucket,
                   int32_t* workspace, int64_t n, int32_t top_k, int64_t vocab, int32_t num_experts, int32_t layers, void* stream);
 
+/* i64h_moe_plan and i64h_embedding_stats_reset (nn.Embedding lookup, model.py:415, + the start-of-forward reset of n_slots
+ * stat slots) of the same token ids: ONE launch for decode-sized steps (top_k * n <= 512 rows: the embedding rows ride as extra
+ * workgroups of the plan launch - both depend on nothing but the ids), the separate launches otherwise.  Same outputs as the two
+ * calls.  embed_table fp32 [embed_vocab, H], embed_out fp32 [n, H], H a multiple of 4. */
+int i64h_moe_plan_embedding(const int64_t* token_ids, const int64_t* tables, int64_t table_layer_stride, int64_t* routes, int32_t* keys,
+                            int32_t* tok_slots, int32_t* offsets, int32_t* expert_offsets, int32_t* perm, int32_t* inv,
+                            int32_t* sorted_bucket, int32_t* workspace, int64_t n, int32_t top_k, int64_t vocab, int32_t num_experts,
+                            int32_t layers, const float* embed_table, float* embed_out, int32_t H, int64_t embed_vocab, uint32_t* stats,
+                            int64_t n_slots, void* stream);
+
 /* dst[i] = src[idx[i]] for rows of row_bytes bytes (idx NULL = copy).  Replaces the row moves of i64_scatter_kernel /
  * i64_gather_kernel (csrc/i64_router.cu:94-165), gather_by_expert (csrc/i64_ops_binding.cu:207-209). */
 int i64h_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n_rows, int64_t row_bytes, void* stream);

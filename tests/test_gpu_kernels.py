@@ -711,3 +711,29 @@ def test_fused_qkv_rope_kv_equals_two_kernel_path(dev):
         for a, b in zip(outs[0], outs[1]):
             assert torch.equal(a, b)
         assert outs[1][0].abs().sum() > 0
+
+
+@pytest.mark.parametrize("n", [1, 64, 200, 300])
+def test_plan_with_embedding_rows_equals_the_two_launches(n):
+    """i64h_moe_plan_embedding against i64h_moe_plan + i64h_embedding_stats_reset: every plan output, the embedding rows and the reset
+    stat slots identical (one launch up to 512 (route, token) rows, the separate launches beyond - n = 300 at top-2)."""
+    from vllm_i64_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(n)
+    L, top_k, V, E, H = 3, 2, 500, 8, 96
+    tables = torch.randint(0, E, (L, top_k, V), generator=g).to(dev)
+    ids = torch.randint(0, V, (n,), generator=g).to(dev)
+    ids[0] = V + 7          # out-of-range ids clamp the same way in both forms
+    embed = torch.randn(V, H, generator=g).to(dev)
+    a, b = ops.MoePlan(n, top_k, E, L, dev, with_routes=True), ops.MoePlan(n, top_k, E, L, dev, with_routes=True)
+    st_a = torch.full((5 * ops.slot_words(),), 12345, dtype=torch.int32, device=dev)
+    st_b = st_a.clone()
+    h_a, h_b = torch.full((n, H), float("nan"), device=dev), torch.full((n, H), float("nan"), device=dev)
+    a.run(ids, tables)
+    ops.embedding(ids, embed, out=h_a, reset_stats=st_a)
+    b.run_with_embedding(ids, tables, embed, h_b, reset_stats=st_b)
+    torch.cuda.synchronize()
+    for name in ("routes", "keys", "offsets", "perm", "inv", "sorted_bucket", "expert_offsets", "tok_slots"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert torch.equal(h_a, h_b) and torch.equal(st_a, st_b)
+    assert not torch.isnan(h_b).any() and int((st_b == 12345).sum()) == 0

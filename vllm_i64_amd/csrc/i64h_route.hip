@@ -149,6 +149,15 @@ __global__ __launch_bounds__(PLAN_THREADS) void bucket_place_kernel(
     }
 }
 
+// embedding rows + stat-slot reset riding in the small plan launch (layers = number of plan workgroups in front; 0 riders when table == nullptr)
+struct PlanEmbed {
+    const float* table;
+    float* out;
+    uint32_t* stats;
+    int64_t stat_words, emb_vocab;
+    int H, layers;
+};
+
 // ---- all three phases in one launch when one wave covers the rows (decode-sized steps: R <= ROWS_PER_WAVE) -----------------
 // One workgroup per layer; wave 0 runs phases A and C exactly as the kernels above do for their single wave, the scan of phase B
 // degenerates to the bucket offsets.  Same keys, offsets, permutation: the results are identical to the three-launch path.
@@ -157,9 +166,21 @@ __global__ __launch_bounds__(MAX_BUCKETS) void bucket_plan_small_kernel(
     const int64_t* __restrict__ ids, const int64_t* __restrict__ tables, int64_t table_layer_stride,
     const int32_t* __restrict__ keys_in, int32_t* __restrict__ keys, int64_t* __restrict__ routes, int32_t* __restrict__ tok_slots,
     int32_t* __restrict__ wave_counts, int32_t* __restrict__ offsets, int32_t* __restrict__ group_offsets, int32_t* __restrict__ perm,
-    int32_t* __restrict__ inv, int32_t* __restrict__ sorted_bucket, int n, int top_k, int64_t V, int nb) {
+    int32_t* __restrict__ inv, int32_t* __restrict__ sorted_bucket, int n, int top_k, int64_t V, int nb, PlanEmbed em) {
     __shared__ int hist[MAX_BUCKETS], cursor[MAX_BUCKETS];
     __shared__ int skey[ROWS_PER_WAVE];
+    if ((int)blockIdx.x >= em.layers) {
+        // riders of the plan launch: the embedding rows of the same token ids and the start-of-forward reset of the stat slots
+        // (both depend on nothing but the ids; as a launch of their own they cost a dispatch and ~4.6 us in front of layer 0)
+        const int t = blockIdx.x - em.layers;
+        for (int64_t i = (int64_t)t * MAX_BUCKETS + threadIdx.x; i < em.stat_words; i += (int64_t)n * MAX_BUCKETS) em.stats[i] = I64H_ORDERED_ZERO;
+        int64_t id = ids[t];
+        id = id < 0 ? 0 : (id >= em.emb_vocab ? em.emb_vocab - 1 : id);
+        const float4* src = (const float4*)(em.table + id * em.H);
+        float4* dst = (float4*)(em.out + (int64_t)t * em.H);
+        for (int i = threadIdx.x; i < em.H / 4; i += MAX_BUCKETS) dst[i] = src[i];
+        return;
+    }
     const int l = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int R = n * top_k;
     if (tid < nb) hist[tid] = 0;
@@ -293,7 +314,7 @@ int64_t i64h_bucketize_workspace_bytes(int64_t rows, int32_t num_buckets, int32_
 static int bucketize_common(bool table, const int64_t* ids, const int64_t* tables, int64_t layer_stride, const int32_t* keys_in,
                             int32_t* keys, int64_t* routes, int32_t* tok_slots, int32_t* offsets, int32_t* group_offsets, int32_t* perm,
                             int32_t* inv, int32_t* sorted_bucket, int32_t* workspace, int n, int top_k, int64_t V, int nb, int L,
-                            hipStream_t st) {
+                            hipStream_t st, const PlanEmbed* riders = nullptr, bool* riders_done = nullptr) {
     I64H_CHECK_ARG(nb > 0 && nb <= MAX_BUCKETS, "bucketize: %d buckets unsupported (max %d)", nb, MAX_BUCKETS);
     I64H_CHECK_ARG(n >= 0 && top_k > 0 && L > 0, "bucketize: bad sizes");
     const int64_t R = (int64_t)n * top_k;
@@ -301,12 +322,19 @@ static int bucketize_common(bool table, const int64_t* ids, const int64_t* table
     int num_waves = (int)((R + ROWS_PER_WAVE - 1) / ROWS_PER_WAVE);
     if (num_waves < 1) num_waves = 1;
     if (R > 0 && R <= ROWS_PER_WAVE) {  // one wave covers the rows: the three phases in one launch
+        PlanEmbed em = {nullptr, nullptr, nullptr, 0, 0, 0, L};
+        if (riders && table) {
+            em = *riders;
+            em.layers = L;
+            *riders_done = true;
+        }
+        const int extra = em.table ? n : 0;
         if (table)
-            hipLaunchKernelGGL(bucket_plan_small_kernel<true>, dim3(L), dim3(MAX_BUCKETS), 0, st, ids, tables, layer_stride, keys_in, keys,
-                               routes, tok_slots, workspace, offsets, group_offsets, perm, inv, sorted_bucket, n, top_k, V, nb);
+            hipLaunchKernelGGL(bucket_plan_small_kernel<true>, dim3(L + extra), dim3(MAX_BUCKETS), 0, st, ids, tables, layer_stride, keys_in, keys,
+                               routes, tok_slots, workspace, offsets, group_offsets, perm, inv, sorted_bucket, n, top_k, V, nb, em);
         else
             hipLaunchKernelGGL(bucket_plan_small_kernel<false>, dim3(L), dim3(MAX_BUCKETS), 0, st, ids, tables, layer_stride, keys_in, keys,
-                               routes, tok_slots, workspace, offsets, group_offsets, perm, inv, sorted_bucket, n, top_k, V, nb);
+                               routes, tok_slots, workspace, offsets, group_offsets, perm, inv, sorted_bucket, n, top_k, V, nb, em);
         I64H_CHECK_LAUNCH();
         return 0;
     }
@@ -342,6 +370,26 @@ int i64h_moe_plan(const int64_t* token_ids, const int64_t* tables, int64_t table
     I64H_CHECK_ARG(n >= 0 && n * top_k < (1ll << 31), "moe_plan: bad token count");
     return bucketize_common(true, token_ids, tables, table_layer_stride, nullptr, keys, routes, tok_slots, offsets, expert_offsets, perm,
                             inv, sorted_bucket, workspace, (int)n, top_k, vocab, num_experts * top_k, layers, (hipStream_t)stream);
+}
+
+int i64h_embedding_stats_reset(const int64_t* ids, const float* table, float* out, int64_t n, int32_t H, int64_t V, uint32_t* stats,
+                               int64_t n_slots, void* stream);
+
+int i64h_moe_plan_embedding(const int64_t* token_ids, const int64_t* tables, int64_t table_layer_stride, int64_t* routes, int32_t* keys,
+                            int32_t* tok_slots, int32_t* offsets, int32_t* expert_offsets, int32_t* perm, int32_t* inv,
+                            int32_t* sorted_bucket, int32_t* workspace, int64_t n, int32_t top_k, int64_t vocab, int32_t num_experts,
+                            int32_t layers, const float* embed_table, float* embed_out, int32_t H, int64_t embed_vocab, uint32_t* stats,
+                            int64_t n_slots, void* stream) {
+    I64H_CHECK_ARG(n >= 0 && n * top_k < (1ll << 31), "moe_plan_embedding: bad token count");
+    I64H_CHECK_ARG(embed_table && embed_out && H > 0 && H % 4 == 0 && embed_vocab > 0, "moe_plan_embedding: H=%d must be a positive multiple of 4", H);
+    I64H_CHECK_ARG(n_slots == 0 || stats, "moe_plan_embedding: stats is NULL");
+    PlanEmbed em = {embed_table, embed_out, stats, stats ? n_slots * I64H_SLOT_WORDS : 0, embed_vocab, H, 0};
+    bool done = false;
+    const int rc = bucketize_common(true, token_ids, tables, table_layer_stride, nullptr, keys, routes, tok_slots, offsets, expert_offsets,
+                                    perm, inv, sorted_bucket, workspace, (int)n, top_k, vocab, num_experts * top_k, layers,
+                                    (hipStream_t)stream, &em, &done);
+    if (rc != 0 || done) return rc;
+    return i64h_embedding_stats_reset(token_ids, embed_table, embed_out, n, H, embed_vocab, stats, n_slots, stream);
 }
 
 int i64h_gather_rows(const void* src, const int32_t* idx, void* dst, int64_t n_rows, int64_t row_bytes, void* stream) {

@@ -262,6 +262,7 @@ class I64MoEModel:
 
     # the tied fp32 lm_head on the bf16 matrix cores through the exact three-term split (48 -> 27 us at batch 64; "0": the f32
     # matrix-core kernel, whose results are bit for bit a k-ordered fp32 chain)
+    PLAN_WITH_EMBEDDING = os.environ.get("I64H_PLAN_WITH_EMBEDDING", "1") != "0"  # the embedding rows ride in the plan launch of a decode-sized step
     LM_HEAD_BF16X3 = os.environ.get("I64H_LM_HEAD_BF16X3", "1") != "0"
 
     def _lm_head(self, B: "_Buffers", logit_rows):
@@ -492,9 +493,13 @@ class I64MoEModel:
                 B.plan.run(ids_all, self.tables)
                 B.row_map = self._ep.exchange_row_map(B.plan.perm, n, self.ep.world, cfg.top_k)
                 B.recv_map = self._ep.owner_row_map(B.plan.keys, n, self.ep.rank, self.ep.world, cfg.top_k, self.ep_le)
+        elif cfg.is_moe and self.PLAN_WITH_EMBEDDING:
+            # routing plan, embedding rows and the reset of the step's stat slots: one launch for decode-sized steps
+            B.plan.run_with_embedding(token_ids, self.tables, self.embed, B.h, reset_stats=st)
         elif cfg.is_moe:
             B.plan.run(token_ids, self.tables)
-        ops.embedding(token_ids, self.embed, out=B.h, reset_stats=st)  # + the reset of the step's stat slots
+        if self.ep is not None or not (cfg.is_moe and self.PLAN_WITH_EMBEDDING):
+            ops.embedding(token_ids, self.embed, out=B.h, reset_stats=st)  # + the reset of the step's stat slots
         # attention splits: enough workgroups to fill the chip when few rows carry long contexts (decode)
         splits = 1
         if max_ctx_hint >= 256 and n <= 256:

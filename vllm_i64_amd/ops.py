@@ -92,6 +92,20 @@ class MoePlan:
              self.n, top_k, V, self.E, L, _stream())
         return self
 
+    def run_with_embedding(self, token_ids: torch.Tensor, tables: torch.Tensor, embed: torch.Tensor, out: torch.Tensor,
+                           reset_stats: Optional[torch.Tensor] = None):
+        """run() and embedding(token_ids, embed, out, reset_stats) as one launch for decode-sized steps (i64h_moe_plan_embedding)."""
+        _chk(token_ids, torch.int64, "token_ids"), _chk(tables, torch.int64, "tables")
+        _chk(embed, torch.float32, "embed"), _chk(out, torch.float32, "out")
+        L, top_k, V = tables.shape
+        assert L == self.L and top_k == self.top_k and token_ids.numel() == self.n
+        assert out.shape[0] >= self.n and out.shape[1] == embed.shape[1]
+        n_slots = reset_stats.numel() // slot_words() if reset_stats is not None else 0
+        call("i64h_moe_plan_embedding", ptr(token_ids), ptr(tables), top_k * V, ptr(self.routes), ptr(self.keys), ptr(self.tok_slots),
+             ptr(self.offsets), ptr(self.expert_offsets), ptr(self.perm), ptr(self.inv), ptr(self.sorted_bucket), ptr(self.ws),
+             self.n, top_k, V, self.E, L, ptr(embed), ptr(out), embed.shape[1], embed.shape[0], ptr(reset_stats), n_slots, _stream())
+        return self
+
 
 def gather_rows(src: torch.Tensor, idx: Optional[torch.Tensor], n_rows: Optional[int] = None) -> torch.Tensor:
     _chk(src, None, "src")
