@@ -237,6 +237,15 @@ int i64h_lm_head(const float* A, const int32_t* a_rows, const float* B, float* C
 int i64h_gemm_f32_grouped(const float* A, const int32_t* a_src_row, const void* B, int32_t b_int8, const float* b_row_scale,
                           const int32_t* group_offsets, int32_t num_groups, int64_t M, int32_t N, int32_t K, float* C,
                           const int32_t* c_row_map, int32_t epilogue, void* stream);
+
+/* The same grouped contraction on int4 weights: B uint8 [E][K][N/2] (two weights per byte along N, high nibble = the even column),
+ * b_scale / b_zero fp32 [E][K][N/group_size] (asymmetric, per group of group_size consecutive columns of a weight row):
+ * w = (float(q) - zero) * scale, formed while a tile is staged, fp32 on the f32 matrix cores.  N % group_size == 0,
+ * group_size % 4 == 0.  Replaces fused_token_routed_forward_int4 (vllm_i64/kernels/fused_experts.py:294-476: per-token weight
+ * gather + bmm, or the per-expert dequantize_int4 + matmul loop; vllm_i64/core/quantization.py:307-373). */
+int i64h_gemm_w4_grouped(const float* A, const int32_t* a_src_row, const void* B, const float* b_scale, const float* b_zero,
+                         int32_t group_size, const int32_t* group_offsets, int32_t num_groups, int64_t M, int32_t N, int32_t K, float* C,
+                         const int32_t* c_row_map, int32_t epilogue, void* stream);
 /* The same grouped contraction with fp16 (dtype 1) or bf16 (dtype 2) operands and output, as the reference's fp16 expert path holds
  * them (csrc/i64_expert_dispatch.cu:144-233: cublasHgemm on half operands; vllm_i64/kernels/fused_experts.py:65-150): A [*, K],
  * B [E][K][N] and C in that type - consumed in place, no fp32 copies -, fp32 accumulation on v_mfma_f32_16x16x32_{f16,bf16}, the

@@ -146,6 +146,55 @@ def fused_token_routed_forward_int8(x, gate_up_int8, gate_up_scale, down_int8, d
 
 
 # ---- fp8 (OCP e4m3fn): vllm_i64/core/fp8.py ---------------------------------------------------------------------------
+def quantize_int4(weight: torch.Tensor, group_size: int = 128):
+    """Per-group asymmetric int4 (vllm_i64/core/quantization.py:307-347): groups of group_size along the last dimension; packed two per
+    byte, high nibble first; returns (packed uint8 [out, in/2], scale [out, groups], zero [out, groups])."""
+    out_f, in_f = weight.shape
+    assert in_f % group_size == 0
+    wg = weight.reshape(out_f, in_f // group_size, group_size)
+    w_min, w_max = wg.amin(dim=-1), wg.amax(dim=-1)
+    scale = ((w_max - w_min) / 15.0).clamp(min=1e-8)
+    zero = (-w_min / scale).round().clamp(0, 15)
+    q = ((wg - w_min.unsqueeze(-1)) / scale.unsqueeze(-1)).round().clamp(0, 15).to(torch.uint8).reshape(out_f, -1)
+    return (q[:, 0::2] << 4) | q[:, 1::2], scale, zero
+
+
+def dequantize_int4(packed: torch.Tensor, scale: torch.Tensor, zero: torch.Tensor, group_size: int = 128) -> torch.Tensor:
+    """(unpacked - zero) * scale per group, shape [out, groups, group_size] (vllm_i64/core/quantization.py:350-373)."""
+    out_f, in_f = packed.shape[0], packed.shape[1] * 2
+    un = torch.stack([(packed >> 4) & 0xF, packed & 0xF], dim=-1).reshape(out_f, in_f)
+    return (un.reshape(out_f, in_f // group_size, group_size).float() - zero.unsqueeze(-1)) * scale.unsqueeze(-1)
+
+
+def int4_linear(x, packed, scale, zero, group_size=128, bias=None):
+    """y = x @ dequant(packed).T + bias (vllm_i64/core/quantization.py:376-421)."""
+    w = dequantize_int4(packed, scale, zero, group_size).reshape(packed.shape[0], -1)
+    return F.linear(x.float(), w, bias)
+
+
+def fused_token_routed_forward_int4(x, gate_up_int4, gate_up_scale, gate_up_zero, down_int4, down_scale, down_zero, expert_ids,
+                                    num_experts, inter, group_size=128):
+    """The per-expert form of vllm_i64/kernels/fused_experts.py:405-476 (the chunked mode's torch branch): rows sorted by expert
+    (stable), per expert dequantize_int4 + matmul + SwiGLU + matmul, rows scattered back.  The bmm mode (fused_experts.py:347-402,
+    N <= 64) computes the same products through per-token weight copies; it differs by the summation order of the matmuls only."""
+    n = x.shape[0]
+    order = expert_ids.argsort(stable=True)
+    sx, se = x[order], expert_ids[order]
+    out = torch.empty(n, x.shape[1], dtype=x.dtype)
+    for e in range(num_experts):
+        sel = (se == e).nonzero().flatten()
+        if sel.numel() == 0:
+            continue
+        w_gu = dequantize_int4(gate_up_int4[e], gate_up_scale[e], gate_up_zero[e], group_size).reshape(gate_up_int4[e].shape[0], -1).to(x.dtype)
+        gu = sx[sel] @ w_gu
+        h = F.silu(gu[..., :inter]) * gu[..., inter:]
+        w_d = dequantize_int4(down_int4[e], down_scale[e], down_zero[e], group_size).reshape(down_int4[e].shape[0], -1).to(x.dtype)
+        out[sel] = h @ w_d
+    res = torch.empty_like(out)
+    res[order] = out
+    return res
+
+
 def quantize_fp8_rows(x: torch.Tensor):
     """quantize_fp8(per_channel=True) / quantize_activations_fp8 (fp8.py:77-130): s = max(amax|x|, 1e-12) / 448,
     q = e4m3fn(clamp(x / s, -448, 448)).  Returns (q float8_e4m3fn [rows, K], s fp32 [rows])."""

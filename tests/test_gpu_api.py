@@ -464,3 +464,42 @@ def test_kv_copy_blocks(dev, dtype):
         want[4], want[0], want[9] = b[1], b[7], b[1]
         assert torch.equal(t.view(torch.uint8), want.view(torch.uint8))
     KV.copy_blocks(c, [], [])
+
+
+def test_int4_operator_path_against_reference_vectors(dev, golden_dir):
+    """quantize_int4 / dequantize_int4 / int4_linear / fused_token_routed_forward_int4 of the operator surface against vectors captured
+    from the imported reference (tests/golden/make_golden_int4.py): codes, scales, zeros and dequantized weights identical; the
+    contractions run on the f32 matrix cores - bound: 2e-5 of the output magnitude (fp32 sums in another order), both of the
+    reference's modes (bmm: 40 rows, chunked: 200 rows with an expert without rows) through the one grouped path."""
+    from vllm_i64_amd import kernels as KN
+    z = np.load(os.path.join(golden_dir, "int4.npz"))
+    gs, inter = int(z["group_size"]), int(z["inter"])
+    t = lambda k: torch.from_numpy(z[k]).to(dev)
+    for name, key in (("gu", "gate_up_f32_e0"), ("dn", "down_f32_e0")):
+        p, s, zz = KN.quantize_int4(t(key), gs)
+        assert p.device.type == "cuda"
+        assert torch.equal(p, t(name + "_p")[0]) and torch.equal(s, t(name + "_s")[0]) and torch.equal(zz, t(name + "_z")[0])
+    assert torch.equal(KN.dequantize_int4(t("gu_p")[1], t("gu_s")[1], t("gu_z")[1], gs), t("dequant_gu1"))
+    y = KN.int4_linear(t("lin_x"), t("lin_p"), t("lin_s"), t("lin_z"), gs, t("lin_bias"))
+    assert (y - t("lin_y")).abs().max().item() <= 2e-5 * float(np.abs(z["lin_y"]).max())
+    for tag in ("bmm", "chunked"):
+        E = z["gu_p"].shape[0]
+        y = KN.fused_token_routed_forward_int4(t(tag + "_x"), t("gu_p"), t("gu_s"), t("gu_z"), t("dn_p"), t("dn_s"), t("dn_z"),
+                                                t(tag + "_eid"), E, inter, gs)
+        ref = t(tag + "_y")
+        d = (y - ref).abs().max().item()
+        print(f"int4 expert forward [{tag}]: max abs diff {d:.3e} (|y| max {ref.abs().max().item():.3f})")
+        assert y.shape == ref.shape and d <= 2e-5 * ref.abs().max().item()
+    # ragged shapes: columns that do not fill a tile, one group per row, a group size that is not the default
+    g = torch.Generator().manual_seed(11)
+    E, H, I, gs2, n = 3, 96, 48, 32, 77
+    gu = torch.randn(E, H, 2 * I, generator=g) * 0.1
+    dn = torch.randn(E, I, H, generator=g) * 0.1
+    pk = [[O.quantize_int4(w[e], gs2) for e in range(E)] for w in (gu, dn)]
+    st = lambda lst, i: torch.stack([q[i] for q in lst])
+    x = torch.randn(n, H, generator=g)
+    eid = torch.randint(0, E, (n,), generator=g)
+    want = O.fused_token_routed_forward_int4(x, st(pk[0], 0), st(pk[0], 1), st(pk[0], 2), st(pk[1], 0), st(pk[1], 1), st(pk[1], 2), eid, E, I, gs2)
+    got = KN.fused_token_routed_forward_int4(x.to(dev), *(st(pk[0], i).to(dev) for i in range(3)), *(st(pk[1], i).to(dev) for i in range(3)),
+                                             eid.to(dev), E, I, gs2)
+    assert (got.cpu() - want).abs().max().item() <= 2e-5 * want.abs().max().item()

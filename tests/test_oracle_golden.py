@@ -224,3 +224,21 @@ def test_variant_ops_oracle_against_reference_vectors(golden_dir):
             assert np.array_equal(torch.cat(parts).numpy(), z[f"at_varlen_{tag}_{W}"])
             y = O.attention_masked(q[:5], k[:19], v[:19], 2, torch.from_numpy(z["at_cached_pos"]), 0.25, W, integer)
             assert np.array_equal(y.numpy(), z[f"at_cached_{tag}_{W}"])
+
+
+def test_oracle_int4_ops_match_reference_fixtures(golden_dir):
+    """Oracle restatement of the int4 path against vectors captured from the imported reference (tests/golden/make_golden_int4.py):
+    quantizer codes / scales / zeros, dequantized weights and int4_linear equal; the expert forward equal in the per-expert
+    (chunked) mode, within summation order of the reference's per-token bmm mode."""
+    z = np.load(os.path.join(golden_dir, "int4.npz"))
+    gs, inter = int(z["group_size"]), int(z["inter"])
+    t = lambda k: torch.from_numpy(z[k])
+    for name, w in (("gu", t("gate_up_f32_e0")), ("dn", t("down_f32_e0"))):
+        p, s, zz = O.quantize_int4(w, gs)
+        assert torch.equal(p, t(name + "_p")[0]) and torch.equal(s, t(name + "_s")[0]) and torch.equal(zz, t(name + "_z")[0])
+    assert torch.equal(O.dequantize_int4(t("gu_p")[1], t("gu_s")[1], t("gu_z")[1], gs), t("dequant_gu1"))
+    assert torch.equal(O.int4_linear(t("lin_x"), t("lin_p"), t("lin_s"), t("lin_z"), gs, t("lin_bias")), t("lin_y"))
+    for tag, tol in (("chunked", 0.0), ("bmm", 2e-6)):
+        y = O.fused_token_routed_forward_int4(t(tag + "_x"), t("gu_p"), t("gu_s"), t("gu_z"), t("dn_p"), t("dn_s"), t("dn_z"),
+                                              t(tag + "_eid"), t("gu_p").shape[0], inter, gs)
+        assert (y - t(tag + "_y")).abs().max().item() <= tol, tag

@@ -46,6 +46,7 @@ SIGNATURES: Dict[str, str] = {
     "i64h_gemm_fp8_rows_pair": "ppip",
     "i64h_gemm_fp8_rows_qkv_rope_kv": "pppfpppp" + "ipppiiiiip",
     "i64h_gemm_f32_grouped": "pppippiliippip",
+    "i64h_gemm_w4_grouped": "pppppipiliippip",
     "i64h_gemm_h16_grouped": "pppipiliippip",
     "i64h_embedding": "pppli" + "lp",
     "i64h_embedding_stats_reset": "pppli" + "lplp",

@@ -6,8 +6,11 @@
 //
 // gemm_f32_grouped_kernel<EPI, W8>: C[r, :] = A[src(r), :K] @ W[g(r)][:K, :N] in fp32 on v_mfma_f32_16x16x4_f32.
 //   EPI = 1: C[r, j] = silu(y[r, j]) * y[r, I + j] with I = N / 2 (the chunk(2) + F.silu(gate) * up of the reference).
-//   W8: weights int8 with one fp32 scale per weight ROW [E][K] (the weight-only int8 form: w = int8 * scale[:, None]),
+//   W8 = 1: weights int8 with one fp32 scale per weight ROW [E][K] (the weight-only int8 form: w = int8 * scale[:, None]),
 //       dequantized to fp32 while the tile is staged - the same fp32 values the reference's w.float() * scale holds.
+//   W8 = 2: weights int4, two per byte along N (high nibble = the even column), asymmetric per group of `gs` consecutive columns
+//       of a weight row: scale and zero fp32 [E][K][N / gs], w = (float(q) - zero) * scale - the fp32 values of the reference's
+//       dequantize_int4 (vllm_i64/core/quantization.py:350-373), formed while the tile is staged.
 //   src(r) = a_src_row ? a_src_row[r] : r (the gather into expert order), stores go to row c_row_map ? c_row_map[r] : r
 //   (the scatter back to token order).
 // Tile 64 rows x 64 columns (EPI: 32 gate columns + their 32 up partners), K steps of 32, 4 waves (2 x 2), double-buffered LDS.
@@ -23,7 +26,8 @@ template <int EPI, int W8>
 __global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(const float* __restrict__ A, const int32_t* __restrict__ a_src_row,
                                                                const void* __restrict__ Bv, const float* __restrict__ b_row_scale,
                                                                const int32_t* __restrict__ group_off, int G, int M, int N, int K,
-                                                               float* __restrict__ C, const int32_t* __restrict__ c_row_map) {
+                                                               float* __restrict__ C, const int32_t* __restrict__ c_row_map,
+                                                               const float* __restrict__ b_zero, int gs) {
     __shared__ float sA[2][GF_BM][GF_BK + 1];
     __shared__ float sB[2][GF_BK][GF_BN + 4];
     __shared__ int s_info[4];
@@ -48,7 +52,9 @@ __global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(const float* __re
     if (g < 0) return;
     const float* Bf = (const float*)Bv + (int64_t)g * K * N;
     const int8_t* B8 = (const int8_t*)Bv + (int64_t)g * K * N;
-    const float* bs = b_row_scale ? b_row_scale + (int64_t)g * K : nullptr;
+    const float* bs = b_row_scale ? b_row_scale + (int64_t)g * K * (W8 == 2 ? N / gs : 1) : nullptr;
+    const uint8_t* B4 = (const uint8_t*)Bv + (int64_t)g * K * (N / 2);
+    const float* bz = (W8 == 2) ? b_zero + (int64_t)g * K * (N / gs) : nullptr;
 
     // staging of A: thread -> 4 consecutive k of tile rows ar and ar + 32
     const int ar = tid >> 3, ak = (tid & 7) * 4;
@@ -90,8 +96,22 @@ __global__ __launch_bounds__(256) void gemm_f32_grouped_kernel(const float* __re
             }
             const int kb = k0 + bk + 16 * ps;
             const bool kin = kb < K;
-            const float sc = (W8 && kin && bs) ? bs[kb] : 1.0f;
-            if (W8) {
+            const float sc = (W8 == 1 && kin && bs) ? bs[kb] : 1.0f;
+            if (W8 == 2) {
+                // the thread's four columns start at a multiple of 4: two whole bytes, one quantization group (gs % 4 == 0)
+                if (kin && bok) {
+                    const uint8_t* p = B4 + ((int64_t)kb * N + bcol) / 2;
+                    const int64_t gi = (int64_t)kb * (N / gs) + bcol / gs;
+                    const float s4 = bs[gi], z4 = bz[gi];
+                    const unsigned b0 = p[0], b1 = (bcol + 2 < blim) ? p[1] : 0u;
+                    const unsigned q[4] = {b0 >> 4, b0 & 15u, b1 >> 4, b1 & 15u};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rb[ps][e] = (bcol + e < blim) ? ((float)q[e] - z4) * s4 : 0.0f;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rb[ps][e] = 0.0f;
+                }
+            } else if (W8) {
                 const int8_t* p = B8 + (int64_t)(kin ? kb : 0) * N + bcol;
                 if (kin && bok && vec_b && bcol + 3 < blim) {
                     const char4 v = *(const char4*)p;
@@ -362,10 +382,37 @@ int i64h_gemm_f32_grouped(const float* A, const int32_t* a_src_row, const void* 
     const dim3 grid((unsigned)(m_tiles * n_tiles));
     hipStream_t st = (hipStream_t)stream;
 #define GF_LAUNCH(E, W) hipLaunchKernelGGL((gemm_f32_grouped_kernel<E, W>), grid, dim3(256), 0, st, A, a_src_row, B, b_row_scale, \
-                                           group_offsets, G, (int)M, N, K, C, c_row_map)
+                                           group_offsets, G, (int)M, N, K, C, c_row_map, (const float*)nullptr, 1)
     if (epilogue) { if (b_int8) GF_LAUNCH(1, 1); else GF_LAUNCH(1, 0); }
     else { if (b_int8) GF_LAUNCH(0, 1); else GF_LAUNCH(0, 0); }
 #undef GF_LAUNCH
+    I64H_CHECK_LAUNCH();
+    return 0;
+}
+
+// The grouped contraction on int4 weights (two per byte along N, high nibble first; fp32 scale and zero per group of group_size
+// consecutive columns of a weight row, [E][K][N / group_size]): w = (float(q) - zero) * scale while the tile is staged, then fp32 on
+// the f32 matrix cores.  Replaces the per-token weight gather + bmm and the per-expert loop of fused_token_routed_forward_int4
+// (vllm_i64/kernels/fused_experts.py:294-476).  Other arguments as i64h_gemm_f32_grouped.
+int i64h_gemm_w4_grouped(const float* A, const int32_t* a_src_row, const void* B, const float* b_scale, const float* b_zero,
+                         int32_t group_size, const int32_t* group_offsets, int32_t num_groups, int64_t M, int32_t N, int32_t K, float* C,
+                         const int32_t* c_row_map, int32_t epilogue, void* stream) {
+    I64H_CHECK_ARG(M >= 0 && M < (1ll << 31) && N > 0 && K > 0, "gemm_w4_grouped: bad sizes");
+    I64H_CHECK_ARG(num_groups >= 1 && num_groups <= 4096 && (group_offsets != nullptr || num_groups == 1), "gemm_w4_grouped: bad grouping");
+    I64H_CHECK_ARG(epilogue == 0 || (epilogue == 1 && N % 8 == 0), "gemm_w4_grouped: bad epilogue %d / N=%d (the SwiGLU form needs N %% 8 == 0)", epilogue, N);
+    I64H_CHECK_ARG(B && b_scale && b_zero, "gemm_w4_grouped: weights, scales and zeros are required");
+    I64H_CHECK_ARG(group_size > 0 && group_size % 4 == 0 && N % group_size == 0, "gemm_w4_grouped: N=%d must be a multiple of group_size=%d (a multiple of 4)", N, group_size);
+    if (M == 0) return 0;
+    const int G = group_offsets ? num_groups : 1;
+    const int n_tiles = epilogue ? (N / 2 + GF_BN / 2 - 1) / (GF_BN / 2) : (N + GF_BN - 1) / GF_BN;
+    const int64_t m_tiles = (M + GF_BM - 1) / GF_BM + G;
+    I64H_CHECK_ARG(m_tiles * n_tiles < (1ll << 31), "gemm_w4_grouped: grid too large");
+    const dim3 grid((unsigned)(m_tiles * n_tiles));
+    hipStream_t st = (hipStream_t)stream;
+    if (epilogue)
+        hipLaunchKernelGGL((gemm_f32_grouped_kernel<1, 2>), grid, dim3(256), 0, st, A, a_src_row, B, b_scale, group_offsets, G, (int)M, N, K, C, c_row_map, b_zero, (int)group_size);
+    else
+        hipLaunchKernelGGL((gemm_f32_grouped_kernel<0, 2>), grid, dim3(256), 0, st, A, a_src_row, B, b_scale, group_offsets, G, (int)M, N, K, C, c_row_map, b_zero, (int)group_size);
     I64H_CHECK_LAUNCH();
     return 0;
 }

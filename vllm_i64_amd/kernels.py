@@ -303,6 +303,75 @@ def fused_token_routed_forward_int8(x: torch.Tensor, gate_up_int8: torch.Tensor,
     return out.to(x.dtype)
 
 
+# ---- int4 weight-only path (vllm_i64/core/quantization.py:307-421, vllm_i64/kernels/fused_experts.py:294-476) -----------------
+def quantize_int4(weight: torch.Tensor, group_size: int = 128) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Per-group asymmetric int4 along the last dimension, two values per byte (high nibble first): (packed uint8 [out, in/2],
+    scale [out, groups], zero [out, groups]) as quantization.py:307-347.  A load-time operation: computed on the host in fp32 with
+    the reference's own expressions (a device division is not correctly rounded, which would move codes at ties), results returned
+    on the weight's device."""
+    out_f, in_f = weight.shape
+    if in_f % group_size != 0:
+        raise ValueError(f"INT4 quantize: in_features ({in_f}) not divisible by group_size ({group_size})")
+    w = weight.detach().to("cpu", torch.float32)
+    wg = w.reshape(out_f, in_f // group_size, group_size)
+    w_min, w_max = wg.amin(dim=-1), wg.amax(dim=-1)
+    scale = ((w_max - w_min) / 15.0).clamp(min=1e-8)
+    zero = (-w_min / scale).round().clamp(0, 15)
+    q = ((wg - w_min.unsqueeze(-1)) / scale.unsqueeze(-1)).round().clamp(0, 15).to(torch.uint8).reshape(out_f, -1)
+    packed = (q[:, 0::2] << 4) | q[:, 1::2]
+    dev = weight.device
+    return packed.to(dev), scale.to(dev), zero.to(dev)
+
+
+def dequantize_int4(packed: torch.Tensor, scale: torch.Tensor, zero: torch.Tensor, group_size: int = 128) -> torch.Tensor:
+    """[out, groups, group_size] fp32 = (nibble - zero) * scale (quantization.py:350-373); integer unpacking and two fp32 operations
+    per element, the same bits on any device."""
+    out_f, in_f = packed.shape[0], packed.shape[1] * 2
+    if in_f % group_size != 0:
+        raise ValueError(f"INT4 dequant: in_features ({in_f}) not divisible by group_size ({group_size})")
+    un = torch.stack([(packed >> 4) & 0xF, packed & 0xF], dim=-1).reshape(out_f, in_f)
+    return (un.reshape(out_f, in_f // group_size, group_size).float() - zero.unsqueeze(-1)) * scale.unsqueeze(-1)
+
+
+def int4_linear(x: torch.Tensor, packed: torch.Tensor, scale: torch.Tensor, zero: torch.Tensor, group_size: int = 128,
+                bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = x @ dequant(packed).T + bias in fp32 (quantization.py:376-421): the weight [out, in] is dequantized once per call, as the
+    reference does, and contracted on the f32 matrix cores."""
+    squeeze = x.dim() == 1
+    xf = _f32(x.reshape(-1, x.shape[-1]))
+    w = dequantize_int4(packed, scale, zero, group_size).reshape(packed.shape[0], -1).contiguous()
+    y = ops.gemm_f32(xf, w)
+    if bias is not None:
+        y = y + bias.float()
+    return y.squeeze(0) if squeeze else y.reshape(*x.shape[:-1], -1)
+
+
+def fused_token_routed_forward_int4(x: torch.Tensor, gate_up_int4: torch.Tensor, gate_up_scale: torch.Tensor, gate_up_zero: torch.Tensor,
+                                    down_int4: torch.Tensor, down_scale: torch.Tensor, down_zero: torch.Tensor, expert_ids: torch.Tensor,
+                                    num_experts: int, intermediate_per_tp: int, group_size: int = 128, bmm_threshold: int = 64) -> torch.Tensor:
+    """int4 weight-only expert MLP (fused_experts.py:294-476): gate_up_int4 uint8 [E, H, 2I/2] with scale / zero [E, H, 2I/group],
+    down_int4 [E, I, H/2] with scale / zero [E, I, H/group].  One stable grouping on the device and TWO launches for all experts
+    (i64h_gemm_w4_grouped): the weight tiles are dequantized while they are staged, the gather rides in the first launch with the
+    SwiGLU, the scatter back in the second; nothing returns to the host, so both of the reference's modes (per-token bmm up to
+    bmm_threshold rows, per-expert loop beyond) are this one capturable path."""
+    n = x.shape[0]
+    if n == 0:
+        return x
+    E, H, I = gate_up_int4.shape[0], gate_up_int4.shape[1], intermediate_per_tp
+    assert gate_up_int4.dtype == torch.uint8 and down_int4.dtype == torch.uint8
+    assert gate_up_int4.shape[2] * 2 == 2 * I and down_int4.shape[1] == I and down_int4.shape[2] * 2 == H
+    offsets, perm, _, _ = ops.bucketize(expert_ids.to(torch.int32).contiguous(), num_experts)
+    xf, gu, dn = _f32(x), gate_up_int4.contiguous(), down_int4.contiguous()
+    gs_, gz_, ds_, dz_ = _f32(gate_up_scale), _f32(gate_up_zero), _f32(down_scale), _f32(down_zero)
+    inter = torch.empty(n, I, dtype=torch.float32, device=x.device)
+    ops.call("i64h_gemm_w4_grouped", ops.ptr(xf), ops.ptr(perm), ops.ptr(gu), ops.ptr(gs_), ops.ptr(gz_), group_size, ops.ptr(offsets), E,
+             n, 2 * I, H, ops.ptr(inter), 0, 1, ops._stream())
+    out = torch.empty(n, H, dtype=torch.float32, device=x.device)
+    ops.call("i64h_gemm_w4_grouped", ops.ptr(inter), 0, ops.ptr(dn), ops.ptr(ds_), ops.ptr(dz_), group_size, ops.ptr(offsets), E, n, H, I,
+             ops.ptr(out), ops.ptr(perm), 0, ops._stream())
+    return out.to(x.dtype)
+
+
 # ---- operator-library pipeline (vllm_i64/kernels/i64_ops.py:17-193) -------------------------------------------------------
 def i64_route_tokens(token_ids: torch.Tensor, num_experts: int) -> torch.Tensor:
     """expert = token_id & (E - 1), int32 (i64_ops.py:17-34)."""
