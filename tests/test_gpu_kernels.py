@@ -737,3 +737,41 @@ def test_plan_with_embedding_rows_equals_the_two_launches(n):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
     assert torch.equal(h_a, h_b) and torch.equal(st_a, st_b)
     assert not torch.isnan(h_b).any() and int((st_b == 12345).sum()) == 0
+
+
+@pytest.mark.parametrize("nh,kv_dtype,splits", [(16, torch.bfloat16, 8), (16, torch.float32, 3), (16, torch.float8_e4m3fn, 4),
+                                                (16, torch.float16, 16)])
+def test_decode_attention_with_three_iterations_in_flight(dev, nh, kv_dtype, splits):
+    """Split launches with few rows keep the K/V rows of three iterations in flight per wave (stages past the context are issued on
+    clamped addresses and skipped): bit for bit the launch with one iteration in flight (row limit 0), and the oracle's cached
+    attention; contexts around the iteration and stage boundaries, rows in permuted slots."""
+    ops = _ops()
+    hd, kvh, block = 64, 4, 16
+    g = torch.Generator().manual_seed(nh * 31 + splits)
+    lens = [1, 63, 64, 65, 200, 1000, 2049, 130, 17, 7, 8, 9, 383, 385]
+    per = [(n + block - 1) // block for n in lens]
+    nblk = sum(per) + 3
+    kc = torch.empty(nblk, block, kvh, hd).normal_(0, 1, generator=g).to(kv_dtype)
+    vc = torch.empty(nblk, block, kvh, hd).normal_(0, 1, generator=g).to(kv_dtype)
+    perm = torch.randperm(nblk, generator=g).to(torch.int32)
+    slots = torch.randperm(len(lens), generator=g).to(torch.int32)          # row i reads block-table row slots[i]
+    bt = torch.full((len(lens), max(per) + 1), -1, dtype=torch.int32)
+    used = 0
+    for i, nb in enumerate(per):
+        bt[slots[i], :nb] = perm[used:used + nb]
+        used += nb
+    q = torch.empty(len(lens), nh, hd).normal_(0, 1, generator=g)
+    args = (q.to(dev), kc.to(dev), vc.to(dev), bt.to(dev), torch.tensor(lens, dtype=torch.int32, device=dev))
+    out = ops.paged_attn(*args, slot_ids=slots.to(dev), splits=splits).cpu()
+    ops.call("i64h_set_decode_attn_deep_rows", 0)
+    try:
+        plain = ops.paged_attn(*args, slot_ids=slots.to(dev), splits=splits).cpu()
+    finally:
+        ops.call("i64h_set_decode_attn_deep_rows", 32)
+    assert torch.equal(out, plain)
+    for i, c in enumerate(lens):
+        rows = bt[slots[i], :per[i]].long()
+        kf = kc[rows].reshape(-1, kvh, hd)[:c].float()
+        vf = vc[rows].reshape(-1, kvh, hd)[:c].float()
+        ref = M.cached_attention(q[i:i + 1], kf, vf, nh // kvh, torch.tensor([c - 1]), 1.0 / hd ** 0.5)[0]
+        torch.testing.assert_close(out[i], ref, rtol=1e-5, atol=3e-6)

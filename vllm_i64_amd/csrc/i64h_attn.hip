@@ -807,7 +807,7 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict
 #ifndef I64H_AH_PDU
 #define I64H_AH_PDU 4  // 8-dim chunks per lane requested together (PD_U = this / CH)
 #endif
-template <int HD, int KVH, int GS, int CH, int NW, typename KV>
+template <int HD, int KVH, int GS, int CH, int NW, typename KV, bool DEEP = false>
 __global__ __launch_bounds__(NW * 64) void paged_attn_allheads_kernel(const float* __restrict__ q, const KV* __restrict__ k_cache,
                                                                   const KV* __restrict__ v_cache, const int32_t* __restrict__ block_table,
                                                                   int max_blocks_per_seq, const int32_t* __restrict__ slot_ids,
@@ -875,6 +875,111 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_allheads_kernel(const floa
             pb[u] = bt[tc >> bsh];
         }
     };
+    if constexpr (DEEP) {
+    // Few rows (small batch): HBM is far from busy and a wave's iteration lasts one memory round trip, so three register stages keep
+    // the K/V rows of iterations i+1 and i+2 in flight during the math of iteration i; the block-table entries of a stage are
+    // requested two issues ahead of its rows, in front of the rows of the stage issued then, so that waiting for them (loads
+    // return in order) never waits for rows.  No branch surrounds a load - a stage past the context is issued on clamped
+    // addresses and only its math is skipped - which is what lets the compiler wait by count.  (At batch 64 the loop runs at the
+    // chip's copy rate already and this form measured 5 % slower from HBM: it is chosen by row count.)
+    struct Stage {
+        Raw8<KV> k[PD_U][CH], v[PD_U][CH];
+        int pb[PD_U];
+        bool live[PD_U];
+    };
+    Stage st0, st1, st2;
+    auto issue = [&](Stage& sg, Stage& ahead, int t0) {
+        fetch_blocks(t0 + 2 * stride, ahead.pb);
+#pragma unroll
+        for (int u = 0; u < PD_U; ++u) {
+            const int t = t0 + u * TPS + tl;
+            const int tc = max(0, min(t, t_end - 1));
+            const int pb = sg.pb[u];
+            sg.live[u] = t < t_end && pb >= 0;
+            const int64_t off = ((int64_t)max(pb, 0) * block + (tc & (block - 1))) * (KVH * HD) + lane_off;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                sg.k[u][j].load(k_cache + off + cdim(j));
+                sg.v[u][j].load(v_cache + off + cdim(j));
+            }
+        }
+    };
+    auto compute = [&](Stage& sg) {
+        float s[PD_U][GS], msafe[GS];
+#pragma unroll
+        for (int u = 0; u < PD_U; ++u) {
+            float kf[CH][8];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) sg.k[u][j].get(kf[j]);
+            const float dead = sg.live[u] ? 0.0f : -INFINITY;
+#pragma unroll
+            for (int h = 0; h < GS; ++h) {
+                v2f a2 = (v2f){0.0f, 0.0f};
+#pragma unroll
+                for (int j = 0; j < CH; ++j)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) a2 = __builtin_elementwise_fma(qr[h][j][d], (v2f){kf[j][2 * d], kf[j][2 * d + 1]}, a2);
+                float a = a2.x + a2.y;
+                a = group_sum(a, CPH);
+                s[u][h] = __builtin_fmaf(a, sl2, dead);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < GS; ++h) {
+            float mx = s[0][h];
+#pragma unroll
+            for (int u = 1; u < PD_U; ++u) mx = fmaxf(mx, s[u][h]);
+            const float mn = fmaxf(m[h], mx);
+            const float alpha = (mn == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m[h] - mn);
+            m[h] = mn;
+            msafe[h] = (mn == -INFINITY) ? 0.0f : mn;
+            l[h] *= alpha;
+#pragma unroll
+            for (int j = 0; j < CH; ++j)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) acc[h][j][d] *= alpha;
+        }
+#pragma unroll
+        for (int u = 0; u < PD_U; ++u) {
+            float vf[CH][8];
+#pragma unroll
+            for (int j = 0; j < CH; ++j) sg.v[u][j].get(vf[j]);
+#pragma unroll
+            for (int h = 0; h < GS; ++h) {
+                const float p = __builtin_amdgcn_exp2f(s[u][h] - msafe[h]);
+                l[h] += p;
+#pragma unroll
+                for (int j = 0; j < CH; ++j)
+#pragma unroll
+                    for (int d = 0; d < 4; ++d)
+                        acc[h][j][d] = __builtin_elementwise_fma((v2f){p, p}, (v2f){vf[j][2 * d], vf[j][2 * d + 1]}, acc[h][j][d]);
+            }
+        }
+    };
+    const int t_first = t_begin + wid * TPI;
+    {
+        bool beyond = false;
+#pragma unroll
+        for (int u = 0; u < PD_U; ++u) {
+            const int t = t_first + u * TPS + tl;
+            st0.pb[u] = bt[min(t >> bsh, max_blocks_per_seq - 1)];
+            beyond |= t >= t_end;
+        }
+        if (__any(beyond)) fetch_blocks(t_first, st0.pb);
+        fetch_blocks(t_first + stride, st1.pb);
+    }
+    issue(st0, st2, t_first);
+    issue(st1, st0, t_first + stride);
+    PA_STAMP(1);
+    for (int t0 = t_first; t0 < t_end; t0 += 3 * stride) {
+        issue(st2, st1, t0 + 2 * stride);
+        compute(st0);
+        issue(st0, st2, t0 + 3 * stride);
+        if (t0 + stride < t_end) compute(st1);
+        issue(st1, st0, t0 + 4 * stride);
+        if (t0 + 2 * stride < t_end) compute(st2);
+    }
+    } else {
     // the K/V rows of iteration i+1 are requested before the math of iteration i (and the block-table entries one
     // iteration before that), so the loop never waits for a whole memory round trip
     int pbn[PD_U];
@@ -971,6 +1076,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_allheads_kernel(const floa
                         acc[h][j][d] = __builtin_elementwise_fma((v2f){p, p}, (v2f){vf[j][2 * d], vf[j][2 * d + 1]}, acc[h][j][d]);
             }
         }
+    }
     }
     PA_STAMP(2);
     // merge the token lanes (same kv head and chunk, each with its own running maximum), then the waves through LDS
@@ -1085,6 +1191,7 @@ static int dispatch_gs(int gs, int kv_dtype, const float* q, const void* kc, con
 
 #define PF_MIN_ROWS 256      // from this many rows on, the 16-row-tile matrix-core kernel is used (splits == 1, head_dim 64)
 static unsigned long long* g_attn_stamps = nullptr;  // diagnostics, see i64h_debug_set_attn_stamps
+static int g_decode_deep_rows = 32;  // split launches of at most this many rows keep the K/V rows of three iterations in flight per wave; 0 = never
 static int g_prefill_mfma = 1;  // tuning / test knob: 0 = always the row-per-workgroup kernel, 1 = matrix cores (bf16 caches: three-term bf16 form), 2 = f32 matrix cores for every cache dtype
 #define ATTN_ARRIVALS 4096  // rows whose splits can be merged by the last-arriving workgroup
 
@@ -1102,6 +1209,12 @@ int64_t i64h_paged_attn_workspace_floats(int64_t rows, int32_t num_heads, int32_
 // 5 merge stored - last-arriving workgroup only); every launch overwrites it; NULL switches it off
 int i64h_debug_set_attn_stamps(void* buffer) {
     g_attn_stamps = (unsigned long long*)buffer;
+    return 0;
+}
+
+int i64h_set_decode_attn_deep_rows(int32_t rows) {
+    I64H_CHECK_ARG(rows >= 0, "set_decode_attn_deep_rows: negative");
+    g_decode_deep_rows = rows;
     return 0;
 }
 
@@ -1175,10 +1288,15 @@ int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, in
 #endif
     bool done = false;
     const bool bp2 = block_size > 0 && (block_size & (block_size - 1)) == 0;  // other block sizes take the per-head kernel
-#define AH_T(HD_, KVH_, GS_, CH_, NW_, T)                                                                                            \
-    hipLaunchKernelGGL((paged_attn_allheads_kernel<HD_, KVH_, GS_, CH_, NW_, T>), grid, dim3(NW_ * 64), 0, st, q, (const T*)k_cache, (const T*)v_cache, \
+#define AH_L(HD_, KVH_, GS_, CH_, NW_, T, D_)                                                                                        \
+    hipLaunchKernelGGL((paged_attn_allheads_kernel<HD_, KVH_, GS_, CH_, NW_, T, D_>), grid, dim3(NW_ * 64), 0, st, q, (const T*)k_cache, (const T*)v_cache, \
                        block_table, max_blocks_per_seq, slot_ids, ctx_len, softmax_scale, out, part_o, part_ml, block_size, splits,      \
                        arrivals, stats, stat_slot, g_attn_stamps)
+#define AH_T(HD_, KVH_, GS_, CH_, NW_, T)                                               \
+    do {                                                                               \
+        if (HD_ == 64 && rows <= g_decode_deep_rows) AH_L(HD_, KVH_, GS_, CH_, NW_, T, (HD_ == 64)); \
+        else AH_L(HD_, KVH_, GS_, CH_, NW_, T, false);                                 \
+    } while (0)
 #define AH(HD_, KVH_, GS_, CH_, NW_)                                                                \
     if (!done && splits > 1 && bp2 && head_dim == HD_ && num_kv_heads == KVH_ && gs == GS_) {     \
         dim3 grid((unsigned)rows, (unsigned)splits);                                              \
@@ -1196,6 +1314,7 @@ int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, in
     AH(128, 4, 2, 1, 4)
 #undef AH
 #undef AH_T
+#undef AH_L
     if (!done) {
 #define GO(H) rc = dispatch_gs<H>(gs, kv_dtype, q, k_cache, v_cache, block_table, max_blocks_per_seq, slot_ids, ctx_len, softmax_scale, out, part_o, part_ml, (int)rows, num_heads, num_kv_heads, block_size, splits, st)
     switch (head_dim) {
