@@ -116,7 +116,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         ndev = torch.cuda.device_count()
-        if ndev < args.gpus:
+        if ndev < args.gpus and os.environ.get("I64_BENCH_SHARE_GPU") != "1":
             raise SystemExit(f"bench.py --gpus {args.gpus}: this machine shows {ndev} GPU(s)")
         raise SystemExit(self_launch(args))
     if world != args.gpus:
@@ -128,6 +128,12 @@ def main():
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
+    # rehearsal of the N > 1 code path on a one-GPU box: I64_BENCH_SHARE_GPU=1 puts every rank on cuda:0, I64_BENCH_BACKEND=gloo
+    # exchanges through the host (no collective can be captured then: use --no-graph).  Never a measurement.
+    share_gpu = os.environ.get("I64_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("I64_BENCH_BACKEND", "nccl")
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     dist = None
@@ -135,7 +141,10 @@ def main():
         import torch.distributed as dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist_.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if backend == "nccl":
+            dist_.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist_.init_process_group(backend, rank=rank, world_size=world)
         dist = dist_
 
     from vllm_i64_amd import _lib, ops, synth
