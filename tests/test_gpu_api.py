@@ -235,7 +235,7 @@ def test_moe_forward_c_entry_matches_oracle_both_paths(dev):
         ids = torch.randint(0, ocfg.vocab_size, (n,), generator=g)
         ref = M.moe_forward(ocfg, bank, 1, x, ids).numpy()
         y = layer(x.to(dev), ids.to(dev)).cpu().numpy()
-        # single quantized Linears may flip one LSB on an fp32-rounding tie of the SwiGLU output; bound from the survey's protocol
+        # single quantized Linears may flip one LSB on an fp32-rounding tie of the SwiGLU output; bound: one quantization step of the layer output
         assert np.abs(y - ref).max() <= 1e-2, (n, np.abs(y - ref).max())
         assert np.abs(y - ref).mean() <= 1e-5, (n, np.abs(y - ref).mean())
 

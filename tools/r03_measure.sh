@@ -1,4 +1,4 @@
-# Round-3 measurement set on the GPU box: the default bench line, its rocprofv3 kernel summary, the HBM counter passes, and the side
+# Measurement set on the GPU box: the default bench line, its rocprofv3 kernel summary, the HBM counter passes, and the side
 # configurations.  usage (from the repository root on the box): bash tools/r03_measure.sh     (results under gpurun_out/r03/)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r03
