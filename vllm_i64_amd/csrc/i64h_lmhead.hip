@@ -7,21 +7,17 @@
 // products whose weight is at least 2^-16 of the leading one (hi.hi, hi.mid, mid.hi, mid.mid, hi.lo, lo.hi) run on
 // v_mfma_f32_16x16x32_bf16 (16 cycles for 32 deep): 96 instead of 256 matrix-core cycles per 32-deep step, fp32 accumulation.  The
 // dropped products are below 2^-24 of the leading one, the rounding of one fp32 multiply.
-// The activation rows (few, shared by every workgroup) are cut once by a small kernel into three bf16 planes, stored step by step
-// in the order the main kernel stages them; the weight rows, each used by one wave of one workgroup only, are cut in registers.
-// Workgroup = 64 rows x 64 vocabulary columns, 4 waves; wave w owns columns [16 w, 16 w + 16) and all four row fragments, so no
-// weight element is loaded or cut twice.
+// The activation rows (few, shared by every workgroup) are cut once by a small kernel into three bf16 planes, stored as the
+// matrix-core fragments themselves; the weight rows, each used by one wave of one workgroup only, are cut in registers.
 // Weight rows are K-major and the matrix-core operand wants lane = column: loading them in operand order makes every lane of a
-// load instruction its own 16-byte request (64 requests per instruction, the address path's limit long before HBM's).  So a wave
-// loads its 16 rows in memory order - half a wave on 512 contiguous bytes of one row - passes them through a private LDS strip
-// and reads them back in operand order.
+// load instruction its own 16-byte request (64 requests per instruction, the address path's limit long before HBM's: measured
+// 47-50 us whatever the prefetch depth).  So a wave loads weight rows in memory order and turns them into operand order through
+// a private LDS strip.  A branch around a load makes the compiler wait for ALL loads in flight (it can no longer count them):
+// every load here is unconditional, on clamped addresses.
 #include "i64h_common.h"
 
 typedef float lm_v4f __attribute__((ext_vector_type(4)));
 typedef __bf16 lm_v8b __attribute__((ext_vector_type(8)));
-
-#define LM_LD 48   // activation planes: LDS row stride in bf16 elements (96 bytes: ds_read_b128 of 16 rows x 4 k groups without bank conflicts)
-#define LM_WLD 136 // weight strip: LDS row stride in floats (544 bytes, conflict-free for the same read)
 
 __device__ __forceinline__ uint32_t lm_top(float x, float y) { return __builtin_amdgcn_perm(__float_as_uint(y), __float_as_uint(x), 0x07060302u); }
 __device__ __forceinline__ void lm_split_pair(float x, float y, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
@@ -32,10 +28,18 @@ __device__ __forceinline__ void lm_split_pair(float x, float y, uint32_t& hi, ui
     lo = lm_top(xl, yl);
 }
 
-// planes[row tile][K step][p][row in tile][32 k] as bf16, p = hi / mid / lo; rows past M and k past K are zero: one K step of a
-// 64-row tile is 12 contiguous KB
-__global__ __launch_bounds__(256) void lm_split_rows_kernel(const float* __restrict__ A, const int32_t* __restrict__ a_rows, uint32_t* __restrict__ planes,
-                                                            int M, int K, int Kpad) {
+// ---- K split over the waves of a workgroup -------------------------------------------------------------------------------------
+// Wave w of a workgroup (64 rows x 64 vocabulary columns) contracts the w-th quarter of K for the WHOLE tile: its activation
+// fragments come straight from L2 in matrix-core lane order (the split kernel writes them that way: one fragment = 1 KB of
+// consecutive bytes), each used for four column fragments, so the activation planes never pass through LDS and the main loop has
+// no workgroup barrier; its weight rows arrive in memory order (128-byte pieces, 8 lanes per row) and turn into operand order in
+// a wave-private LDS strip.  The four partial tiles are summed through LDS at the end, in wave order.
+#define LMK_LD 40  // strip row stride in floats (conflict-free for the operand-order ds_read_b128)
+
+// planes in fragment order: [row tile][K step][p][row fragment i][lane (fr, fq)][8 bf16], element e of the lane = k 4 fq + e (e < 4),
+// 16 + 4 fq + (e - 4) (e >= 4) of row 16 i + fr
+__global__ __launch_bounds__(256) void lm_split_rows_frag_kernel(const float* __restrict__ A, const int32_t* __restrict__ a_rows, uint32_t* __restrict__ planes,
+                                                                 int M, int K, int Kpad) {
     const int r = blockIdx.x;
     const int64_t src = r < M ? (a_rows ? a_rows[r] : r) : 0;
     const float2* x = (const float2*)(A + src * K);
@@ -46,111 +50,122 @@ __global__ __launch_bounds__(256) void lm_split_rows_kernel(const float* __restr
             const float2 v = x[i];
             lm_split_pair(v.x, v.y, hi, mid, lo);
         }
-        // inside a 32 deep step the plane holds k in the order the main kernel's weight reads deliver it: position
-        // 8 q + e <- k = 4 q + e (e < 4), 16 + 4 q + (e - 4) (e >= 4); a pair (2 i, 2 i + 1) stays a pair
         const int blk = i & 15, q = (blk & 7) >> 1, e2 = (blk & 1) + 2 * (blk >> 3);
-        const int64_t o = ((int64_t)(r >> 6) * KTP + (i >> 4)) * (3 * 64 * 16) + (r & 63) * 16 + q * 4 + e2;
+        const int64_t frag = ((int64_t)(r >> 6) * KTP + (i >> 4)) * 12 + ((r & 63) >> 4);  // + 4 p
+        const int64_t o = (frag * 64 + q * 16 + (r & 15)) * 4 + e2;
         planes[o] = hi;
-        planes[o + 64 * 16] = mid;
-        planes[o + 2 * 64 * 16] = lo;
+        planes[o + 4 * 256] = mid;
+        planes[o + 8 * 256] = lo;
     }
 }
 
-__global__ __launch_bounds__(256) void lm_head_bf16x3_kernel(const uint32_t* __restrict__ planes, const float* __restrict__ B, float* __restrict__ C,
-                                                             int M, int N, int K, int Kpad) {
-    __shared__ __attribute__((aligned(16))) uint16_t sA[2][3][64][LM_LD];
-    __shared__ __attribute__((aligned(16))) float sW[4][16][LM_WLD];
+__global__ __launch_bounds__(256, 2) void lm_head_bf16x3_ks_kernel(const uint32_t* __restrict__ planes, const float* __restrict__ B, float* __restrict__ C,
+                                                                   int M, int N, int K, int Kpad) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * 64 * 64];  // strips (4 x 64 x LMK_LD floats) during the loop, the partial tiles after it
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-    const int col = n0 + wid * 16 + fr;
-    const int KT = K / 32, KTP = Kpad / 32, KQ = (K + 127) / 128;  // 128-float quarters of a padded row that hold any data
-    // weight loads: instruction j takes rows 2 j and 2 j + 1 of the wave's 16, 512 contiguous bytes each (four K steps)
-    const int wr = lane >> 5, wc = (lane & 31) * 4;
-    const float* bp = B + wc;
-    int64_t wrow[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) wrow[j] = (int64_t)min(n0 + wid * 16 + 2 * j + wr, N - 1) * K;
-    const int wc_ok = K - 4;  // a quarter that straddles K re-reads the row's last four floats (the planes are zero there)
-    // staging of the activation planes: thread -> 16 bytes of each plane of one K step (row tid / 4, k group tid % 4)
-    const int ar = tid >> 2, ak = (tid & 3) * 8;
-    const char* pa = (const char*)planes + (int64_t)blockIdx.y * KTP * (3 * 4096) + tid * 16;
-    lm_v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-    // The loop has NO branch around a load: with one the compiler can no longer count the loads in flight and waits for all of
-    // them at every step.  Requests past the end re-read the last step / quarter; the planes are zero-padded to Kpad.
-    uint4 p0a, p0b, p0c, p1a, p1b, p1c, p2a, p2b, p2c, p3a, p3b, p3c;  // set (kt + 1) % 4 goes into LDS at the end of step kt, re-requested for kt + 5
-    float4 g0, g1, g2, g3, g4, g5, g6, g7;                            // the wave's 16 x 128 weight values of the next four steps
-#define LM_ALOAD(kt, R0, R1, R2) do { const int64_t o_ = (int64_t)min((kt), KTP - 1) * (3 * 4096); R0 = *(const uint4*)(pa + o_); \
-                                      R1 = *(const uint4*)(pa + o_ + 4096); R2 = *(const uint4*)(pa + o_ + 8192); } while (0)
-#define LM_ASTORE(buf, R0, R1, R2) do { *(uint4*)&sA[buf][0][ar][ak] = R0; *(uint4*)&sA[buf][1][ar][ak] = R1; *(uint4*)&sA[buf][2][ar][ak] = R2; } while (0)
-#define LM_GLOAD(kq) do { const int o_ = min(min((kq), KQ - 1) * 128 + wc, wc_ok) - wc;                                              \
-        g0 = *(const float4*)(bp + wrow[0] + o_); g1 = *(const float4*)(bp + wrow[1] + o_); g2 = *(const float4*)(bp + wrow[2] + o_); \
-        g3 = *(const float4*)(bp + wrow[3] + o_); g4 = *(const float4*)(bp + wrow[4] + o_); g5 = *(const float4*)(bp + wrow[5] + o_); \
-        g6 = *(const float4*)(bp + wrow[6] + o_); g7 = *(const float4*)(bp + wrow[7] + o_); } while (0)
-#define LM_GSTORE() do {                                                                                            \
-        __builtin_amdgcn_wave_barrier();                                                                            \
-        *(float4*)&sW[wid][0 + wr][wc] = g0; *(float4*)&sW[wid][2 + wr][wc] = g1; *(float4*)&sW[wid][4 + wr][wc] = g2; \
-        *(float4*)&sW[wid][6 + wr][wc] = g3; *(float4*)&sW[wid][8 + wr][wc] = g4; *(float4*)&sW[wid][10 + wr][wc] = g5; \
-        *(float4*)&sW[wid][12 + wr][wc] = g6; *(float4*)&sW[wid][14 + wr][wc] = g7;                                  \
-        __builtin_amdgcn_wave_barrier();                                                                            \
-    } while (0)
-#define LM_MFMA6(ACC, i, cur)                                                                                      \
-    do {                                                                                                           \
-        const lm_v8b a1 = __builtin_bit_cast(lm_v8b, *(const uint4*)&sA[cur][0][(i) * 16 + fr][fq * 8]);           \
-        const lm_v8b a2 = __builtin_bit_cast(lm_v8b, *(const uint4*)&sA[cur][1][(i) * 16 + fr][fq * 8]);           \
-        const lm_v8b a3 = __builtin_bit_cast(lm_v8b, *(const uint4*)&sA[cur][2][(i) * 16 + fr][fq * 8]);           \
-        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b1, ACC, 0, 0, 0); /* small terms first */              \
-        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b3, ACC, 0, 0, 0);                                       \
-        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, ACC, 0, 0, 0);                                       \
-        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1, ACC, 0, 0, 0);                                       \
-        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, ACC, 0, 0, 0);                                       \
-        ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, ACC, 0, 0, 0);                                       \
-    } while (0)
-    // K step kt (step s of its group of four) out of the weight strip and LDS buffer cur; R0..R2 hold the planes of step kt + 1
-#define LM_STEP(kt, s, cur, R0, R1, R2)                                                                            \
-    do {                                                                                                           \
-        const float4 w0 = *(const float4*)&sW[wid][fr][(s) * 32 + fq * 4], w1 = *(const float4*)&sW[wid][fr][(s) * 32 + 16 + fq * 4]; \
-        uint4 bh, bm, bl;                                                                                          \
-        lm_split_pair(w0.x, w0.y, bh.x, bm.x, bl.x);                                                               \
-        lm_split_pair(w0.z, w0.w, bh.y, bm.y, bl.y);                                                               \
-        lm_split_pair(w1.x, w1.y, bh.z, bm.z, bl.z);                                                               \
-        lm_split_pair(w1.z, w1.w, bh.w, bm.w, bl.w);                                                               \
-        const lm_v8b b1 = __builtin_bit_cast(lm_v8b, bh), b2 = __builtin_bit_cast(lm_v8b, bm), b3 = __builtin_bit_cast(lm_v8b, bl); \
-        LM_MFMA6(acc0, 0, cur); LM_MFMA6(acc1, 1, cur); LM_MFMA6(acc2, 2, cur); LM_MFMA6(acc3, 3, cur);            \
-        LM_ASTORE((cur) ^ 1, R0, R1, R2);                                                                          \
-        LM_ALOAD((kt) + 5, R0, R1, R2);                                                                            \
-        __syncthreads();                                                                                           \
-    } while (0)
-    LM_ALOAD(0, p0a, p0b, p0c);
-    LM_GLOAD(0);
-    LM_ALOAD(1, p1a, p1b, p1c); LM_ALOAD(2, p2a, p2b, p2c); LM_ALOAD(3, p3a, p3b, p3c);
-    LM_ASTORE(0, p0a, p0b, p0c);
-    LM_ALOAD(4, p0a, p0b, p0c);
-    __syncthreads();
-    for (int kt = 0; kt < KTP; kt += 4) {
-        LM_GSTORE();
-        LM_GLOAD((kt >> 2) + 1);
-        LM_STEP(kt, 0, 0, p1a, p1b, p1c);
-        LM_STEP(kt + 1, 1, 1, p2a, p2b, p2c);
-        LM_STEP(kt + 2, 2, 0, p3a, p3b, p3c);
-        LM_STEP(kt + 3, 3, 1, p0a, p0b, p0c);
-    }
-#undef LM_STEP
-#undef LM_MFMA6
-#undef LM_GSTORE
-#undef LM_GLOAD
-#undef LM_ASTORE
-#undef LM_ALOAD
-    (void)KT;
-    if (col >= N) return;
-    const lm_v4f accs[4] = {acc0, acc1, acc2, acc3};
+    const int KT = K / 32, KTP = Kpad / 32, S = KTP / 4;  // S steps per wave (Kpad is a multiple of 256)
+    const int k_first = wid * S;
+    float* strip = smem + wid * (64 * LMK_LD);
+    // weight loads: instruction j takes rows 8 j .. 8 j + 7 of the tile, 128 contiguous bytes each (one K step)
+    const int wr = lane >> 3, wc = (lane & 7) * 4;
+#define LMK_ROW(j) const int64_t wrow##j = (int64_t)min(n0 + 8 * j + wr, N - 1) * K + wc
+    LMK_ROW(0); LMK_ROW(1); LMK_ROW(2); LMK_ROW(3); LMK_ROW(4); LMK_ROW(5); LMK_ROW(6); LMK_ROW(7);
+#undef LMK_ROW
+    const uint4* ap = (const uint4*)planes + ((int64_t)blockIdx.y * KTP * 12) * 64 + lane;  // fragment f of step kt: ap[(kt * 12 + f) * 64]
+    lm_v4f acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int r = m0 + i * 16 + fq * 4 + reg;
-            if (r < M) C[(int64_t)r * N + col] = accs[i][reg];
-        }
+        for (int c = 0; c < 4; ++c) acc[i][c] = (lm_v4f){0.f, 0.f, 0.f, 0.f};
+    float4 g0, g1, g2, g3, g4, g5, g6, g7;
+    // no branch around a load (the waits are counted): steps past the wave's share re-read its last step, steps past K read the
+    // row's last step against zero planes
+#define LMK_W1(j, kt_) g##j = *(const float4*)(B + wrow##j + (kt_) * 32)
+#define LMK_WLOAD(s_)                                                                                               \
+    do {                                                                                                           \
+        const int kt_ = min(k_first + min((s_), S - 1), KT - 1);                                                   \
+        LMK_W1(0, kt_); LMK_W1(1, kt_); LMK_W1(2, kt_); LMK_W1(3, kt_); LMK_W1(4, kt_); LMK_W1(5, kt_); LMK_W1(6, kt_); LMK_W1(7, kt_); \
+    } while (0)
+#define LMK_ALOAD(s_, A_)                                                                                          \
+    do {                                                                                                           \
+        const int64_t kt_ = k_first + min((s_), S - 1);                                                            \
+        _Pragma("unroll") for (int f = 0; f < 12; ++f) A_[f] = ap[(kt_ * 12 + f) * 64];                            \
+    } while (0)
+#define LMK_S1(j) *(float4*)&strip[(8 * j + wr) * LMK_LD + wc] = g##j
+#define LMK_WSTORE()                                                                                               \
+    do {                                                                                                           \
+        __builtin_amdgcn_wave_barrier();                                                                           \
+        LMK_S1(0); LMK_S1(1); LMK_S1(2); LMK_S1(3); LMK_S1(4); LMK_S1(5); LMK_S1(6); LMK_S1(7);                    \
+        __builtin_amdgcn_wave_barrier();                                                                           \
+    } while (0)
+#define LMK_STEP(A_)                                                                                               \
+    do {                                                                                                           \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                            \
+            const float4 w0 = *(const float4*)&strip[(16 * c + fr) * LMK_LD + fq * 4];                             \
+            const float4 w1 = *(const float4*)&strip[(16 * c + fr) * LMK_LD + 16 + fq * 4];                        \
+            uint4 bh, bm, bl;                                                                                      \
+            lm_split_pair(w0.x, w0.y, bh.x, bm.x, bl.x);                                                           \
+            lm_split_pair(w0.z, w0.w, bh.y, bm.y, bl.y);                                                           \
+            lm_split_pair(w1.x, w1.y, bh.z, bm.z, bl.z);                                                           \
+            lm_split_pair(w1.z, w1.w, bh.w, bm.w, bl.w);                                                           \
+            const lm_v8b b1 = __builtin_bit_cast(lm_v8b, bh), b2 = __builtin_bit_cast(lm_v8b, bm), b3 = __builtin_bit_cast(lm_v8b, bl); \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                        \
+                const lm_v8b a1 = __builtin_bit_cast(lm_v8b, A_[i]), a2 = __builtin_bit_cast(lm_v8b, A_[4 + i]),   \
+                             a3 = __builtin_bit_cast(lm_v8b, A_[8 + i]);                                           \
+                lm_v4f t = acc[i][c];                                                                              \
+                t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b1, t, 0, 0, 0); /* small terms first */           \
+                t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b3, t, 0, 0, 0);                                   \
+                t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, t, 0, 0, 0);                                   \
+                t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1, t, 0, 0, 0);                                   \
+                t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, t, 0, 0, 0);                                   \
+                t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, t, 0, 0, 0);                                   \
+                acc[i][c] = t;                                                                                     \
+            }                                                                                                      \
+        }                                                                                                          \
+    } while (0)
+    uint4 afa[12], afb[12];
+    LMK_WLOAD(0);
+    LMK_ALOAD(0, afa);
+    LMK_WSTORE();
+    LMK_WLOAD(1);
+    for (int s = 0; s < S; s += 2) {
+        LMK_ALOAD(s + 1, afb);
+        LMK_STEP(afa);
+        LMK_WSTORE();      // step s + 1's weight rows (in registers since the previous step) replace step s's in the strip
+        LMK_WLOAD(s + 2);
+        LMK_ALOAD(s + 2, afa);
+        LMK_STEP(afb);
+        LMK_WSTORE();
+        LMK_WLOAD(s + 3);
+    }
+#undef LMK_STEP
+#undef LMK_WSTORE
+#undef LMK_ALOAD
+#undef LMK_WLOAD
+#undef LMK_W1
+#undef LMK_S1
+    // the four partial tiles through LDS (the strips are dead: every wave is past its last read once the barrier is passed)
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) smem[(wid * 64 + i * 16 + fq * 4 + reg) * 64 + c * 16 + fr] = acc[i][c][reg];
+    __syncthreads();
+    for (int e = tid; e < 64 * 16; e += 256) {  // four consecutive columns per thread
+        const int r = e >> 4, c4 = (e & 15) * 4;
+        if (m0 + r >= M) continue;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ((smem[(0 * 64 + r) * 64 + c4 + j] + smem[(1 * 64 + r) * 64 + c4 + j]) + smem[(2 * 64 + r) * 64 + c4 + j]) + smem[(3 * 64 + r) * 64 + c4 + j];
+        float* cp = C + (int64_t)(m0 + r) * N + n0 + c4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (n0 + c4 + j < N) cp[j] = v[j];
+    }
 }
 
 extern "C" {
@@ -166,9 +181,9 @@ int i64h_lm_head(const float* A, const int32_t* a_rows, const float* B, float* C
     if (M == 0) return 0;
     const int Mpad = (int)((M + 63) / 64 * 64), Kpad = (K + 255) / 256 * 256;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(lm_split_rows_kernel, dim3((unsigned)Mpad), dim3(256), 0, st, A, a_rows, (uint32_t*)workspace, (int)M, (int)K, Kpad);
+    hipLaunchKernelGGL(lm_split_rows_frag_kernel, dim3((unsigned)Mpad), dim3(256), 0, st, A, a_rows, (uint32_t*)workspace, (int)M, (int)K, Kpad);
     I64H_CHECK_LAUNCH();
-    hipLaunchKernelGGL(lm_head_bf16x3_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)(Mpad / 64)), dim3(256), 0, st, (const uint32_t*)workspace, B, C,
+    hipLaunchKernelGGL(lm_head_bf16x3_ks_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)(Mpad / 64)), dim3(256), 0, st, (const uint32_t*)workspace, B, C,
                        (int)M, (int)N, (int)K, Kpad);
     I64H_CHECK_LAUNCH();
     return 0;
