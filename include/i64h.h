@@ -227,6 +227,9 @@ int i64h_gemm_f32(const float* A, const int32_t* a_rows, const float* B, float* 
  * (16-byte aligned) for the activation rows' three planes.  K % 32 == 0. */
 int64_t i64h_lm_head_workspace_bytes(int64_t M, int32_t K);
 int i64h_lm_head(const float* A, const int32_t* a_rows, const float* B, float* C, int64_t M, int32_t N, int32_t K, void* workspace, void* stream);
+/* The same product on activation planes already in the workspace (written by i64h_fused_residual_norm_lm, rows 0 .. M - 1 in order):
+ * the main launch only - the row split launch is saved. */
+int i64h_lm_head_planes(const void* workspace, const float* B, float* C, int64_t M, int32_t N, int32_t K, void* stream);
 /* Grouped float expert contraction in one launch: C[r, :] = A[a_src_row ? a_src_row[r] : r, :K] @ B[g][:K, :N] for the rows
  * r in [group_offsets[g], group_offsets[g + 1]) (device offsets, NULL = one group), stored at row c_row_map ? c_row_map[r] : r.
  * B in the reference's expert layout [E][K][N] (gate_up_proj [E, H, 2I], down_proj [E, I, H]), fp32 (b_int8 = 0) or int8 with
@@ -425,6 +428,13 @@ int i64h_fused_residual_norm(const float* h, const float* add, const float* moe_
                              const float* route_weights, int32_t top_k, float routed_scale, float shared_scale, float* h_out,
                              const float* norm_weight, float eps, float* normed, int64_t n, int32_t H, const int32_t* slots,
                              int32_t slots_per_row, int32_t slot_base, uint32_t* stats, void* stream);
+/* i64h_fused_residual_norm that also writes the normalised rows as the activation planes of i64h_lm_head_planes (final norm of a
+ * decode-sized step, model.py:433-437): lm_workspace = i64h_lm_head_workspace_bytes(n, H) bytes, zeroed ONCE by the caller;
+ * H % 32 == 0, n <= 2048. */
+int i64h_fused_residual_norm_lm(const float* h, const float* add, const float* moe_rows, const int32_t* moe_inv, const float* moe_shared,
+                                const float* route_weights, int32_t top_k, float routed_scale, float shared_scale, float* h_out,
+                                const float* norm_weight, float eps, float* normed, int64_t n, int32_t H, const int32_t* slots,
+                                int32_t slots_per_row, int32_t slot_base, uint32_t* stats, void* lm_workspace, void* stream);
 /* The same residual update + norm, with the per-call quantization of the Linear calls that read the normalised rows folded in
  * (the rows of DynamicInt8Linear.forward's _quantize_activations, vllm_i64/core/loader.py:57-76, for every call fed by this
  * norm): one launch of co-resident workgroups with a grid barrier between "ranges of all rows known" and "rows quantized", so

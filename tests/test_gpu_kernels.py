@@ -775,3 +775,26 @@ def test_decode_attention_with_three_iterations_in_flight(dev, nh, kv_dtype, spl
         vf = vc[rows].reshape(-1, kvh, hd)[:c].float()
         ref = M.cached_attention(q[i:i + 1], kf, vf, nh // kvh, torch.tensor([c - 1]), 1.0 / hd ** 0.5)[0]
         torch.testing.assert_close(out[i], ref, rtol=1e-5, atol=3e-6)
+
+
+@pytest.mark.parametrize("n,H", [(64, 1024), (5, 256), (130, 96)])
+def test_final_norm_writes_the_lm_head_planes(dev, n, H):
+    """fused_residual_norm(..., lm_workspace) + lm_head_planes against fused_residual_norm + lm_head: the same logits bit for bit (the
+    planes are cut from the same fp32 values, in the lm_head's fragment order), the normalised rows and the residual stream unchanged;
+    row counts that do not fill a 64-row tile, a K that is padded to 256."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(n + H)
+    V = 777
+    h = torch.randn(n, H, generator=g).to(dev)
+    add = torch.randn(n, H, generator=g).to(dev)
+    w = (1.0 + 0.1 * torch.randn(H, generator=g)).to(dev)
+    embed = (0.05 * torch.randn(V, H, generator=g)).to(dev)
+    h1, x1 = ops.fused_residual_norm(h, w, 1e-6, add=add)
+    ws1 = torch.empty(ops.lm_head_workspace_bytes(n, H), dtype=torch.uint8, device=dev)
+    want = ops.lm_head(x1, embed, None, torch.empty(n, V, device=dev), ws1)
+    ws2 = torch.zeros(ops.lm_head_workspace_bytes(n, H), dtype=torch.uint8, device=dev)
+    for _ in range(2):   # the workspace is written again by every step
+        h2, x2 = ops.fused_residual_norm(h, w, 1e-6, add=add, lm_workspace=ws2)
+        got = ops.lm_head_planes(ws2, embed, torch.empty(n, V, device=dev))
+        assert torch.equal(h1, h2) and torch.equal(x1, x2)
+        assert torch.equal(got, want)

@@ -52,6 +52,8 @@ SIGNATURES: Dict[str, str] = {
     "i64h_embedding_stats_reset": "pppli" + "lplp",
     "i64h_rmsnorm": "ppplifp",
     "i64h_fused_residual_norm": "ppppppiffppfplipiipp",
+    "i64h_fused_residual_norm_lm": "ppppppiffppfplipiippp",
+    "i64h_lm_head_planes": "ppplii" + "p",
     "i64h_fused_residual_norm_fp8": "ppppppiffppfplippp",
     "i64h_fused_residual_norm_quant": "ppppppiffppflipiippppipppip",
     "i64h_qk_norm_rope_kv": "pppfppppipppiliiiip",

@@ -189,4 +189,17 @@ int i64h_lm_head(const float* A, const int32_t* a_rows, const float* B, float* C
     return 0;
 }
 
+// i64h_lm_head on activation planes that are already in the workspace (written by i64h_fused_residual_norm_lm for the rows 0 .. M - 1
+// in order): the main launch only.
+int i64h_lm_head_planes(const void* workspace, const float* B, float* C, int64_t M, int32_t N, int32_t K, void* stream) {
+    I64H_CHECK_ARG(M >= 0 && M < (1ll << 24) && N > 0 && K > 0 && K % 32 == 0, "lm_head_planes: K=%d must be a multiple of 32", K);
+    I64H_CHECK_ARG(workspace && ((uintptr_t)workspace | (uintptr_t)B) % 16 == 0, "lm_head_planes: workspace missing or operands not 16-byte aligned");
+    if (M == 0) return 0;
+    const int Mpad = (int)((M + 63) / 64 * 64), Kpad = (K + 255) / 256 * 256;
+    hipLaunchKernelGGL(lm_head_bf16x3_ks_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)(Mpad / 64)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint32_t*)workspace, B, C, (int)M, (int)N, (int)K, Kpad);
+    I64H_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // extern "C"

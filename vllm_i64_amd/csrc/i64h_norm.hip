@@ -59,12 +59,21 @@ struct MoeCombine {
     float routed_scale, shared_scale;
 };
 
+// fp32 pair -> three bf16 terms by truncation (hi + mid + lo == the value), packed (x low half, y high half): the split of i64h_lmhead.hip
+__device__ __forceinline__ void frn_split_pair(float x, float y, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+    const float xr = x - __uint_as_float(__float_as_uint(x) & 0xffff0000u), yr = y - __uint_as_float(__float_as_uint(y) & 0xffff0000u);
+    const float xl = xr - __uint_as_float(__float_as_uint(xr) & 0xffff0000u), yl = yr - __uint_as_float(__float_as_uint(yr) & 0xffff0000u);
+    hi = __builtin_amdgcn_perm(__float_as_uint(y), __float_as_uint(x), 0x07060302u);
+    mid = __builtin_amdgcn_perm(__float_as_uint(yr), __float_as_uint(xr), 0x07060302u);
+    lo = __builtin_amdgcn_perm(__float_as_uint(yl), __float_as_uint(xl), 0x07060302u);
+}
+
 #define FRN_MAXV 4  // float4 per thread => H <= 4096
 __global__ __launch_bounds__(256) void fused_residual_norm_kernel(const float* __restrict__ h, const float* __restrict__ add,
                                                                   MoeCombine mc, int n, int rpb, float* __restrict__ h_out,
                                                                   const float* __restrict__ w, float eps, float* __restrict__ normed,
                                                                   int H, const int32_t* __restrict__ slots, int spr, int slot_base,
-                                                                  uint32_t* __restrict__ stats) {
+                                                                  uint32_t* __restrict__ stats, uint32_t* __restrict__ lm_planes, int lm_ktp) {
     __shared__ float red[8], rlo[4], rhi[4];
     __shared__ float tab_lo[I64H_STAT_TAB], tab_hi[I64H_STAT_TAB];
     // one row per workgroup (decode): the row's few slots are updated directly, without the per-workgroup table
@@ -143,6 +152,19 @@ __global__ __launch_bounds__(256) void fused_residual_norm_kernel(const float* _
                 float4 a = v[j];
                 a.x = a.x * rr * g.x; a.y = a.y * rr * g.y; a.z = a.z * rr * g.z; a.w = a.w * rr * g.w;
                 ((float4*)(normed + t * H))[i] = a;
+                if (lm_planes) {
+                    // the tied lm_head's activation planes of this row, in its fragment order (i64h_lmhead.hip): the four values are the
+                    // pairs 2 i and 2 i + 1 of the row, neighbours in a lane's 16 bytes - the row split launch of i64h_lm_head, saved
+                    uint32_t ph[2], pm[2], pl[2];
+                    frn_split_pair(a.x, a.y, ph[0], pm[0], pl[0]);
+                    frn_split_pair(a.z, a.w, ph[1], pm[1], pl[1]);
+                    const int pr = 2 * i, blk = pr & 15, q = (blk & 7) >> 1, e2 = 2 * (blk >> 3);
+                    const int64_t frag = ((t >> 6) * lm_ktp + (pr >> 4)) * 12 + ((t & 63) >> 4);
+                    uint32_t* o = lm_planes + (frag * 64 + q * 16 + (t & 15)) * 4 + e2;
+                    *(uint2*)o = make_uint2(ph[0], ph[1]);
+                    *(uint2*)(o + 4 * 256) = make_uint2(pm[0], pm[1]);
+                    *(uint2*)(o + 8 * 256) = make_uint2(pl[0], pl[1]);
+                }
                 lo = fminf(lo, fminf(fminf(a.x, a.y), fminf(a.z, a.w)));
                 hi = fmaxf(hi, fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)));
             }
@@ -792,10 +814,10 @@ int i64h_rmsnorm(const float* x, const float* weight, float* out, int64_t rows, 
     return 0;
 }
 
-int i64h_fused_residual_norm(const float* h, const float* add, const float* moe_rows, const int32_t* moe_inv, const float* moe_shared,
+static int frn_launch(const float* h, const float* add, const float* moe_rows, const int32_t* moe_inv, const float* moe_shared,
                              const float* route_weights, int32_t top_k, float routed_scale, float shared_scale, float* h_out,
                              const float* norm_weight, float eps, float* normed, int64_t n, int32_t H, const int32_t* slots,
-                             int32_t slots_per_row, int32_t slot_base, uint32_t* stats, void* stream) {
+                             int32_t slots_per_row, int32_t slot_base, uint32_t* stats, void* stream, uint32_t* lm_planes, int lm_ktp) {
     I64H_CHECK_ARG(n >= 0 && H > 0 && H % 4 == 0 && H <= 1024 * FRN_MAXV, "fused_residual_norm: H=%d unsupported (multiple of 4, <= %d)", H,
                    1024 * FRN_MAXV);
     I64H_CHECK_ARG(top_k >= 0 && top_k <= 8, "fused_residual_norm: top_k=%d unsupported", top_k);
@@ -811,7 +833,7 @@ int i64h_fused_residual_norm(const float* h, const float* add, const float* moe_
     mc.shared_scale = shared_scale;
     const bool al16 = (((uintptr_t)h | (uintptr_t)add | (uintptr_t)moe_rows | (uintptr_t)moe_shared | (uintptr_t)h_out | (uintptr_t)normed |
                         (uintptr_t)norm_weight) % 16) == 0;
-    if (n > 2048 && H <= 1024 && slots_per_row <= 64 && al16) {  // many rows: a wave per FRR_RPW rows (same bits)
+    if (n > 2048 && H <= 1024 && slots_per_row <= 64 && al16 && !lm_planes) {  // many rows: a wave per FRR_RPW rows (same bits)
         const int64_t waves = (n + FRR_RPW - 1) / FRR_RPW;
         FrrArgs fa;
         fa.h = h; fa.add = add; fa.mc = mc; fa.n = n; fa.h_out = h_out; fa.eps = eps; fa.H = (int)H;
@@ -822,9 +844,30 @@ int i64h_fused_residual_norm(const float* h, const float* add, const float* moe_
     }
     const int rpb = n > 2048 ? 8 : 1;  // many rows: fold 8 rows per workgroup before touching the global stat slots
     hipLaunchKernelGGL(fused_residual_norm_kernel, dim3((unsigned)i64h_cdiv(n, rpb)), dim3(256), 0, (hipStream_t)stream, h, add, mc,
-                       (int)n, rpb, h_out, norm_weight, eps, normed, (int)H, slots, (int)slots_per_row, (int)slot_base, stats);
+                       (int)n, rpb, h_out, norm_weight, eps, normed, (int)H, slots, (int)slots_per_row, (int)slot_base, stats, lm_planes, lm_ktp);
     I64H_CHECK_LAUNCH();
     return 0;
+}
+
+int i64h_fused_residual_norm(const float* h, const float* add, const float* moe_rows, const int32_t* moe_inv, const float* moe_shared,
+                             const float* route_weights, int32_t top_k, float routed_scale, float shared_scale, float* h_out,
+                             const float* norm_weight, float eps, float* normed, int64_t n, int32_t H, const int32_t* slots,
+                             int32_t slots_per_row, int32_t slot_base, uint32_t* stats, void* stream) {
+    return frn_launch(h, add, moe_rows, moe_inv, moe_shared, route_weights, top_k, routed_scale, shared_scale, h_out, norm_weight, eps, normed, n,
+                      H, slots, slots_per_row, slot_base, stats, stream, nullptr, 0);
+}
+
+// i64h_fused_residual_norm that also writes the normalised rows as the activation planes of i64h_lm_head_planes (rows in order:
+// row t of this call is lm_head row t): lm_workspace = i64h_lm_head_workspace_bytes(n, H) bytes, ZEROED once by the caller (the
+// rows up to the next multiple of 64 and the K pad stay zero); H % 32 == 0, at most 2048 rows.  Saves the lm_head's row split launch.
+int i64h_fused_residual_norm_lm(const float* h, const float* add, const float* moe_rows, const int32_t* moe_inv, const float* moe_shared,
+                                const float* route_weights, int32_t top_k, float routed_scale, float shared_scale, float* h_out,
+                                const float* norm_weight, float eps, float* normed, int64_t n, int32_t H, const int32_t* slots,
+                                int32_t slots_per_row, int32_t slot_base, uint32_t* stats, void* lm_workspace, void* stream) {
+    I64H_CHECK_ARG(lm_workspace != nullptr && (uintptr_t)lm_workspace % 16 == 0 && normed != nullptr, "fused_residual_norm_lm: workspace (16-byte aligned) and normed are required");
+    I64H_CHECK_ARG(H % 32 == 0 && n <= 2048, "fused_residual_norm_lm: H=%d must be a multiple of 32, at most 2048 rows", H);
+    return frn_launch(h, add, moe_rows, moe_inv, moe_shared, route_weights, top_k, routed_scale, shared_scale, h_out, norm_weight, eps, normed, n,
+                      H, slots, slots_per_row, slot_base, stats, stream, (uint32_t*)lm_workspace, (H + 255) / 256 * 8);
 }
 
 // Residual update + RMSNorm + the per-token e4m3fn quantization of the normalised rows (i64h_fused_residual_norm followed by

@@ -185,6 +185,7 @@ class _Buffers:
             self.d_out = torch.empty(n, H, **f32)
         self.logits = torch.empty(n_logit_rows, cfg.vocab_size, **f32)
         self.lm_ws: Optional[torch.Tensor] = None     # activation planes of the lm_head (allocated on first use)
+        self.lm_planes_ws: Optional[torch.Tensor] = None  # the same, zeroed once and written by the final norm of a decode-sized step
         self.attn_ws: Optional[torch.Tensor] = None
         self.attn_splits = 1
         self.tails: Dict[tuple, list] = {}   # prepared persistent-launch descriptions per set of external buffers
@@ -264,6 +265,7 @@ class I64MoEModel:
     # matrix-core kernel, whose results are bit for bit a k-ordered fp32 chain)
     PLAN_WITH_EMBEDDING = os.environ.get("I64H_PLAN_WITH_EMBEDDING", "1") != "0"  # the embedding rows ride in the plan launch of a decode-sized step
     LM_HEAD_BF16X3 = os.environ.get("I64H_LM_HEAD_BF16X3", "1") != "0"
+    LM_PLANES_FROM_NORM = os.environ.get("I64H_LM_PLANES_FROM_NORM", "1") != "0"  # decode-sized steps: no row split launch in front of the lm_head
 
     def _lm_head(self, B: "_Buffers", logit_rows):
         M, H = B.logits.shape[0], self.cfg.hidden_size
@@ -523,8 +525,15 @@ class I64MoEModel:
         if (self.FUSE_DECODE_NORM and fuse_rows and tails is None and record is None and inject is None and self.ep is None and self.fuse_qkr
                 and cfg.head_dim == 64 and 256 <= H <= 1024 and H % 64 == 0
                 and (not cfg.is_moe or (cfg.shared_intermediate_size and 0 < B.plan.rows <= self.FUSE_MAX_ROWS))):
-            self._layers_norm_fused(B, kvc, positions, slot_ids, ctx_len, splits, rows_are_slots)
-            self._lm_head(B, logit_rows)
+            # every row's logits are wanted (a decode step): the final norm writes the lm_head's activation planes itself
+            lm_planes = (self.LM_HEAD_BF16X3 and self.LM_PLANES_FROM_NORM and logit_rows is None and H % 32 == 0 and B.logits.shape[0] == n)
+            if lm_planes and B.lm_planes_ws is None:
+                B.lm_planes_ws = torch.zeros(max(16, ops.lm_head_workspace_bytes(n, H)), dtype=torch.uint8, device=self.device)
+            self._layers_norm_fused(B, kvc, positions, slot_ids, ctx_len, splits, rows_are_slots, lm_ws=B.lm_planes_ws if lm_planes else None)
+            if lm_planes:
+                ops.lm_head_planes(B.lm_planes_ws, self.embed, B.logits)
+            else:
+                self._lm_head(B, logit_rows)
             return B.logits
         for l, W in enumerate(self.layers):
             base = l * spl
@@ -632,7 +641,7 @@ class I64MoEModel:
         self._lm_head(B, logit_rows)
         return B.logits
 
-    def _layers_norm_fused(self, B: _Buffers, kvc, positions, slot_ids, ctx_len, splits: int, rows_are_slots: bool):
+    def _layers_norm_fused(self, B: _Buffers, kvc, positions, slot_ids, ctx_len, splits: int, rows_are_slots: bool, lm_ws=None):
         """The layers of a decode-sized step with five launches each: qkv projection (+ QK norm, RoPE, cache write; from the second
         layer on with the previous layer's combine + residual + norm in front of its quantizer), attention, o projection with the
         residual add in its epilogue, the gate_up launch with residual norm in front of its quantizer, the down launch.  Enters with
@@ -690,9 +699,9 @@ class I64MoEModel:
         Wl = self.layers[L - 1]
         if cfg.is_moe:
             ops.fused_residual_norm(hbuf, self.final_norm, eps, normed=B.normed, moe_rows=B.e_out, moe_inv=None, moe_shared=B.sh_out if S else None,
-                                    route_weights=rw, routed_scale=Wl["routed_scale"], shared_scale=Wl["shared_scale"], h_out=B.h)
+                                    route_weights=rw, routed_scale=Wl["routed_scale"], shared_scale=Wl["shared_scale"], h_out=B.h, lm_workspace=lm_ws)
         else:
-            ops.fused_residual_norm(hbuf, self.final_norm, eps, normed=B.normed, h_out=B.h)
+            ops.fused_residual_norm(hbuf, self.final_norm, eps, normed=B.normed, h_out=B.h, lm_workspace=lm_ws)
 
     def _forward_fp8(self, token_ids, positions, slot_ids, ctx_len, logit_rows, kvc, record, max_ctx_hint, rows_are_slots):
         """The forward with every Linear an fp8_linear (vllm_i64/core/fp8.py:137-194, its torch._scaled_mm branch): activations are

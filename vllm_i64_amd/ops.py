@@ -422,6 +422,13 @@ def lm_head(a: torch.Tensor, b: torch.Tensor, a_rows: Optional[torch.Tensor] = N
     return out
 
 
+def lm_head_planes(workspace: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """lm_head on planes that fused_residual_norm(..., lm_workspace=workspace) wrote for the rows of `out`, in order."""
+    _chk(b, torch.float32, "b"), _chk(out, torch.float32, "out")
+    call("i64h_lm_head_planes", ptr(workspace), ptr(b), ptr(out), out.shape[0], b.shape[0], b.shape[1], _stream())
+    return out
+
+
 def lm_head_workspace_bytes(M: int, K: int) -> int:
     return int(_lib.load().i64h_lm_head_workspace_bytes(M, K))
 
@@ -490,7 +497,9 @@ def fused_residual_norm(h: torch.Tensor, norm_weight: Optional[torch.Tensor], ep
                         moe_shared: Optional[torch.Tensor] = None, route_weights: Sequence[float] = (), routed_scale: float = 1.0,
                         shared_scale: float = 1.0, h_out: Optional[torch.Tensor] = None, normed: Optional[torch.Tensor] = None,
                         want_normed: bool = True, slots: Optional[torch.Tensor] = None, slot_base: int = 0,
-                        stats: Optional[torch.Tensor] = None):
+                        stats: Optional[torch.Tensor] = None, lm_workspace: Optional[torch.Tensor] = None):
+    """lm_workspace (zeroed once by the caller, lm_head_workspace_bytes(n, H) bytes): the normalised rows are also written as the
+    activation planes of lm_head_planes."""
     _chk(h, torch.float32, "h")
     n, H = h.shape
     if h_out is None:
@@ -499,6 +508,12 @@ def fused_residual_norm(h: torch.Tensor, norm_weight: Optional[torch.Tensor], ep
         normed = torch.empty_like(h)
     rw = (ctypes.c_float * 8)(*([float(w) for w in route_weights] + [0.0] * (8 - len(route_weights))))
     spr = 1 if slots is None else (slots.shape[1] if slots.dim() == 2 else 1)
+    if lm_workspace is not None:
+        assert want_normed and lm_workspace.numel() * lm_workspace.element_size() >= lm_head_workspace_bytes(n, H)
+        call("i64h_fused_residual_norm_lm", ptr(h), ptr(add), ptr(moe_rows), ptr(moe_inv), ptr(moe_shared), ctypes.addressof(rw),
+             len(route_weights), float(routed_scale), float(shared_scale), ptr(h_out), ptr(norm_weight), float(eps), ptr(normed), n, H,
+             ptr(slots), spr, slot_base, ptr(stats), ptr(lm_workspace), _stream())
+        return h_out, normed
     call("i64h_fused_residual_norm", ptr(h), ptr(add), ptr(moe_rows), ptr(moe_inv), ptr(moe_shared), ctypes.addressof(rw),
          len(route_weights), float(routed_scale), float(shared_scale), ptr(h_out), ptr(norm_weight), float(eps),
          ptr(normed) if want_normed else 0, n, H, ptr(slots), spr, slot_base, ptr(stats), _stream())
