@@ -131,11 +131,15 @@ __global__ __launch_bounds__(256, 2) void lm_head_bf16x3_ks_kernel(const uint32_
     LMK_WSTORE();
     LMK_WLOAD(1);
     for (int s = 0; s < S; s += 2) {
+        // the scheduling barriers keep the next step's requests IN FRONT of this step's matrix-core instructions (left alone, the
+        // scheduler sinks them behind the 96 MFMAs, i.e. right in front of their use)
         LMK_ALOAD(s + 1, afb);
+        __builtin_amdgcn_sched_barrier(0);
         LMK_STEP(afa);
         LMK_WSTORE();      // step s + 1's weight rows (in registers since the previous step) replace step s's in the strip
         LMK_WLOAD(s + 2);
         LMK_ALOAD(s + 2, afa);
+        __builtin_amdgcn_sched_barrier(0);
         LMK_STEP(afb);
         LMK_WSTORE();
         LMK_WLOAD(s + 3);
