@@ -266,10 +266,17 @@ def main():
         if multi_ep and not args.no_graph:
             contingency.update(result_line(elapsed, False, prefill_tps, note="eager launches; the graph replay of the step did not complete"))
             extras["ep_eager_ms_per_step"] = round(elapsed / args.steps * 1e3, 4)   # the same steps launched one by one
-            dec.use_graph = True
-            dec.prepare()
-            if dec.graph is not None:
-                elapsed = timed_steps(dec, emit_contingency)
+            try:
+                dec.use_graph = True
+                dec.prepare()
+                if dec.graph is not None:
+                    elapsed = timed_steps(dec, emit_contingency)
+            except Exception as e:  # the capture itself refused (a collective that cannot be captured on this stack): the eager
+                # measurement above stands, labelled as such; a replay that HANGS is the guard's business (exit status 5)
+                sys.stderr.write(f"bench.py: capturing the expert-parallel step failed ({type(e).__name__}: {str(e)[:300]}); reporting the eager launches\n")
+                extras["ep_graph_error"] = f"{type(e).__name__}: {str(e)[:200]}"
+                dec.use_graph = False
+                dec.graph = None
         return model, dec, prefill_tps, elapsed
 
     def fill_cache(model, dec):
