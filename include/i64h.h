@@ -412,6 +412,11 @@ int i64h_debug_set_decode_stamps(void* buffer); /* diagnostics: 16 uint64 of s_m
 
 /* ---- row kernels -------------------------------------------------------------------------------------------------------
  * nn.Embedding lookup (model.py:415). */
+/* mu-guidance glue (models/complexity_deep/model.py:58-67, 167-170, 417-419, 431-432; off unless the config says use_mu_guidance):
+ * x[r, 0:w] += y[r, 0:w] for a column block of a wider matrix (q, k, v += the mu projections), and the layer's mu for the next layer:
+ * out[r, :] = clamp(clamp(mu, 0, 2) + proj[r, :], -2, 2), or mu expanded over the rows when proj is NULL (mu_init). */
+int i64h_add_cols(float* x, int64_t ldx, const float* y, int64_t n, int32_t w, void* stream);
+int i64h_mu_update(const float* mu, const float* proj, float* out, int64_t n, int32_t H, void* stream);
 int i64h_embedding(const int64_t* ids, const float* table, float* out, int64_t n, int32_t H, int64_t V, void* stream);
 /* The embedding rows and, in the same launch, i64h_stats_reset(stats, n_slots): the first two launches of a forward in one. */
 int i64h_embedding_stats_reset(const int64_t* ids, const float* table, float* out, int64_t n, int32_t H, int64_t V, uint32_t* stats,

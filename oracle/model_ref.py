@@ -58,6 +58,7 @@ class SynthConfig:
     rope_theta: float = 10000.0
     max_pos: int = 2304
     table_routing: bool = True             # False => cyclic (v + k) % E default tables
+    use_mu_guidance: bool = False          # MuGuidance state passed from layer to layer (models/complexity_deep/model.py:58-67)
 
     @property
     def head_dim(self) -> int:
@@ -93,6 +94,10 @@ def named_config(name: str) -> SynthConfig:
         return SynthConfig(name=name, vocab_size=512, hidden_size=128, num_layers=2, num_heads=4, num_kv_heads=2,
                            intermediate_size=256, num_experts=8, shared_intermediate_size=96, top_k=2,
                            primary_weight=0.5, routed_scale=1.5, shared_scale=0.75, max_pos=256)
+    if name == "tiny-mu":      # tiny-moe with mu-guidance switched on
+        return SynthConfig(name=name, vocab_size=512, hidden_size=128, num_layers=2, num_heads=4, num_kv_heads=2,
+                           intermediate_size=256, num_experts=8, shared_intermediate_size=96, top_k=2,
+                           primary_weight=0.5, routed_scale=1.5, shared_scale=0.75, max_pos=256, use_mu_guidance=True)
     if name == "tiny-cyclic":
         return SynthConfig(name=name, vocab_size=512, hidden_size=128, num_layers=2, num_heads=4, num_kv_heads=2,
                            intermediate_size=256, num_experts=4, shared_intermediate_size=64, top_k=2,
@@ -140,6 +145,16 @@ def make_weights(cfg: SynthConfig, seed: int = 0, std: float = 0.02) -> Dict[str
 
     w: Dict[str, torch.Tensor] = {"embed": rn(cfg.vocab_size, H), "final_norm": torch.ones(H)}
     tables = make_tables(cfg)
+    if cfg.use_mu_guidance:   # the reference initialises mu_init and mu_proj to zero and mu to one; random here, so that every term counts
+        gm = torch.Generator().manual_seed(seed + 991)
+        w["mu_init"] = torch.empty(H).normal_(0.0, 0.5, generator=gm)
+        for l in range(cfg.num_layers):
+            p = f"l{l}."
+            w[p + "mu"] = torch.empty(H).uniform_(-0.5, 2.5, generator=gm)      # both clamps of MuGuidance.forward bite
+            w[p + "mu_proj"] = torch.empty(H, H).normal_(0.0, std, generator=gm)
+            w[p + "mu_q"] = torch.empty(H, H).normal_(0.0, std, generator=gm)
+            w[p + "mu_k"] = torch.empty(kv, H).normal_(0.0, std, generator=gm)
+            w[p + "mu_v"] = torch.empty(kv, H).normal_(0.0, std, generator=gm)
     for l in range(cfg.num_layers):
         p = f"l{l}."
         w[p + "ln1"] = torch.ones(H)
@@ -383,12 +398,16 @@ def dense_mlp_forward(bank: LinearBank, l: int, x: torch.Tensor) -> torch.Tensor
 
 
 def attention_forward(cfg: SynthConfig, bank: LinearBank, l: int, x, positions, kv: PagedKV,
-                      seq_ids: Sequence[int], tokens_per_seq: Sequence[int], record=None):
+                      seq_ids: Sequence[int], tokens_per_seq: Sequence[int], record=None, mu_prev=None):
     p = f"l{l}."
     n = x.shape[0]
     H, kvw, hd = cfg.hidden_size, cfg.num_kv_heads * cfg.head_dim, cfg.head_dim
     qkv = bank(p + "qkv", x, tag=f"{p}qkv")
     q, k, v = qkv.split((H, kvw, kvw), dim=-1)
+    if mu_prev is not None:   # three Linear calls of their own on the previous layer's mu (model.py:167-170)
+        q = q + bank(p + "mu_q", mu_prev, tag=f"{p}mu_q")
+        k = k + bank(p + "mu_k", mu_prev, tag=f"{p}mu_k")
+        v = v + bank(p + "mu_v", mu_prev, tag=f"{p}mu_v")
     q = q.reshape(n, cfg.num_heads, hd)
     k = k.reshape(n, cfg.num_kv_heads, hd)
     v = v.reshape(n, cfg.num_kv_heads, hd)
@@ -417,12 +436,13 @@ def model_forward(cfg: SynthConfig, bank: LinearBank, token_ids: torch.Tensor, p
                   record: Optional[dict] = None) -> torch.Tensor:
     """fp32 logits [N, V] for one engine step (models/complexity_deep/model.py:389-441)."""
     h = F.embedding(token_ids, bank.w["embed"])
+    mu_prev = bank.w["mu_init"].view(1, -1).expand(h.shape[0], -1) if cfg.use_mu_guidance else None   # model.py:417-419
     for l in range(cfg.num_layers):
         p = f"l{l}."
         if record is not None:
             record[f"{p}in"] = h.clone()
         a = attention_forward(cfg, bank, l, rmsnorm(h, bank.w[p + "ln1"], cfg.rms_eps), positions, kv,
-                              seq_ids, tokens_per_seq, record)
+                              seq_ids, tokens_per_seq, record, mu_prev=mu_prev)
         h = h + a
         x2 = rmsnorm(h, bank.w[p + "ln2"], cfg.rms_eps)
         if record is not None:
@@ -433,6 +453,11 @@ def model_forward(cfg: SynthConfig, bank: LinearBank, token_ids: torch.Tensor, p
         h = h + m
         if record is not None:
             record[f"{p}out"] = h.clone()
+        if cfg.use_mu_guidance:   # mu of this layer from its output (model.py:58-67, 365-367), clamped for the next one (model.py:431-432)
+            mu_cur = torch.clamp(bank.w[p + "mu"], 0.0, 2.0) + bank(p + "mu_proj", h, tag=f"{p}mu_proj")
+            mu_prev = torch.clamp(mu_cur, -2.0, 2.0)
+            if record is not None:
+                record[f"{p}mu"] = mu_prev.clone()
     h = rmsnorm(h, bank.w["final_norm"], cfg.rms_eps)
     return F.linear(h.float(), bank.w["embed"].float())
 

@@ -123,3 +123,31 @@ def test_learned_output_gates_round_trip_and_oracle(golden_dir):
     broken = {k: v for k, v in sd.items() if not k.endswith("routed_output_gate")}
     with pytest.raises(KeyError, match="go together"):
         C.native_to_weights(broken, cfg)
+
+
+def test_mu_guidance_tensors_round_trip_and_are_rejected_when_switched_off(tmp_path):
+    """A config with use_mu_guidance carries mu_init and, per layer, mu_guidance.mu / mu_guidance.mu_proj and the attention's
+    mu_to_q / k / v under the reference's names (models/complexity_deep/model.py:58-67, 92-101, 385-387); a config that switches
+    it off refuses a checkpoint that holds them (dropping them would run a different model)."""
+    from oracle import model_ref as M
+    from vllm_i64_amd import checkpoint as C
+    from vllm_i64_amd.config import ModelConfig
+    ocfg = M.named_config("tiny-mu")
+    cfg = ModelConfig.from_any(ocfg)
+    assert cfg.use_mu_guidance
+    w = M.make_weights(ocfg, seed=0)
+    sd = C.weights_to_native(w, cfg)
+    for name in ("mu_init", "layers.1.mu_guidance.mu", "layers.1.mu_guidance.mu_proj.weight", "layers.0.self_attn.mu_to_k.weight"):
+        assert name in sd, name
+    assert tuple(sd["mu_init"].shape) == (1, 1, cfg.hidden_size)
+    back = C.native_to_weights(sd, cfg)
+    C.check_shapes(cfg, back)
+    for k in ("mu_init", "l0.mu", "l1.mu_proj", "l0.mu_q", "l1.mu_k", "l0.mu_v"):
+        assert torch.equal(back[k], w[k]), k
+    assert C.config_from_dict(C.config_to_json(cfg)).use_mu_guidance
+    C.save_packed(str(tmp_path / "mu.safetensors"), cfg, back)   # the int8 pack carries the four mu matrices of a layer too
+    pcfg, pw = C.load_packed(str(tmp_path / "mu.safetensors"))
+    assert pcfg.use_mu_guidance and pw["l1.mu_proj"].w_q.dtype == torch.int8 and torch.equal(pw["l0.mu"], w["l0.mu"])
+    off = C.config_from_dict({**C.config_to_json(cfg), "use_mu_guidance": False})
+    with pytest.raises((KeyError, ValueError)):
+        C.native_to_weights(sd, off)

@@ -84,9 +84,10 @@ def test_moe_layer_tier0_bit_exact(dev):
     assert checked >= 12
 
 
-@pytest.mark.parametrize("name", ["tiny-moe", "tiny-cyclic", "tiny-dense"])
+@pytest.mark.parametrize("name", ["tiny-moe", "tiny-cyclic", "tiny-dense", "tiny-mu"])
 def test_model_golden_logits(dev, golden_dir, name):
-    """Prefill (33 + 21 tokens) and 4 teacher-forced decode steps against the reference's int8 logits.
+    """Prefill (33 + 21 tokens) and 4 teacher-forced decode steps against the reference's int8 logits (tiny-mu: tiny-moe with
+    mu-guidance switched on and random mu weights, so that its five extra Linear calls per layer all count).
     Tier-2 check: the int8 forward is discontinuous (one flipped activation LSB perturbs everything downstream),
     so the bound here is the quantization-noise scale, reported next to the exact-match statistics."""
     from vllm_i64_amd.model import GreedyDecoder
@@ -139,9 +140,10 @@ def test_model_layers_teacher_forced(dev, name):
         assert da.mean() <= 1e-4 and do.mean() <= 1e-4
 
 
-def test_graph_decode_matches_eager(dev):
+@pytest.mark.parametrize("name", ["tiny-moe", "tiny-mu"])
+def test_graph_decode_matches_eager(dev, name):
     from vllm_i64_amd.model import GreedyDecoder
-    ocfg, w, model = _model("tiny-moe", dev)
+    ocfg, w, model = _model(name, dev)
     ids = M.make_token_ids(ocfg, 40, seed=5)
     outs = []
     for use_graph in (False, True):
@@ -488,3 +490,38 @@ def test_pair_launch_refuses_group_slots_without_the_row_slot_index(dev):
     d.a_group_slots = 2
     with pytest.raises(_lib.I64HError, match="a_row_slot"):
         ops.gemm_i8_pair(d)
+
+
+def test_mu_guidance_layers_teacher_forced_and_refusals(dev):
+    """mu-guidance (models/complexity_deep/model.py:58-67, 167-170, 431-432): with every layer fed the oracle's layer input, the
+    layer outputs match the oracle's to the bound of the other model tests - and since the vector handed from layer to layer is
+    NOT teacher-forced, this also checks the chain mu_init -> mu_proj -> clamp through the layers.  The runners that do not carry
+    the mu Linears (e4m3, expert-parallel) refuse the config instead of dropping the terms."""
+    from vllm_i64_amd.config import ModelConfig
+    from vllm_i64_amd.model import I64MoEModel
+    ocfg, w, model = _model("tiny-mu", dev)
+    ids = M.make_token_ids(ocfg, 54, seed=7)
+    lens = [33, 21]
+    eng = M.OracleEngine(ocfg, w, mode="int8", max_seqs=2, num_blocks=64)
+    rec = {}
+    eng.prefill([ids[:33], ids[33:]], record=rec)
+    for s, n in enumerate(lens):
+        model.kv.reserve(s, n)
+    pos = torch.cat([torch.arange(n, dtype=torch.int32) for n in lens]).to(dev)
+    slots = torch.cat([torch.full((n,), s, dtype=torch.int32) for s, n in enumerate(lens)]).to(dev)
+    inject = {l: rec[f"l{l}.in"].to(dev) for l in range(ocfg.num_layers)}
+    grec = {}
+    model.forward(ids.to(dev), pos, slots, (pos + 1).contiguous(), record=grec, inject=inject)
+    for l in range(ocfg.num_layers):
+        do = (grec[f"l{l}.out"].cpu() - rec[f"l{l}.out"]).abs()
+        print(f"tiny-mu layer {l}: layer-out diff max {do.max():.3e} mean {do.mean():.3e}")
+        assert do.max() <= 1e-2 and do.mean() <= 1e-4
+    # the terms count: the same weights without them give another layer output
+    plain = I64MoEModel(ModelConfig.from_any(M.named_config("tiny-moe")), w, device=dev, max_seqs=4, num_kv_blocks=64)
+    for s, n in enumerate(lens):
+        plain.kv.reserve(s, n)
+    prec = {}
+    plain.forward(ids.to(dev), pos, slots, (pos + 1).contiguous(), record=prec, inject=inject)
+    assert (prec["l1.out"].cpu() - rec["l1.out"]).abs().max() > 0.05
+    with pytest.raises(NotImplementedError, match="mu-guidance"):
+        I64MoEModel(ModelConfig.from_any(ocfg), w, device=dev, max_seqs=4, num_kv_blocks=64, quant="fp8")

@@ -139,7 +139,7 @@ def test_moe_layer_golden(golden_dir):
             assert np.array_equal(y.numpy(), z[f"{name}_n{n}_y"]), (name, n)
 
 
-@pytest.mark.parametrize("name", ["tiny-moe", "tiny-cyclic", "tiny-dense"])
+@pytest.mark.parametrize("name", ["tiny-moe", "tiny-cyclic", "tiny-dense", "tiny-mu"])
 def test_model_golden(golden_dir, name):
     z = _load(golden_dir, f"model_{name}.npz")
     cfg = M.named_config(name)

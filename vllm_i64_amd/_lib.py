@@ -21,6 +21,8 @@ SIGNATURES: Dict[str, str] = {
     "i64h_route_lookup": "ppplilp",
     "i64h_bucketize": "ppppppplip",
     "i64h_moe_plan": "pplpppppppppliliip",
+    "i64h_add_cols": "plplip",
+    "i64h_mu_update": "ppplip",
     "i64h_moe_plan_embedding": "pplpppppppppliliipp" + "ilplp",
     "i64h_gather_rows": "pppllp",
     "i64h_silu_mul": "ppliip",

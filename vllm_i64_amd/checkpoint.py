@@ -27,7 +27,7 @@ import torch
 
 from .config import ModelConfig
 
-MATRIX_KEYS = ("qkv", "o", "exp_gate_up", "exp_down", "sh_gate_up", "sh_down", "gate_up", "down")
+MATRIX_KEYS = ("qkv", "o", "exp_gate_up", "exp_down", "sh_gate_up", "sh_down", "gate_up", "down", "mu_proj", "mu_q", "mu_k", "mu_v")
 PACKED_FORMAT = "i64h-packed-v1"
 
 
@@ -104,7 +104,8 @@ def config_from_dict(d: dict) -> ModelConfig:
         primary_weight=float(0.95 if pw is None else pw),  # unset -> 0.95 (layers/token_routed_mlp.py:53-54)
         routed_scale=float(g("routed_output_scale", 1.0)), shared_scale=float(g("shared_output_scale", 1.0)),
         rms_eps=float(g("rms_norm_eps", g("norm_eps", 1e-6))), rope_theta=float(g("rope_theta", 10000.0)),
-        max_pos=int(g("max_position_embeddings", 2048)), table_routing=g("routing_strategy", "modulo_cyclic") != "modulo_cyclic")
+        max_pos=int(g("max_position_embeddings", 2048)), table_routing=g("routing_strategy", "modulo_cyclic") != "modulo_cyclic",
+        use_mu_guidance=bool(g("use_mu_guidance", False)) and not bool(g("disable_mu_guidance", False)))
 
 
 def config_to_json(cfg: ModelConfig) -> dict:
@@ -114,7 +115,7 @@ def config_to_json(cfg: ModelConfig) -> dict:
             "shared_expert": cfg.shared_intermediate_size > 0, "shared_intermediate_size": cfg.shared_intermediate_size or None,
             "top_k": cfg.top_k, "top_k_primary_weight": cfg.primary_weight, "routed_output_scale": cfg.routed_scale,
             "shared_output_scale": cfg.shared_scale, "rms_norm_eps": cfg.rms_eps, "rope_theta": cfg.rope_theta,
-            "max_position_embeddings": cfg.max_pos, "use_qk_norm": True, "tie_word_embeddings": True, "use_mu_guidance": False,
+            "max_position_embeddings": cfg.max_pos, "use_qk_norm": True, "tie_word_embeddings": True, "use_mu_guidance": bool(cfg.use_mu_guidance),
             "routing_strategy": "token_table" if cfg.table_routing else "modulo_cyclic"}
 
 
@@ -122,7 +123,8 @@ def config_to_json(cfg: ModelConfig) -> dict:
 def native_to_weights(state: Dict[str, torch.Tensor], cfg: ModelConfig) -> Dict[str, torch.Tensor]:
     """The reference's tensor names -> this package's keys (embed, final_norm, l{i}.ln1 / qkv / q_norm / k_norm / o / ln2 /
     exp_gate_up / exp_down / sh_gate_up / sh_down / table | gate_up / down).  Raises on anything the forward needs but the
-    checkpoint lacks; tensors the forward does not read (mu-guidance, dynamics, gates of other variants) are rejected
+    checkpoint lacks; tensors the forward does not read (dynamics, gates of other variants, mu-guidance tensors of a config that
+    switches it off) are rejected
     loudly rather than dropped: loading them silently would run a different model."""
     sd = {}
     for k, v in state.items():
@@ -146,8 +148,15 @@ def native_to_weights(state: Dict[str, torch.Tensor], cfg: ModelConfig) -> Dict[
     w["embed"] = f32(emb if emb is not None else e2)
     w["final_norm"] = f32(take("norm.weight"))
     E, K = cfg.num_experts, cfg.top_k
+    if cfg.use_mu_guidance:   # model.py:385-387: the first layer's mu
+        w["mu_init"] = f32(take("mu_init")).reshape(-1)
     for l in range(cfg.num_layers):
         p, q = f"layers.{l}.", f"l{l}."
+        if cfg.use_mu_guidance:   # model.py:58-67 (MuGuidance of the layer), 92-101 (its projections into q, k, v)
+            w[q + "mu"] = f32(take(p + "mu_guidance.mu"))
+            w[q + "mu_proj"] = f32(take(p + "mu_guidance.mu_proj.weight"))
+            for part in ("q", "k", "v"):
+                w[q + "mu_" + part] = f32(take(p + f"self_attn.mu_to_{part}.weight"))
         w[q + "ln1"] = f32(take(p + "input_layernorm.weight"))
         w[q + "ln2"] = f32(take(p + "post_attention_layernorm.weight"))
         a = p + "self_attn."
@@ -198,8 +207,14 @@ def weights_to_native(w: Dict[str, torch.Tensor], cfg: ModelConfig) -> Dict[str,
     H, kvw = cfg.hidden_size, cfg.num_kv_heads * cfg.head_dim
     c = lambda t: t.contiguous().clone()  # safetensors refuses tensors that share storage
     sd = {"embed_tokens.weight": c(w["embed"]), "norm.weight": c(w["final_norm"])}
+    if cfg.use_mu_guidance:
+        sd["mu_init"] = c(w["mu_init"]).reshape(1, 1, -1)
     for l in range(cfg.num_layers):
         p, q = f"layers.{l}.", f"l{l}."
+        if cfg.use_mu_guidance:
+            sd[p + "mu_guidance.mu"], sd[p + "mu_guidance.mu_proj.weight"] = c(w[q + "mu"]), c(w[q + "mu_proj"])
+            for part in ("q", "k", "v"):
+                sd[p + f"self_attn.mu_to_{part}.weight"] = c(w[q + "mu_" + part])
         sd[p + "input_layernorm.weight"] = c(w[q + "ln1"])
         sd[p + "post_attention_layernorm.weight"] = c(w[q + "ln2"])
         a = p + "self_attn."
@@ -232,9 +247,13 @@ def weights_to_native(w: Dict[str, torch.Tensor], cfg: ModelConfig) -> Dict[str,
 def check_shapes(cfg: ModelConfig, w) -> None:
     H, kvw, hd = cfg.hidden_size, cfg.num_kv_heads * cfg.head_dim, cfg.head_dim
     want = {"embed": (cfg.vocab_size, H), "final_norm": (H,)}
+    if cfg.use_mu_guidance:
+        want["mu_init"] = (H,)
     for l in range(cfg.num_layers):
         q = f"l{l}."
         want.update({q + "ln1": (H,), q + "ln2": (H,), q + "qkv": (H + 2 * kvw, H), q + "o": (H, H), q + "q_norm": (hd,), q + "k_norm": (hd,)})
+        if cfg.use_mu_guidance:
+            want.update({q + "mu": (H,), q + "mu_proj": (H, H), q + "mu_q": (H, H), q + "mu_k": (kvw, H), q + "mu_v": (kvw, H)})
         if cfg.is_moe:
             ei, S = cfg.expert_inter, cfg.shared_intermediate_size
             want.update({q + "exp_gate_up": (cfg.num_experts, 2 * ei, H), q + "exp_down": (cfg.num_experts, H, ei), q + "table": (cfg.top_k, cfg.vocab_size)})

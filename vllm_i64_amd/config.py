@@ -25,6 +25,7 @@ class ModelConfig:
     max_pos: int = 2304
     table_routing: bool = True
     kv_block: int = 16                    # reference hard-codes 16 (engine/i64_engine.py:245)
+    use_mu_guidance: bool = False         # MuGuidance (models/complexity_deep/model.py:58-67): a per-token vector handed from layer to layer
 
     @property
     def head_dim(self) -> int:

@@ -22,6 +22,33 @@ __global__ void embedding_kernel(const int64_t* __restrict__ ids, const float* _
     for (int i = threadIdx.x; i < H / 4; i += blockDim.x) d[i] = s[i];
 }
 
+// ---- mu-guidance glue (models/complexity_deep/model.py:58-67, 167-170, 431-432) ------------------------------------------------
+// x[r, c] += y[r, c] for a column block of x (row stride ldx floats) and a dense y [n, w]: q, k, v each get their mu projection
+__global__ __launch_bounds__(256) void add_cols_kernel(float* __restrict__ x, int64_t ldx, const float* __restrict__ y, int64_t n, int w4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n * w4; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / w4;
+        const int c = (int)(i - r * w4);
+        float4* px = (float4*)(x + r * ldx) + c;
+        float4 a = *px;
+        const float4 b = ((const float4*)y)[i];
+        a.x = a.x + b.x; a.y = a.y + b.y; a.z = a.z + b.z; a.w = a.w + b.w;
+        *px = a;
+    }
+}
+// mu_next[r, j] = clamp(clamp(mu[j], 0, 2) + proj[r, j], -2, 2); proj == nullptr: mu_next[r, j] = init[j] (the first layer's mu)
+__global__ __launch_bounds__(256) void mu_update_kernel(const float* __restrict__ mu, const float* __restrict__ proj, float* __restrict__ out,
+                                                        int64_t n, int H) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n * H; i += (int64_t)gridDim.x * 256) {
+        const int j = (int)(i % H);
+        if (proj) {
+            const float m = fminf(fmaxf(mu[j], 0.0f), 2.0f);
+            out[i] = fminf(fmaxf(m + proj[i], -2.0f), 2.0f);
+        } else {
+            out[i] = mu[j];
+        }
+    }
+}
+
 // ---- plain RMSNorm: out = x * rsqrt(mean(x^2) + eps) * w -------------------------------------------------
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ out,
                                                       int H, float eps) {
@@ -783,6 +810,30 @@ int i64h_argmax_rows(const float* x, int64_t* out, int64_t rows, int32_t D, void
 int i64h_advance(int32_t* positions, int32_t* ctx_len, int64_t n, void* stream) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(advance_kernel, dim3(i64h_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, positions, ctx_len, (int)n);
+    I64H_CHECK_LAUNCH();
+    return 0;
+}
+
+// x[r, 0:w] += y[r, 0:w] (x: a column block of a wider matrix, row stride ldx floats; y dense [n, w]; w, ldx multiples of 4, both
+// 16-byte aligned): q, k, v += mu_to_q / k / v(mu_prev) (model.py:167-170)
+int i64h_add_cols(float* x, int64_t ldx, const float* y, int64_t n, int32_t w, void* stream) {
+    I64H_CHECK_ARG(n >= 0 && w > 0 && w % 4 == 0 && ldx % 4 == 0 && ldx >= w && (((uintptr_t)x | (uintptr_t)y) % 16) == 0,
+                   "add_cols: w and ldx must be multiples of 4 (ldx >= w), operands 16-byte aligned");
+    if (n == 0) return 0;
+    const int64_t tot = n * (w / 4);
+    hipLaunchKernelGGL(add_cols_kernel, dim3((unsigned)(tot + 255 < 256 * 2048 ? (tot + 255) / 256 : 2048)), dim3(256), 0, (hipStream_t)stream, x, ldx, y, n,
+                       (int)(w / 4));
+    I64H_CHECK_LAUNCH();
+    return 0;
+}
+
+// MuGuidance.forward + the clamp in front of the next layer (model.py:58-67, 431-432): out[r, :] = clamp(clamp(mu, 0, 2) + proj[r, :], -2, 2);
+// proj == NULL: out[r, :] = mu (mu_init expanded over the rows, model.py:417-419)
+int i64h_mu_update(const float* mu, const float* proj, float* out, int64_t n, int32_t H, void* stream) {
+    I64H_CHECK_ARG(n >= 0 && H > 0 && mu && out, "mu_update: bad arguments");
+    if (n == 0) return 0;
+    const int64_t tot = n * H;
+    hipLaunchKernelGGL(mu_update_kernel, dim3((unsigned)(tot + 255 < 256 * 2048 ? (tot + 255) / 256 : 2048)), dim3(256), 0, (hipStream_t)stream, mu, proj, out, n, (int)H);
     I64H_CHECK_LAUNCH();
     return 0;
 }

@@ -183,6 +183,9 @@ class _Buffers:
             self.da = torch.empty(n, I, **i8)
             self.ds = torch.empty(n, **f32)
             self.d_out = torch.empty(n, H, **f32)
+        if cfg.use_mu_guidance:
+            self.mu_prev = torch.empty(n, H, **f32)   # the vector the previous layer hands on (mu_init for the first)
+            self.mu_out = torch.empty(n, H, **f32)    # a mu Linear's product (widest: mu_proj, mu_to_q)
         self.logits = torch.empty(n_logit_rows, cfg.vocab_size, **f32)
         self.lm_ws: Optional[torch.Tensor] = None     # activation planes of the lm_head (allocated on first use)
         self.lm_planes_ws: Optional[torch.Tensor] = None  # the same, zeroed once and written by the final norm of a decode-sized step
@@ -209,6 +212,8 @@ class I64MoEModel:
         assert quant in ("int8", "fp8")
         self.quant = quant
         assert not (quant == "fp8" and expert_parallel), "the expert-parallel runner is built for the int8 scheme"
+        if cfg.use_mu_guidance and (quant != "int8" or expert_parallel):
+            raise NotImplementedError("mu-guidance runs on the single-GPU int8 runner only")
         pack = pack_per_tensor if quant == "int8" else pack_fp8
         self.ep = None            # expert-parallel communication (ep.EPComm) or None
         self.ep_e0 = self.ep_le = 0
@@ -230,6 +235,10 @@ class I64MoEModel:
             p = f"l{l}."
             d = dict(ln1=f(weights[p + "ln1"]), ln2=f(weights[p + "ln2"]), q_norm=f(weights[p + "q_norm"]),
                      k_norm=f(weights[p + "k_norm"]), qkv=pack(weights[p + "qkv"], dev), o=pack(weights[p + "o"], dev))
+            if cfg.use_mu_guidance:   # models/complexity_deep/model.py:58-67, 92-101: five more nn.Linear calls per layer
+                d["mu"] = f(weights[p + "mu"])
+                for name in ("mu_proj", "mu_q", "mu_k", "mu_v"):
+                    d[name] = pack_per_tensor(weights[p + name], dev)
             if cfg.is_moe:
                 # expert parallel: this rank's experts only (one quantization scale per expert matrix, so slicing commutes with
                 # packing); the shared expert, the attention projections and the routing tables are replicated
@@ -248,6 +257,7 @@ class I64MoEModel:
             d["routed_scale"] = float(weights[p + "routed_gate"]) if p + "routed_gate" in weights else cfg.routed_scale
             d["shared_scale"] = float(weights[p + "shared_gate"]) if p + "shared_gate" in weights else cfg.shared_scale
             self.layers.append(d)
+        self.mu_init = f(weights["mu_init"]).reshape(-1) if cfg.use_mu_guidance else None
         self.tables = torch.stack(tables).to(dev).contiguous() if tables else None  # [L, top_k, V] int64
         self.rope = rope_table(cfg.max_pos, cfg.head_dim, cfg.rope_theta).to(dev)
         nb = num_kv_blocks or max_seqs * ((cfg.max_pos + cfg.kv_block - 1) // cfg.kv_block)
@@ -256,6 +266,11 @@ class I64MoEModel:
         # stat slots per layer; the expert-parallel runner keeps one more: the shared expert's gate_up call is quantized over THIS
         # rank's tokens (every rank an engine of its own for the dense calls), while slot 2 collects all ranks' rows
         self.spl = (4 + 2 * self.nb + (1 if self.ep is not None else 0)) if cfg.is_moe else 4
+        # mu-guidance: two more slots at the end of a layer's block - the range of mu_prev (one range for the three projections
+        # that read it) and the range of the layer's output rows (the mu_proj call)
+        self.mu_slot = self.spl
+        if cfg.use_mu_guidance:
+            self.spl += 2
         self.stats = ops.stats_alloc(self.spl * cfg.num_layers + 1, dev)
         self._bufs: Dict[tuple, _Buffers] = {}
         self.dec_sync = ops.decode_sync_alloc(dev)
@@ -511,18 +526,21 @@ class I64MoEModel:
             B.attn_splits = splits
         # prefill-sized chunks that fit one resident grid: residual + norm + the quantization of the calls that read the normalised
         # rows are one launch (the fp32 normalised rows are never stored); record / inject / expert-parallel runs keep the two-kernel form
+        mu = cfg.use_mu_guidance   # mu-guidance keeps the one-kernel-per-operation form: its Linears sit between the fused ones
         fq = (self.FUSE_NORM_QUANT and n > self.FUSE_MAX_ROWS and n <= self._fq_rows() and record is None and inject is None
-              and self.ep is None and H <= 1024 and H % 4 == 0)
+              and self.ep is None and H <= 1024 and H % 4 == 0 and not mu)
         if fq:
             self._resident_used = True
             ops.fused_residual_norm_quant(B.h, self.layers[0]["ln1"], eps, st, self.dec_sync, B.xa, B.xs, h_out=B.h, slot_base=0)
         else:
             ops.fused_residual_norm(B.h, self.layers[0]["ln1"], eps, h_out=B.h, normed=B.normed, slot_base=0, stats=st)
         tails = None
-        if fuse_rows and record is None and inject is None and self._tail_supported(n):
+        if mu:
+            ops.call("i64h_mu_update", ops.ptr(self.mu_init), 0, ops.ptr(B.mu_prev), n, H, ops._stream())   # model.py:417-419
+        if fuse_rows and record is None and inject is None and not mu and self._tail_supported(n):
             tails = self._tails(B, kvc, positions, slot_ids)
             self._resident_used = True
-        if (self.FUSE_DECODE_NORM and fuse_rows and tails is None and record is None and inject is None and self.ep is None and self.fuse_qkr
+        if (self.FUSE_DECODE_NORM and fuse_rows and tails is None and record is None and inject is None and self.ep is None and self.fuse_qkr and not mu
                 and cfg.head_dim == 64 and 256 <= H <= 1024 and H % 64 == 0
                 and (not cfg.is_moe or (cfg.shared_intermediate_size and 0 < B.plan.rows <= self.FUSE_MAX_ROWS))):
             # every row's logits are wanted (a decode step): the final norm writes the lm_head's activation planes itself
@@ -554,7 +572,20 @@ class I64MoEModel:
             if record is not None:
                 record[f"l{l}.in"] = B.h.clone()
             # the library's own conditions for the fused form (i64h_gemm_i8_qkv_rope_kv): other shapes take the two-kernel path
-            if fuse_rows and self.fuse_qkr and cfg.head_dim == 64 and 256 <= H <= 2048 and H % 64 == 0:
+            if mu:
+                # q, k, v = split(qkv_proj(x)) + mu_to_q / k / v(mu_prev) (model.py:160-170): three more Linear calls over the same
+                # input rows (one range, three weight scales), added in front of QK norm, RoPE and the cache write
+                self._linear(B.normed, W["qkv"], base + 0, B.xa, B.xs, B.qkv)
+                ops.rows_minmax(B.mu_prev, st, slot_base=base + self.mu_slot)
+                kvw, col = cfg.num_kv_heads * cfg.head_dim, 0
+                for name, wd in (("mu_q", H), ("mu_k", kvw), ("mu_v", kvw)):
+                    part = B.mu_out.view(-1)[: n * wd].view(n, wd)
+                    self._linear(B.mu_prev, W[name], base + self.mu_slot, B.xa, B.xs, part)
+                    ops.call("i64h_add_cols", ops.ptr(B.qkv) + 4 * col, B.qkv.shape[1], ops.ptr(part), n, wd, ops._stream())
+                    col += wd
+                ops.qk_norm_rope_kv(B.qkv, W["q_norm"], W["k_norm"], 1e-6, self.rope, positions, slot_ids, kvc.block_table,
+                                    kvc.k[l], kvc.v[l], cfg.num_heads, cfg.num_kv_heads, cfg.head_dim, q_out=B.q)
+            elif fuse_rows and self.fuse_qkr and cfg.head_dim == 64 and 256 <= H <= 2048 and H % 64 == 0:
                 # decode-sized step: projection, QK norm, RoPE and cache write in one launch (a 64-column tile is one head)
                 ops.gemm_i8_qkv_rope_kv(ops.gemm_desc(B.normed, W["qkv"].w_q, W["qkv"].w_s, B.qkv, a_slot_base=base + 0, stats=st, w_frags=self._wf(W["qkv"])),
                                         W["q_norm"], W["k_norm"], 1e-6, self.rope, positions, slot_ids, kvc.block_table, kvc.k[l], kvc.v[l],
@@ -638,6 +669,11 @@ class I64MoEModel:
                                             stats=None if last else st)
                 if record is not None:
                     record[f"l{l}.out"] = B.h.clone()
+            if mu and l + 1 < cfg.num_layers:
+                # mu for the next layer: clamp(clamp(mu, 0, 2) + mu_proj(h), -2, 2) on the layer's output rows (model.py:58-67, 431-432)
+                ops.rows_minmax(B.h, st, slot_base=base + self.mu_slot + 1)
+                self._linear(B.h, W["mu_proj"], base + self.mu_slot + 1, B.xa, B.xs, B.mu_out)
+                ops.call("i64h_mu_update", ops.ptr(W["mu"]), ops.ptr(B.mu_out), ops.ptr(B.mu_prev), n, H, ops._stream())
         self._lm_head(B, logit_rows)
         return B.logits
 
