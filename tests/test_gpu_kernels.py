@@ -457,11 +457,22 @@ def test_paged_attention_random(dev, hd, nh, kvh):
         torch.testing.assert_close(out[i], ref, rtol=1e-5, atol=2e-6)
 
 
+@pytest.fixture
+def head_split(request):
+    """The decode attention's form for head_dim 64 / 4 kv heads of 4 q heads: 1 = one kv head per workgroup (the default), 0 = all kv
+    heads per workgroup, -k = one kv head per workgroup with k context splits."""
+    ops = _ops()
+    ops.call("i64h_set_decode_attn_head_split", request.param)
+    yield request.param
+    ops.call("i64h_set_decode_attn_head_split", 1)
+
+
+@pytest.mark.parametrize("head_split", [1, 0, -3, -1], indirect=True)
 @pytest.mark.parametrize("block,splits,kv_dtype", [(16, 4, torch.float32), (16, 7, torch.bfloat16), (32, 5, torch.bfloat16), (12, 4, torch.float32),
                                                    (8, 16, torch.float32)])
-def test_paged_attention_split_interleave(dev, block, splits, kv_dtype):
+def test_paged_attention_split_interleave(dev, block, splits, kv_dtype, head_split):
     """Long and ragged contexts over many split iterations (and a block size that is not a power of two, which takes the
-    per-head kernel): every split count and block size gives the oracle's cached attention."""
+    per-head kernel): every split count, block size and form of the launch gives the oracle's cached attention."""
     ops = _ops()
     hd, nh, kvh = 64, 16, 4
     g = torch.Generator().manual_seed(block * 100 + splits)
@@ -739,9 +750,10 @@ def test_plan_with_embedding_rows_equals_the_two_launches(n):
     assert not torch.isnan(h_b).any() and int((st_b == 12345).sum()) == 0
 
 
+@pytest.mark.parametrize("head_split", [0], indirect=True)   # the form with all kv heads per workgroup is the one that has the stages
 @pytest.mark.parametrize("nh,kv_dtype,splits", [(16, torch.bfloat16, 8), (16, torch.float32, 3), (16, torch.float8_e4m3fn, 4),
-                                                (16, torch.float16, 16)])
-def test_decode_attention_with_three_iterations_in_flight(dev, nh, kv_dtype, splits):
+                                                (16, torch.float16, 16)])   # the form with all kv heads per workgroup is the one that has the stages
+def test_decode_attention_with_three_iterations_in_flight(dev, nh, kv_dtype, splits, head_split):
     """Split launches with few rows keep the K/V rows of three iterations in flight per wave (stages past the context are issued on
     clamped addresses and skipped): bit for bit the launch with one iteration in flight (row limit 0), and the oracle's cached
     attention; contexts around the iteration and stage boundaries, rows in permuted slots."""

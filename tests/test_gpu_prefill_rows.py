@@ -128,7 +128,8 @@ def test_fused_residual_norm_many_rows_equals_the_few_row_form(dev, H_, mode):
 
 
 @pytest.mark.parametrize("rows_,splits,kv_dtype,mode", [(700, 1, torch.bfloat16, 1), (700, 1, torch.float32, 1), (700, 1, torch.bfloat16, 0),
-                                                       (40, 1, torch.bfloat16, 1), (40, 4, torch.bfloat16, 1), (300, 3, torch.float32, 1)])
+                                                       (40, 1, torch.bfloat16, 1), (40, 4, torch.bfloat16, 1), (300, 3, torch.float32, 1), (10, 4, torch.bfloat16, 1),
+                                                       (10, 4, torch.float8_e4m3fn, 1)])
 def test_attention_folds_the_range_of_its_output_whichever_kernel_runs(dev, rows_, splits, kv_dtype, mode):
     """stats != NULL: the o projection's slot receives min / max (with zero) of the output from the many-row kernels' epilogue, the
     split merge, or a pass behind the unsplit row kernel - the same words a rows_minmax over the output leaves."""

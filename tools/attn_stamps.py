@@ -15,18 +15,29 @@ q = torch.randn(B, nh, hd, device=dev)
 cl = torch.full((B,), ctx, dtype=torch.int32, device=dev)
 out = torch.empty_like(q)
 ws = ops.attn_workspace(B, nh, hd, splits, dev)
+if os.environ.get("HEAD_SPLITS"):   # one kv head per workgroup with this many context splits (HEAD_SPLITS=1: the stamps end at index 3)
+    ops.call("i64h_set_decode_attn_head_split", -int(os.environ["HEAD_SPLITS"]))
+else:
+    ops.call("i64h_set_decode_attn_head_split", 0)
 junk = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
 for _ in range(3):
     ops.paged_attn(q, kc, vc, bt, cl, splits=splits, out=out, workspace=ws)
-buf = torch.zeros(B * splits * 8, dtype=torch.int64, device=dev)
+nwg = B * 4 * int(os.environ["HEAD_SPLITS"]) if os.environ.get("HEAD_SPLITS") else B * splits
+buf = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
 ops.call("i64h_debug_set_attn_stamps", ops.ptr(buf))
 junk.view(torch.int64).sum()   # cold caches by reading (a write flush leaves dirty lines to evict under the launch)
 ops.paged_attn(q, kc, vc, bt, cl, splits=splits, out=out, workspace=ws)
 torch.cuda.synchronize()
 ops.call("i64h_debug_set_attn_stamps", 0)
-st = buf.view(B * splits, 8).cpu().double()
+st = buf.view(nwg, 8).cpu().double()
 names = ["entry -> first rows requested", "-> token loop done", "-> partials written", "-> arrival counted"]
 d = st[:, 1:5] - st[:, 0:4]
+if os.environ.get("HEAD_SPLITS") == "1":
+    d3 = st[:, 1:4] - st[:, 0:3]
+    print(f"one workgroup per (row, kv head): lifetime median {(st[:, 3] - st[:, 0]).median():.0f} max {(st[:, 3] - st[:, 0]).max():.0f} ticks; entry -> first rows requested "
+          f"{d3[:, 0].median():.0f}, -> token loop done {d3[:, 1].median():.0f}, -> output and range written {d3[:, 2].median():.0f}; "
+          f"first entry to last stamp {st[:, :4].max() - st[:, 0].min():.0f} ticks")
+    sys.exit(0)
 print(f"batch {B} splits {splits} ctx {ctx}: workgroup lifetime median {(st[:, 4] - st[:, 0]).median():.0f} max {(st[:, 4] - st[:, 0]).max():.0f} ticks; "
       + ", ".join(f"{n} {d[:, j].median():.0f}" for j, n in enumerate(names)))
 last = st[:, 5] > 0

@@ -72,6 +72,7 @@ SIGNATURES: Dict[str, str] = {
     "i64h_paged_attn": "pppipippfppliiiiipip",
     "i64h_paged_attn_workspace_init": "pp",
     "i64h_set_decode_attn_deep_rows": "i",
+    "i64h_set_decode_attn_head_split": "i",
     "i64h_set_prefill_attn": "i",
     "i64h_debug_set_attn_stamps": "p",
     "i64h_gemm_i8_pair": "ppp",

@@ -807,7 +807,13 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict
 #ifndef I64H_AH_PDU
 #define I64H_AH_PDU 4  // 8-dim chunks per lane requested together (PD_U = this / CH)
 #endif
-template <int HD, int KVH, int GS, int CH, int NW, typename KV, bool DEEP = false>
+// KVT > KVH ("head split"): the cache rows hold KVT kv heads and the workgroup (row, split, blockIdx.z) takes kv heads
+// [blockIdx.z * KVH, + KVH) only: a token is then one 2 * HD * KVH-byte piece per K and V instead of the full row, but a launch has
+// KVT / KVH times the workgroups per context split.  Many rows: no context split at all - no partial results, no arrival count, no
+// merge, the workgroup folds the range of its heads into the stat slot itself.  Few rows: the vector instructions of a token (the
+// bound of a small launch) spread over KVT / KVH times the CUs, and the last-arriving workgroup of a (row, head group) merges that
+// group's partial results only.
+template <int HD, int KVH, int GS, int CH, int NW, typename KV, bool DEEP = false, int KVT = KVH>
 __global__ __launch_bounds__(NW * 64) void paged_attn_allheads_kernel(const float* __restrict__ q, const KV* __restrict__ k_cache,
                                                                   const KV* __restrict__ v_cache, const int32_t* __restrict__ block_table,
                                                                   int max_blocks_per_seq, const int32_t* __restrict__ slot_ids,
@@ -815,7 +821,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_allheads_kernel(const floa
                                                                   float* part_o, float* part_ml, int block,
                                                                   int splits, int* __restrict__ arrivals, uint32_t* __restrict__ stats,
                                                                   int stat_slot, unsigned long long* __restrict__ stamps) {
-#define PA_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PA_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     PA_STAMP(0);
     // A lane owns CH chunks of 8 dims of one kv head of one token: chunk j covers dims [(j * CPH + ch) * 8, +8), so one load
     // instruction reads CPH * 8 consecutive elements per head.  More dims per lane = fewer lanes per score: the cross-lane sums,
@@ -824,11 +830,16 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_allheads_kernel(const floa
     constexpr int LPT = KVH * CPH;      // lanes per token
     constexpr int TPS = 64 / LPT;       // tokens per wave step
     constexpr int NH = KVH * GS;
+    constexpr bool HSPLIT = KVT != KVH;
+    constexpr int NHT = KVT * GS;   // q heads of a row
+    constexpr int ROWE = KVT * HD;  // elements of a token's K (or V) row in the cache
     constexpr int PD_U = I64H_AH_PDU / CH;  // steps loaded together
     constexpr float LOG2E = 1.4426950408889634f;
     static_assert(64 % LPT == 0 && CPH >= 1 && (CH == 1 || CH == 2), "token row must fit a wave");
     __shared__ float s_m[NW][NH], s_l[NW][NH], s_o[NW][NH][HD];
     const int row = blockIdx.x, sp = blockIdx.y;
+    const int kv0 = HSPLIT ? blockIdx.z * KVH : 0;  // first kv head of this workgroup
+    const int unit = HSPLIT ? row * (KVT / KVH) + blockIdx.z : row;  // what the splits of one merge belong to: a row, or a row's head group
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ch = lane % CPH, kh = (lane / CPH) % KVH, tl = lane / LPT;
     const int ctx = ctx_len[row];
@@ -844,7 +855,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_allheads_kernel(const floa
     const int stride = splits * NW * TPI;
     const int t_begin = sp * NW * TPI;
     const int t_end = ctx;
-    const int lane_off = kh * HD;  // element offset of the lane's kv head inside a token row
+    const int lane_off = (kv0 + kh) * HD;  // element offset of the lane's kv head inside a token row
     // first dim of the lane's chunk j.  16- and 32-bit caches: chunk j of all chunk lanes is one run of CPH * 8 elements
     // (whole 64-byte pieces per load instruction); 8-bit caches: a lane's chunks are adjacent, i.e. one 16-byte load per lane.
     auto cdim = [&](int j) { return sizeof(KV) == 1 ? (ch * CH + j) * 8 : (j * CPH + ch) * 8; };
@@ -857,7 +868,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_allheads_kernel(const floa
     for (int h = 0; h < GS; ++h) {
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-            const float* qp = q + ((int64_t)row * NH + kh * GS + h) * HD + cdim(j);
+            const float* qp = q + ((int64_t)row * NHT + (kv0 + kh) * GS + h) * HD + cdim(j);
             float4 a = *(const float4*)qp, b = *(const float4*)(qp + 4);
             qr[h][j][0] = (v2f){a.x, a.y}; qr[h][j][1] = (v2f){a.z, a.w};
             qr[h][j][2] = (v2f){b.x, b.y}; qr[h][j][3] = (v2f){b.z, b.w};
@@ -896,7 +907,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_allheads_kernel(const floa
             const int tc = max(0, min(t, t_end - 1));
             const int pb = sg.pb[u];
             sg.live[u] = t < t_end && pb >= 0;
-            const int64_t off = ((int64_t)max(pb, 0) * block + (tc & (block - 1))) * (KVH * HD) + lane_off;
+            const int64_t off = ((int64_t)max(pb, 0) * block + (tc & (block - 1))) * ROWE + lane_off;
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 sg.k[u][j].load(k_cache + off + cdim(j));
@@ -992,7 +1003,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_allheads_kernel(const floa
             const int tc = max(0, min(t, t_end - 1));
             const int pb = pbn[u];
             nlive[u] = t < t_end && pb >= 0;
-            const int64_t off = ((int64_t)max(pb, 0) * block + (tc & (block - 1))) * (KVH * HD) + lane_off;
+            const int64_t off = ((int64_t)max(pb, 0) * block + (tc & (block - 1))) * ROWE + lane_off;
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
                 nk[u][j].load(k_cache + off + cdim(j));
@@ -1111,6 +1122,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_allheads_kernel(const floa
         }
     }
     __syncthreads();
+    float olo = 0.0f, ohi = 0.0f;  // head split: the range of this workgroup's outputs
     for (int i = threadIdx.x; i < NH * HD / 2; i += NW * 64) {  // two adjacent dims per thread: 8-byte stores
         const int h = i / (HD / 2), d = (i % (HD / 2)) * 2;
         float mm = s_m[0][h];
@@ -1126,28 +1138,42 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_allheads_kernel(const floa
                 o1 = __builtin_fmaf(f, s_o[w][h][d + 1], o1);
             }
         }
-        const int64_t head = (int64_t)row * NH + h;
+        const int64_t head = (int64_t)row * NHT + kv0 * GS + h;
         if (splits == 1) {
-            *(float2*)(out + head * HD + d) = make_float2((lt > 0.0f) ? o0 / lt : 0.0f, (lt > 0.0f) ? o1 / lt : 0.0f);
+            const float r0 = (lt > 0.0f) ? o0 / lt : 0.0f, r1 = (lt > 0.0f) ? o1 / lt : 0.0f;
+            *(float2*)(out + head * HD + d) = make_float2(r0, r1);
+            if (HSPLIT) { olo = fminf(olo, fminf(r0, r1)); ohi = fmaxf(ohi, fmaxf(r0, r1)); }
         } else {
             st_agent2(&part_o[(head * splits + sp) * HD + d], o0, o1);
             if (d == 0) st_agent2(&part_ml[(head * splits + sp) * 2], mm, lt);
         }
     }
-    if (splits == 1 || arrivals == nullptr) return;
+    if (HSPLIT && stats && splits == 1) {
+        __shared__ float s_lo[NW], s_hi[NW];
+        olo = wave_min(olo);
+        ohi = wave_max(ohi);
+        if (lane == 0) { s_lo[wid] = olo; s_hi[wid] = ohi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int w = 1; w < NW; ++w) { olo = fminf(olo, s_lo[w]); ohi = fmaxf(ohi, s_hi[w]); }
+            stat_update(stats, stat_slot, row, olo, ohi);
+        }
+    }
     PA_STAMP(3);
+    if (splits == 1 || arrivals == nullptr) return;
     __shared__ int s_last;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial results have left the CU ...
     __syncthreads();                                   // ... and so have those of the workgroup's other waves
     if (threadIdx.x == 0) {
-        const int seen = __hip_atomic_fetch_add(&arrivals[row], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int seen = __hip_atomic_fetch_add(&arrivals[unit], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = seen == splits - 1;
-        if (s_last) __hip_atomic_store(&arrivals[row], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (s_last) __hip_atomic_store(&arrivals[unit], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     PA_STAMP(4);
     if (s_last) {
-        attn_merge_row<true>(part_o, part_ml, out, row, NH, HD, splits, stats, stat_slot, 1);
+        attn_merge_row<true>(part_o, part_ml, out, unit, NH, HD, splits, stats, stat_slot, 1);  // heads [unit * NH, + NH)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PA_STAMP(5);
     }
@@ -1191,6 +1217,7 @@ static int dispatch_gs(int gs, int kv_dtype, const float* q, const void* kc, con
 
 #define PF_MIN_ROWS 256      // from this many rows on, the 16-row-tile matrix-core kernel is used (splits == 1, head_dim 64)
 static unsigned long long* g_attn_stamps = nullptr;  // diagnostics, see i64h_debug_set_attn_stamps
+static int g_decode_head_split = 1;  // 0: never; 1: decode launches of the shapes that have the form run one kv head per workgroup; -k: with k context splits (measurements)
 static int g_decode_deep_rows = 32;  // split launches of at most this many rows keep the K/V rows of three iterations in flight per wave; 0 = never
 static int g_prefill_mfma = 1;  // tuning / test knob: 0 = always the row-per-workgroup kernel, 1 = matrix cores (bf16 caches: three-term bf16 form), 2 = f32 matrix cores for every cache dtype
 #define ATTN_ARRIVALS 4096  // rows whose splits can be merged by the last-arriving workgroup
@@ -1212,6 +1239,10 @@ int i64h_debug_set_attn_stamps(void* buffer) {
     return 0;
 }
 
+int i64h_set_decode_attn_head_split(int32_t mode) {
+    g_decode_head_split = mode;
+    return 0;
+}
 int i64h_set_decode_attn_deep_rows(int32_t rows) {
     I64H_CHECK_ARG(rows >= 0, "set_decode_attn_deep_rows: negative");
     g_decode_deep_rows = rows;
@@ -1297,6 +1328,27 @@ int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, in
         if (HD_ == 64 && rows <= g_decode_deep_rows) AH_L(HD_, KVH_, GS_, CH_, NW_, T, (HD_ == 64)); \
         else AH_L(HD_, KVH_, GS_, CH_, NW_, T, false);                                 \
     } while (0)
+    bool head_split = false;
+    // head_dim 64, 4 kv heads of 4 q heads, 16- and 32-bit caches: one kv head per workgroup (see the kernel's comment), context
+    // splits so that rows x 4 x splits is about one workgroup per CU.  Measured against the split launch over all heads (bf16,
+    // context 2048, graph replays over rotating caches): batch 1: 16.1 -> 10.0 us, 8: 17.0 -> 12.3, 16: 18.1 -> 14.3, 32: 21.8 -> 20.5,
+    // 64: 33.9 -> 31.4, 96: 46.4 -> 45.1, 128: 53.6 -> 54.5
+    if (g_decode_head_split != 0 && splits > 1 && bp2 && head_dim == 64 && num_kv_heads == 4 && gs == 4 && kv_dtype <= 2 &&
+        rows * 4 <= ATTN_ARRIVALS) {
+        int hs = g_decode_head_split < 0 ? -g_decode_head_split : (int)(64 / rows);
+        hs = hs < 1 ? 1 : (hs > splits ? splits : hs);  // the caller sized the workspace for `splits`
+        dim3 grid((unsigned)rows, (unsigned)hs, 4);
+#define AHH(T)                                                                                                                                   \
+    hipLaunchKernelGGL((paged_attn_allheads_kernel<64, 1, 4, 1, 4, T, false, 4>), grid, dim3(256), 0, st, q, (const T*)k_cache, (const T*)v_cache, \
+                       block_table, max_blocks_per_seq, slot_ids, ctx_len, softmax_scale, out, part_o, part_ml, block_size, hs, arrivals, stats,  \
+                       stat_slot, g_attn_stamps)
+        if (kv_dtype == 0) AHH(float);
+        else if (kv_dtype == 1) AHH(__half);
+        else AHH(__hip_bfloat16);
+#undef AHH
+        done = head_split = true;
+        rc = 0;
+    }
 #define AH(HD_, KVH_, GS_, CH_, NW_)                                                                \
     if (!done && splits > 1 && bp2 && head_dim == HD_ && num_kv_heads == KVH_ && gs == GS_) {     \
         dim3 grid((unsigned)rows, (unsigned)splits);                                              \
@@ -1328,6 +1380,7 @@ int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, in
 #undef GO
     I64H_CHECK_ARG(rc == 0, "paged_attn: launch failed for group size %d", gs);
     I64H_CHECK_LAUNCH();
+    if (head_split) return 0;
     if (splits > 1 && !(done && arrivals)) {
         hipLaunchKernelGGL(attn_merge_kernel, dim3((unsigned)rows), dim3(256), 0, st, part_o, part_ml, out, (int)num_heads, (int)head_dim,
                            (int)splits, stats, (int)stat_slot, done ? 1 : 0);
