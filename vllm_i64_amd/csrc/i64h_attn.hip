@@ -1090,23 +1090,78 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_allheads_kernel(const floa
     }
     }
     PA_STAMP(2);
+    if constexpr (HSPLIT && NH == NW && CH == 1 && NW * TPS == 32) {
+        // One kv head per workgroup: 8 token lanes per wave, so the lane-exchange merge below would take three rounds over every
+        // accumulator register (120 exchanges per lane).  Instead every (wave, token lane) leaves its state in LDS as it is - 32
+        // states per workgroup - and wave w merges q head w: lane s finds the factor of state s (one exponential), lane d sums dim d.
+        constexpr int S = NW * TPS;        // states
+        constexpr int SSTR = NH * HD + 4;  // floats per state: 16 bytes of padding stagger the token lanes' 16-byte stores over the banks
+        __shared__ __attribute__((aligned(16))) float sx_o[S * SSTR];
+        __shared__ float sx_m[S][NH], sx_l[S][NH], sx_f[NW][S];
+        const int state = wid * TPS + tl;
+#pragma unroll
+        for (int h = 0; h < GS; ++h) {
+            float* po = &sx_o[state * SSTR + h * HD + ch * 8];
+            *(float4*)po = make_float4(acc[h][0][0].x, acc[h][0][0].y, acc[h][0][1].x, acc[h][0][1].y);
+            *(float4*)(po + 4) = make_float4(acc[h][0][2].x, acc[h][0][2].y, acc[h][0][3].x, acc[h][0][3].y);
+            if (ch == 0) { sx_m[state][h] = m[h]; sx_l[state][h] = l[h]; }  // identical in the chunk lanes of a token lane
+        }
+        __syncthreads();
+        const int hh = wid, sidx = lane & (S - 1);
+        const float ms = sx_m[sidx][hh];
+        const float mm = wave_max(ms);
+        const float f = (ms == -INFINITY) ? 0.0f : __builtin_amdgcn_exp2f(ms - mm);
+        const float lt = wave_sum(lane < S ? f * sx_l[sidx][hh] : 0.0f);
+        if (lane < S) sx_f[wid][lane] = f;
+        __syncthreads();
+        float o = 0.0f;
+#pragma unroll
+        for (int s4 = 0; s4 < S; s4 += 4) {
+            const float4 f4 = *(const float4*)&sx_f[wid][s4];
+            o = __builtin_fmaf(f4.x, sx_o[(s4 + 0) * SSTR + hh * HD + lane], o);
+            o = __builtin_fmaf(f4.y, sx_o[(s4 + 1) * SSTR + hh * HD + lane], o);
+            o = __builtin_fmaf(f4.z, sx_o[(s4 + 2) * SSTR + hh * HD + lane], o);
+            o = __builtin_fmaf(f4.w, sx_o[(s4 + 3) * SSTR + hh * HD + lane], o);
+        }
+        const int64_t head = (int64_t)row * NHT + kv0 * GS + hh;
+        if (splits == 1) {
+            const float r = (lt > 0.0f) ? o / lt : 0.0f;
+            out[head * HD + lane] = r;
+            if (stats) {
+                __shared__ float s_lo[NW], s_hi[NW];
+                const float olo = wave_min(fminf(r, 0.0f)), ohi = wave_max(fmaxf(r, 0.0f));
+                if (lane == 0) { s_lo[wid] = olo; s_hi[wid] = ohi; }
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    float a = s_lo[0], b = s_hi[0];
+#pragma unroll
+                    for (int w = 1; w < NW; ++w) { a = fminf(a, s_lo[w]); b = fmaxf(b, s_hi[w]); }
+                    stat_update(stats, stat_slot, row, a, b);
+                }
+            }
+            PA_STAMP(3);
+            return;
+        }
+        st_agent(&part_o[(head * splits + sp) * HD + lane], o);
+        if (lane == 0) st_agent2(&part_ml[(head * splits + sp) * 2], mm, lt);
+    } else {
     // merge the token lanes (same kv head and chunk, each with its own running maximum), then the waves through LDS
 #pragma unroll
     for (int h = 0; h < GS; ++h) {
 #pragma unroll
         for (int o = LPT; o < 64; o <<= 1) {
-            const float mm = fmaxf(m[h], __shfl_xor(m[h], o));
+            const float mm = pair_max(m[h], o);
             const float f = (m[h] == -INFINITY) ? 0.0f : __builtin_amdgcn_exp2f(m[h] - mm);
             m[h] = mm;
             l[h] *= f;
-            l[h] += __shfl_xor(l[h], o);
+            l[h] = pair_add(l[h], o);
 #pragma unroll
             for (int j = 0; j < CH; ++j)
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     acc[h][j][d] *= f;
-                    acc[h][j][d].x += __shfl_xor(acc[h][j][d].x, o);
-                    acc[h][j][d].y += __shfl_xor(acc[h][j][d].y, o);
+                    acc[h][j][d].x = pair_add(acc[h][j][d].x, o);
+                    acc[h][j][d].y = pair_add(acc[h][j][d].y, o);
                 }
         }
         if (tl == 0) {
@@ -1159,6 +1214,7 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_allheads_kernel(const floa
             for (int w = 1; w < NW; ++w) { olo = fminf(olo, s_lo[w]); ohi = fmaxf(ohi, s_hi[w]); }
             stat_update(stats, stat_slot, row, olo, ohi);
         }
+    }
     }
     PA_STAMP(3);
     if (splits == 1 || arrivals == nullptr) return;

@@ -120,6 +120,20 @@ __device__ __forceinline__ float lane_xor(float v, int o) {
     if (o == 16) { PairF r = swap_rows(v); return (threadIdx.x & 16) ? r.lo : r.hi; }
     return __shfl_xor(v, o);
 }
+// v + (v of lane ^ o) and max(v, v of lane ^ o), every lane with the same bits as its partner: register exchanges for compile-time
+// o = 32, 16 (lane swaps) and 8 (row rotation), the LDS shuffle otherwise
+__device__ __forceinline__ float pair_add(float v, int o) {
+    if (o == 32) { PairF r = swap_halves(v); return r.lo + r.hi; }
+    if (o == 16) { PairF r = swap_rows(v); return r.lo + r.hi; }
+    if (o == 8) return v + I64H_DPPF(v, 0x128);  // row_ror:8
+    return v + __shfl_xor(v, o);
+}
+__device__ __forceinline__ float pair_max(float v, int o) {
+    if (o == 32) { PairF r = swap_halves(v); return fmaxf(r.lo, r.hi); }
+    if (o == 16) { PairF r = swap_rows(v); return fmaxf(r.lo, r.hi); }
+    if (o == 8) return fmaxf(v, I64H_DPPF(v, 0x128));
+    return fmaxf(v, __shfl_xor(v, o));
+}
 __device__ __forceinline__ float wave_max(float v) {  // register-to-register lane exchanges only (no LDS round trips)
     v = row16_max(v);
     PairF a = swap_rows(v);
