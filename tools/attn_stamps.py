@@ -32,6 +32,14 @@ ops.call("i64h_debug_set_attn_stamps", 0)
 st = buf.view(nwg, 8).cpu().double()
 names = ["entry -> first rows requested", "-> token loop done", "-> partials written", "-> arrival counted"]
 d = st[:, 1:5] - st[:, 0:4]
+place = buf.view(nwg, 8)[:, 6].cpu()
+cu = ((place >> 32) & 0xf) * 4096 + ((place >> 13) & 0x7) * 512 + ((place >> 12) & 0x1) * 256 + ((place >> 8) & 0xf)   # (xcc, se, sh, cu)
+uniq, counts = torch.unique(cu, return_counts=True)
+life = (st[:, 3] - st[:, 0]) if os.environ.get("HEAD_SPLITS") == "1" else (st[:, 4] - st[:, 0])
+per = {int(k): int(c) for k, c in zip(uniq, counts)}
+shared = torch.tensor([per[int(c)] > 1 for c in cu])
+print(f"{nwg} workgroups on {len(uniq)} CUs; workgroups per CU: " + ", ".join(f"{int(n)} CUs x {int(k)}" for k, n in zip(*torch.unique(counts, return_counts=True)))
+      + (f"; lifetime median alone {life[~shared].median():.0f}" if (~shared).any() else "") + (f", sharing a CU {life[shared].median():.0f}" if shared.any() else ""))
 if os.environ.get("HEAD_SPLITS") == "1":
     d3 = st[:, 1:4] - st[:, 0:3]
     print(f"one workgroup per (row, kv head): lifetime median {(st[:, 3] - st[:, 0]).median():.0f} max {(st[:, 3] - st[:, 0]).max():.0f} ticks; entry -> first rows requested "

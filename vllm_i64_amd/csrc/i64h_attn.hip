@@ -792,6 +792,86 @@ __global__ __launch_bounds__(256) void attn_merge_kernel(const float* __restrict
     attn_merge_row<false>(part_o, part_ml, out, blockIdx.x, nh, HD, splits, stats, stat_slot, base2);
 }
 
+// (A matrix-core form of the one-kv-head-per-workgroup launch was built, measured and not kept: S^T = K . Q^T with K rows straight from
+// global memory as the row operand, V through a wave-private LDS image and the transposing read, three-term bf16 products, every wave
+// on its own with three register stages in flight - 27 matrix instructions and ~150 vector instructions per 32 tokens instead of
+// ~480.  It matched to 1e-7 and was faster only where a workgroup's loop is long (batch 16 without context splits 23.6 -> 17.5 us);
+// at the split counts the launcher picks the loop is already at the memory rate - batch 16: 35.6 MB in 14 k cycles = 5.1 TB/s - and
+// the launch is its fixed chain: 13.2 -> 13.0 us at batch 16, 8.9 -> 9.0 at batch 1, 28.6 -> 30.1 at batch 64.)
+// ---- shared tails of the decode kernels ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pa_stamp(unsigned long long* stamps, int i) {
+    if (stamps && threadIdx.x == 0)
+        stamps[(((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + i] = __builtin_amdgcn_s_memtime();
+}
+// The NW per-wave states (running maximum, sum, accumulators of NH heads) of a workgroup, merged: the output rows when the context is
+// not split (FOLD: with their range folded into the stat slot), this split's partial results otherwise.  head0: first output head.
+template <int NH, int HD, int NW, bool FOLD>
+__device__ __forceinline__ void decode_merge_waves(const float (&s_m)[NW][NH], const float (&s_l)[NW][NH], const float (&s_o)[NW][NH][HD],
+                                                   const int64_t head0, const int row, const int sp, const int splits, float* __restrict__ out,
+                                                   float* part_o, float* part_ml, uint32_t* __restrict__ stats, const int stat_slot) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float olo = 0.0f, ohi = 0.0f;
+    for (int i = threadIdx.x; i < NH * HD / 2; i += NW * 64) {  // two adjacent dims per thread: 8-byte stores
+        const int h = i / (HD / 2), d = (i % (HD / 2)) * 2;
+        float mm = s_m[0][h];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) mm = fmaxf(mm, s_m[w][h]);
+        float lt = 0.0f, o0 = 0.0f, o1 = 0.0f;
+        if (mm != -INFINITY) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const float f = (s_m[w][h] == -INFINITY) ? 0.0f : exp2f(s_m[w][h] - mm);
+                lt = __builtin_fmaf(f, s_l[w][h], lt);
+                o0 = __builtin_fmaf(f, s_o[w][h][d], o0);
+                o1 = __builtin_fmaf(f, s_o[w][h][d + 1], o1);
+            }
+        }
+        const int64_t head = head0 + h;
+        if (splits == 1) {
+            const float r0 = (lt > 0.0f) ? o0 / lt : 0.0f, r1 = (lt > 0.0f) ? o1 / lt : 0.0f;
+            *(float2*)(out + head * HD + d) = make_float2(r0, r1);
+            if (FOLD) { olo = fminf(olo, fminf(r0, r1)); ohi = fmaxf(ohi, fmaxf(r0, r1)); }
+        } else {
+            st_agent2(&part_o[(head * splits + sp) * HD + d], o0, o1);
+            if (d == 0) st_agent2(&part_ml[(head * splits + sp) * 2], mm, lt);
+        }
+    }
+    if (FOLD && stats && splits == 1) {
+        __shared__ float s_lo[NW], s_hi[NW];
+        olo = wave_min(olo);
+        ohi = wave_max(ohi);
+        if (lane == 0) { s_lo[wid] = olo; s_hi[wid] = ohi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int w = 1; w < NW; ++w) { olo = fminf(olo, s_lo[w]); ohi = fmaxf(ohi, s_hi[w]); }
+            stat_update(stats, stat_slot, row, olo, ohi);
+        }
+    }
+}
+// This workgroup's partial results are out: count its arrival; the last of the unit's (a row's, or a row's head group's) `splits`
+// workgroups merges them.  The counter is left at zero for the next launch.
+template <int NH, int HD>
+__device__ __forceinline__ void decode_arrive_merge(const int unit, const int splits, int* __restrict__ arrivals, const float* part_o,
+                                                    const float* part_ml, float* __restrict__ out, uint32_t* __restrict__ stats,
+                                                    const int stat_slot, unsigned long long* stamps) {
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial results have left the CU ...
+    __syncthreads();                                   // ... and so have those of the workgroup's other waves
+    if (threadIdx.x == 0) {
+        const int seen = __hip_atomic_fetch_add(&arrivals[unit], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = seen == splits - 1;
+        if (s_last) __hip_atomic_store(&arrivals[unit], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    pa_stamp(stamps, 4);
+    if (s_last) {
+        attn_merge_row<true>(part_o, part_ml, out, unit, NH, HD, splits, stats, stat_slot, 1);  // heads [unit * NH, + NH)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pa_stamp(stamps, 5);
+    }
+}
+
 // ---- decode form: one workgroup = (query row, split), ALL kv heads --------------------------------------------------
 // In the cache a token's K (or V) for all kv heads is one contiguous KVH*HD-element row, so a wave-instruction that
 // covers whole token rows is fully coalesced (512-B segments at 4 x 64 bf16) instead of one 128-B piece per token.
@@ -823,6 +903,12 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_allheads_kernel(const floa
                                                                   int stat_slot, unsigned long long* __restrict__ stamps) {
 #define PA_STAMP(i) do { if (stamps && threadIdx.x == 0) stamps[(((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     PA_STAMP(0);
+    if (stamps && threadIdx.x == 0) {  // where the workgroup runs: HW_ID (CU, shader array, shader engine) and the XCC
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        stamps[(((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + 6] = ((unsigned long long)xcc << 32) | hw;
+    }
     // A lane owns CH chunks of 8 dims of one kv head of one token: chunk j covers dims [(j * CPH + ch) * 8, +8), so one load
     // instruction reads CPH * 8 consecutive elements per head.  More dims per lane = fewer lanes per score: the cross-lane sums,
     // the exponentials and the softmax bookkeeping are per (lane, head, token) and shrink with 1 / CH per cached byte.
@@ -1177,62 +1263,11 @@ __global__ __launch_bounds__(NW * 64) void paged_attn_allheads_kernel(const floa
         }
     }
     __syncthreads();
-    float olo = 0.0f, ohi = 0.0f;  // head split: the range of this workgroup's outputs
-    for (int i = threadIdx.x; i < NH * HD / 2; i += NW * 64) {  // two adjacent dims per thread: 8-byte stores
-        const int h = i / (HD / 2), d = (i % (HD / 2)) * 2;
-        float mm = s_m[0][h];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) mm = fmaxf(mm, s_m[w][h]);
-        float lt = 0.0f, o0 = 0.0f, o1 = 0.0f;
-        if (mm != -INFINITY) {
-#pragma unroll
-            for (int w = 0; w < NW; ++w) {
-                const float f = (s_m[w][h] == -INFINITY) ? 0.0f : exp2f(s_m[w][h] - mm);
-                lt = __builtin_fmaf(f, s_l[w][h], lt);
-                o0 = __builtin_fmaf(f, s_o[w][h][d], o0);
-                o1 = __builtin_fmaf(f, s_o[w][h][d + 1], o1);
-            }
-        }
-        const int64_t head = (int64_t)row * NHT + kv0 * GS + h;
-        if (splits == 1) {
-            const float r0 = (lt > 0.0f) ? o0 / lt : 0.0f, r1 = (lt > 0.0f) ? o1 / lt : 0.0f;
-            *(float2*)(out + head * HD + d) = make_float2(r0, r1);
-            if (HSPLIT) { olo = fminf(olo, fminf(r0, r1)); ohi = fmaxf(ohi, fmaxf(r0, r1)); }
-        } else {
-            st_agent2(&part_o[(head * splits + sp) * HD + d], o0, o1);
-            if (d == 0) st_agent2(&part_ml[(head * splits + sp) * 2], mm, lt);
-        }
-    }
-    if (HSPLIT && stats && splits == 1) {
-        __shared__ float s_lo[NW], s_hi[NW];
-        olo = wave_min(olo);
-        ohi = wave_max(ohi);
-        if (lane == 0) { s_lo[wid] = olo; s_hi[wid] = ohi; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int w = 1; w < NW; ++w) { olo = fminf(olo, s_lo[w]); ohi = fmaxf(ohi, s_hi[w]); }
-            stat_update(stats, stat_slot, row, olo, ohi);
-        }
-    }
+    decode_merge_waves<NH, HD, NW, HSPLIT>(s_m, s_l, s_o, (int64_t)row * NHT + kv0 * GS, row, sp, splits, out, part_o, part_ml, stats, stat_slot);
     }
     PA_STAMP(3);
     if (splits == 1 || arrivals == nullptr) return;
-    __shared__ int s_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's partial results have left the CU ...
-    __syncthreads();                                   // ... and so have those of the workgroup's other waves
-    if (threadIdx.x == 0) {
-        const int seen = __hip_atomic_fetch_add(&arrivals[unit], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = seen == splits - 1;
-        if (s_last) __hip_atomic_store(&arrivals[unit], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    PA_STAMP(4);
-    if (s_last) {
-        attn_merge_row<true>(part_o, part_ml, out, unit, NH, HD, splits, stats, stat_slot, 1);  // heads [unit * NH, + NH)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        PA_STAMP(5);
-    }
+    decode_arrive_merge<NH, HD>(unit, splits, arrivals, part_o, part_ml, out, stats, stat_slot, stamps);
 #undef PA_STAMP
 }
 
