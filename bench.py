@@ -385,9 +385,14 @@ def main():
                     traffic = int((kd["hbm_read_bytes_corrected"] + kd["hbm_write_bytes"]) * ctx_now / ctx_prof)
     except Exception:
         traffic = None
-    roofline = {"bound": "hbm", "kernel": "paged_attn_allheads_kernel of one layer (split merge included)", "achieved": round(achieved, 1),
+    # what the library launches for these shapes (i64h_paged_attn): one kv head per workgroup when the shape has that form
+    head_form = (cfg.head_dim == 64 and cfg.num_kv_heads == 4 and cfg.num_heads == 16 and kvb >= 2 and splits > 1)
+    ctx_splits = max(1, min(splits, 64 // B)) if head_form else splits
+    kname = (f"paged_attn_allheads_kernel of one layer ({'one kv head per workgroup, ' if head_form else ''}"
+             f"{'context unsplit' if ctx_splits == 1 else str(ctx_splits) + ' context splits, merge included'})")
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "avg_launch_ms": round(attn_ms, 4), "algorithmic_bytes_per_launch": attn_bytes, "splits": splits,
+                "avg_launch_ms": round(attn_ms, 4), "algorithmic_bytes_per_launch": attn_bytes, "splits": splits, "context_splits_launched": ctx_splits,
                 "share_of_step": round(attn_ms * cfg.num_layers / ms_per_step, 3)}
 
     # ---- the whole decode step against HBM: bytes a step cannot avoid (every weight once, the cached K/V rows once, the
