@@ -520,11 +520,13 @@ int i64h_advance(int32_t* positions, int32_t* ctx_len, int64_t n, void* stream);
  * ctx_len[r] cached tokens of sequence slot_ids[r] (NULL: r).  Replaces naive_paged_decode_attention
  * (vllm_i64/layers/attention.py:517-601), naive_cached_attention (190-245) and the model's per-sequence cache loop
  * (model.py:203-236).  workspace: i64h_paged_attn_workspace_floats(...) 32-bit words when splits > 1; it starts with
- * per-row arrival counters that must be zero before the first launch using the buffer (i64h_paged_attn_workspace_init,
- * once after allocation) and that every launch leaves zero: the splits of a row are merged by the row's last-finishing
- * workgroup, so launches sharing one workspace must not overlap.  With stats != NULL the minimum and maximum of the
- * output (with zero) are folded into stat slot stat_slot - the input statistics of o_proj - by the split merge, by the
- * many-row kernels' own epilogue, or by a pass over the output behind the one kernel that has neither. */
+ * arrival counters (per row, or per row and kv head) that must be zero before the first launch using the buffer
+ * (i64h_paged_attn_workspace_init, once after allocation) and that every launch leaves zero: the splits of a row (or of a
+ * row's head group) are merged by their last-finishing workgroup, so launches sharing one workspace must not overlap.
+ * splits is an upper bound: the library may split a context fewer ways when it spreads a row's kv heads over workgroups
+ * instead (i64h_set_decode_attn_head_split).  With stats != NULL the minimum and maximum of the output (with zero) are
+ * folded into stat slot stat_slot - the input statistics of o_proj - by the split merge, by the unsplit kernels' own
+ * epilogue, or by a pass over the output behind the one kernel that has neither. */
 int64_t i64h_paged_attn_workspace_floats(int64_t rows, int32_t num_heads, int32_t head_dim, int32_t splits);
 int i64h_paged_attn_workspace_init(float* workspace, void* stream);
 int i64h_debug_set_attn_stamps(void* buffer); /* diagnostics: 8 uint64 of s_memtime phase stamps per workgroup of the decode attention kernel; NULL = off */
