@@ -17,6 +17,7 @@ roofline objects of the dominant decode kernel and of the grouped expert GEMM, a
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -260,6 +261,13 @@ def main():
         model = I64MoEModel(cfg, weights, device=dev, kv_dtype=kv_dtype, max_seqs=B, expert_parallel=expert_parallel, quant=args.weights)
         multi_ep = model.ep is not None   # collectives on the data path (several ranks, or one rank with them forced)
         dec = GreedyDecoder(model, B, use_graph=not (args.no_graph or multi_ep))
+        if os.environ.get("I64_BENCH_GC", "freeze") == "freeze":
+            # the interpreter's cycle collector would otherwise pick its own moment for a full pass over everything the imports
+            # left behind - tens of milliseconds of a host that enqueues nothing, and a moment that moves with the interpreter's
+            # allocation history (measured: one 33-37 ms idle gap of the GPU in the second prefill chunk of every process but the
+            # first on a box, none in the first).  What exists now is set aside once, as serving engines do after start-up.
+            gc.collect()
+            gc.freeze()
         prefill_tps = fill_cache(model, dec)
         dec.prepare()  # buffer allocation and graph capture are set-up, not steps (no state advances)
         elapsed = timed_steps(dec, give_up)
@@ -487,7 +495,6 @@ def main():
     if dist is not None:
         # tear-down must never cost the result: captured graphs hold kernels of the collective library, so release them first,
         # and leave without the orderly shutdown if that does not come back
-        import gc
         import threading
         bail = threading.Timer(30.0, lambda: os._exit(0))
         bail.daemon = True

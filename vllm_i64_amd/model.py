@@ -303,10 +303,9 @@ class I64MoEModel:
             self._bufs[key] = _Buffers(self.cfg, n, n_logit_rows, self.device, ep_world=ep_world)
         return self._bufs[key]
 
-    # e4m3 runner, prefill chunks: residual + norm + per-token quantization in one pass.  Off by default: the pass itself is faster
-    # (40.8 us against 46.5 + 22.8 us, 13 ms less kernel time per prefill in the kernel trace), but on a box that has run other
-    # processes before the prefill as a whole measured slower with it (545-595 k against 676-680 k tokens/s; 724-728 k on a fresh box)
-    FP8_FUSE_NORM = os.environ.get("I64H_FP8_FUSE_NORM", "0") == "1"
+    # e4m3 runner, prefill chunks: residual + norm + per-token quantization in one pass (40.8 us against 46.5 + 22.8 us per launch,
+    # bit-identical; prefill 656-665 k -> 716 k tokens/s in alternating processes on one box; "0" keeps the two launches)
+    FP8_FUSE_NORM = os.environ.get("I64H_FP8_FUSE_NORM", "1") != "0"
     # e4m3 runner, decode-sized steps: QK norm + RoPE + cache write in the epilogue of the qkv projection (8 instead of 9 launches per
     # layer, bit-identical; 2.017 -> 1.992 ms per step once the kernel had its helper waves - before that it measured slower)
     FP8_FUSE_QKV = os.environ.get("I64H_FP8_FUSE_QKV", "1") != "0"
@@ -762,7 +761,7 @@ class I64MoEModel:
             B.attn_splits = splits
         S = cfg.shared_intermediate_size if cfg.is_moe else 0
         small = n * max(1, cfg.top_k if cfg.is_moe else 1) <= self.FUSE_MAX_ROWS
-        # prefill-sized chunks (opt-in, see FP8_FUSE_NORM): the norm quantizes the normalised rows itself (a row's scale needs only that
+        # prefill-sized chunks (see FP8_FUSE_NORM): the norm quantizes the normalised rows itself (a row's scale needs only that
         # row), the fp32 rows are not stored; decode-sized steps quantize inside their GEMMs; recording runs keep the fp32 rows
         nq = self.FP8_FUSE_NORM and not small and record is None and H <= 1024 and H % 4 == 0
         if nq:
