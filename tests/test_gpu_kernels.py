@@ -810,3 +810,58 @@ def test_final_norm_writes_the_lm_head_planes(dev, n, H):
         got = ops.lm_head_planes(ws2, embed, torch.empty(n, V, device=dev))
         assert torch.equal(h1, h2) and torch.equal(x1, x2)
         assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("rows_,splits,kv_dtype", [(1, 8, torch.bfloat16), (5, 8, torch.float32), (17, 8, torch.bfloat16), (33, 2, torch.float16),
+                                                   (70, 3, torch.bfloat16), (130, 2, torch.float32)])
+def test_decode_attention_one_kv_head_per_workgroup_against_all_heads_per_workgroup(dev, rows_, splits, kv_dtype):
+    """The two forms of the split decode launch at head_dim 64 / 4 kv heads of 4 q heads - one kv head per workgroup (context splits chosen by
+    the library from the row count) and all kv heads per workgroup - over random contexts (one empty, one of a single token), rows in
+    permuted slots, with the output's range folded into a stat slot: same rows to a few ulps, same range words, and the oracle's cached
+    attention on a sample of the rows."""
+    ops = _ops()
+    hd, nh, kvh, block = 64, 16, 4, 16
+    g = torch.Generator().manual_seed(rows_ * 7 + splits)
+    lens = torch.randint(1, 900, (rows_,), generator=g).tolist()
+    lens[0] = 1
+    if rows_ > 2:
+        lens[rows_ // 2] = 0
+    per = [(n + block - 1) // block for n in lens]
+    nblk = sum(per) + 2
+    kc = torch.empty(nblk, block, kvh, hd).normal_(0, 1, generator=g).to(kv_dtype)
+    vc = torch.empty(nblk, block, kvh, hd).normal_(0, 1, generator=g).to(kv_dtype)
+    perm = torch.randperm(nblk, generator=g).to(torch.int32)
+    slots = torch.randperm(rows_, generator=g).to(torch.int32)
+    bt = torch.full((rows_, max(per) + 1), -1, dtype=torch.int32)
+    used = 0
+    for i, nb in enumerate(per):
+        bt[slots[i], :nb] = perm[used:used + nb]
+        used += nb
+    q = torch.empty(rows_, nh, hd).normal_(0, 1, generator=g)
+    args = (q.to(dev), kc.to(dev), vc.to(dev), bt.to(dev), torch.tensor(lens, dtype=torch.int32, device=dev))
+    res = {}
+    for mode in (1, 0):
+        ops.call("i64h_set_decode_attn_head_split", mode)
+        try:
+            st = ops.stats_alloc(2, dev)
+            ops.stats_reset(st)
+            out = ops.paged_attn(*args, slot_ids=slots.to(dev), splits=splits, stats=st, stat_slot=1)
+            res[mode] = (out.cpu(), [t.cpu() for t in ops.qparams(st, 2)])
+        finally:
+            ops.call("i64h_set_decode_attn_head_split", 1)
+    torch.testing.assert_close(res[1][0], res[0][0], rtol=2e-6, atol=1e-6)
+    lo_hi = [r[1][2][1] for r in (res[1], res[0])]
+    torch.testing.assert_close(lo_hi[0], lo_hi[1], rtol=2e-6, atol=1e-6)
+    ref_range = torch.tensor([min(float(res[1][0].min()), 0.0), max(float(res[1][0].max()), 0.0)])
+    assert torch.equal(lo_hi[0], ref_range)   # the slot holds exactly the range of the rows this form wrote
+    if rows_ > 2:
+        assert not res[1][0][rows_ // 2].any()   # the row without context stores zeros
+    for i in list(range(0, rows_, max(1, rows_ // 6)))[:8]:
+        c = lens[i]
+        if c == 0:
+            continue
+        rws = bt[slots[i], :per[i]].long()
+        kf = kc[rws].reshape(-1, kvh, hd)[:c].float()
+        vf = vc[rws].reshape(-1, kvh, hd)[:c].float()
+        ref = M.cached_attention(q[i:i + 1], kf, vf, nh // kvh, torch.tensor([c - 1]), 1.0 / hd ** 0.5)[0]
+        torch.testing.assert_close(res[1][0][i], ref, rtol=1e-5, atol=3e-6)
