@@ -309,6 +309,10 @@ typedef struct i64h_fp8_rows_desc {
     float* C;                       /* [M, N] or [M, N / 2] (epilogue 1) */
     const int32_t* c_row_map;       /* output row r stored at row c_row_map[r] (NULL: r) */
     int32_t b_frags;                /* 1 = B points to the fragment pack of the e4m3 bytes (i64h_pack_weight_frags; N % 16 == 0, epilogue 1: N % 32 == 0) */
+    const float* c_add;             /* epilogue 0: C = c_add + product, rows as C (the residual add of the decoder layer, model.py:421-427; may be C itself; NULL: none) */
+    const float* norm_w;            /* RMSNorm weight [K] (K <= 1024): the operand rows are normalised in front of the quantizer, bit for bit
+                                       i64h_fused_residual_norm's rows (the layer's input_layernorm / post_attention_layernorm, model.py:419-425; NULL: none) */
+    float norm_eps;
 } i64h_fp8_rows_desc;
 int i64h_gemm_fp8_rows_pair(const i64h_fp8_rows_desc* a, const i64h_fp8_rows_desc* b, int32_t epilogue, void* stream);
 /* Decode-sized fused form for e4m3 weights: qkv projection (one problem of i64h_gemm_fp8_rows_pair, epilogue 0: one group, no row

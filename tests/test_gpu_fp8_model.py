@@ -319,6 +319,34 @@ def test_fp8_decode_steps_with_the_fused_qkv_launch_give_the_same_bits(dev):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("name", ["tiny-moe", "tiny-dense"])
+def test_fp8_decode_steps_without_norm_and_residual_launches_give_the_same_bits(dev, name):
+    """Greedy decode steps (eager and as a graph) of the e4m3 runner on models with 64-wide heads: with the residual adds in the o / down
+    projections' epilogues and RMSNorm in front of the quantizers of the qkv / gate_up launches, against the launches they replace -
+    logits bit for bit."""
+    import dataclasses
+    from vllm_i64_amd.config import ModelConfig
+    from vllm_i64_amd.model import GreedyDecoder, I64MoEModel
+    ocfg = dataclasses.replace(M.named_config(name), hidden_size=256, num_heads=4, num_kv_heads=2, name=name + "-hd64")
+    w = M.make_weights(ocfg, seed=0)
+    model = I64MoEModel(ModelConfig.from_any(ocfg), w, device=dev, max_seqs=3, num_kv_blocks=64, quant="fp8")
+    assert model.cfg.head_dim == 64 and I64MoEModel.FP8_FUSE_DECODE_NORM
+    ids = M.make_token_ids(ocfg, 45, seed=6)
+    outs = []
+    for fused, graph in ((True, False), (False, False), (True, True)):
+        for s in range(3):
+            model.kv.free(s)
+        model.FP8_FUSE_DECODE_NORM = fused
+        try:
+            dec = GreedyDecoder(model, 3, use_graph=graph)
+            dec.prefill([ids[:20], ids[20:27], ids[27:]], reserve_extra=8)
+            outs.append(torch.stack([dec.step().clone() for _ in range(4)]).cpu())   # (later steps read the earlier steps' cache rows)
+        finally:
+            model.FP8_FUSE_DECODE_NORM = I64MoEModel.FP8_FUSE_DECODE_NORM
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert outs[0].abs().sum() > 0
+
+
 @pytest.mark.parametrize("scenario", ["prefill4096", "decode64"])
 def test_fp8_model_at_the_bench_dimensions(dev, scenario):
     """The fp8 configuration at trhash500m-synth's real dimensions (two-layer cut), teacher-forced against the oracle's "fp8" mode:
@@ -380,3 +408,74 @@ def test_fp8_model_at_the_bench_dimensions(dev, scenario):
         # random weights give flat logits: a mean distance of 2e-2 already moves the arg max of about one row in ten (the reference's
         # two branches agree on 0.85-0.9 of these rows)
         assert agree >= (g.argmax(-1) == deq.argmax(-1)).float().mean().item() - 0.1 and agree >= 0.8
+
+
+@pytest.mark.parametrize("K,n", [(1024, 64), (768, 21), (256, 5), (320, 33)])
+def test_fp8_rows_with_the_norm_in_front_and_the_residual_behind(dev, K, n):
+    """The decode-sized e4m3 Linear with (a) the RMSNorm of its operand rows in front of its quantizer and (b) the residual add in its
+    epilogue, against the launches they replace (i64h_fused_residual_norm in front, a separate add behind): bit for bit - plain and
+    SwiGLU epilogues, gathered rows of a grouped problem, weights row-major and as a fragment pack, and the fused qkv form."""
+    from vllm_i64_amd import ops
+    from vllm_i64_amd.model import pack_fp8, rope_table
+    g = torch.Generator().manual_seed(K + n)
+    eps = 1e-6
+    h = (torch.empty(n, K).normal_(0, 1.5, generator=g) + 0.2).to(dev)
+    nw = (torch.rand(K, generator=g) + 0.5).to(dev)
+    normed = torch.empty_like(h)
+    ops.fused_residual_norm(h, nw, eps, normed=normed)
+    # (a) plain epilogue, packed and row-major weights
+    N = 192
+    W = pack_fp8(torch.empty(N, K).normal_(0, 0.05, generator=g), dev)
+    for wf in (None, W.frags(False)):
+        ref = ops.gemm_fp8_rows(normed, W.w_q, W.w_s, torch.empty(n, N, device=dev), w_frags=wf)
+        got = ops.gemm_fp8_rows(h, W.w_q, W.w_s, torch.empty(n, N, device=dev), w_frags=wf, norm_w=nw, norm_eps=eps)
+        assert torch.equal(ref, got)
+        assert ref.abs().sum() > 0
+    # (a) SwiGLU epilogue over gathered rows of three groups, in a pair with an ungrouped problem that has no norm
+    G, I2 = 3, 128
+    Wg = pack_fp8(torch.empty(G, 2 * I2, K).normal_(0, 0.05, generator=g), dev)
+    R = 2 * n
+    src = torch.randint(0, n, (R,), generator=g).to(torch.int32).to(dev)
+    cuts = sorted(torch.randint(0, R + 1, (G - 1,), generator=g).tolist())
+    offs = torch.tensor([0] + cuts + [R], dtype=torch.int32, device=dev)
+    outs = []
+    for fused in (False, True):
+        o1, o2 = torch.zeros(R, I2, device=dev), torch.zeros(n, I2, device=dev)
+        a = normed if not fused else h
+        kw = dict(norm_w=nw, norm_eps=eps) if fused else {}
+        ops.gemm_fp8_rows_pair(
+            ops.fp8_rows_desc(normed, Wg.w_q[0], Wg.w_s[0], o2, w_frags=None),
+            ops.fp8_rows_desc(a, Wg.w_q, Wg.w_s, o1, m=R, a_src_row=src, a_src_mod=n, group_offsets=offs, w_frags=Wg.frags(True), **kw),
+            epilogue=ops.EPI_SWIGLU)
+        outs.append((o1.clone(), o2.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert outs[0][0].abs().sum() > 0
+    # (b) the residual add: out = c_add + product, in place
+    x = torch.empty(n, 128).normal_(0, 1, generator=g).to(dev)
+    Wo = pack_fp8(torch.empty(K, 128).normal_(0, 0.05, generator=g), dev)
+    prod = ops.gemm_fp8_rows(x, Wo.w_q, Wo.w_s, torch.empty(n, K, device=dev))
+    acc = h.clone()
+    ops.gemm_fp8_rows(x, Wo.w_q, Wo.w_s, acc, c_add=acc)
+    assert torch.equal(acc, h + prod)
+    # the fused qkv form with the norm in front
+    if K >= 256:
+        nh, kvh, hd = 2, 1, 64
+        tab = rope_table(64, hd, 10000.0).to(dev)
+        Wq = pack_fp8(torch.empty((nh + 2 * kvh) * hd, K).normal_(0, 0.05, generator=g), dev)
+        qw, kwt = (torch.rand(hd, generator=g) + 0.5).to(dev), (torch.rand(hd, generator=g) + 0.5).to(dev)
+        slot = (torch.arange(n, dtype=torch.int32) % 5).to(dev)
+        pos = (torch.arange(n, dtype=torch.int32) // 5 + 1).to(dev)
+        bt = torch.randperm(5 * 4, generator=g).to(torch.int32).view(5, 4).to(dev)
+        res = []
+        for fused in (False, True):
+            kc = torch.zeros(20, 16, kvh, hd, device=dev)
+            vc = torch.zeros(20, 16, kvh, hd, device=dev)
+            q = torch.zeros(n, nh, hd, device=dev)
+            qkv = torch.zeros(n, (nh + 2 * kvh) * hd, device=dev)
+            d = (ops.fp8_rows_desc(h, Wq.w_q, Wq.w_s, qkv, w_frags=Wq.frags(False), norm_w=nw, norm_eps=eps) if fused
+                 else ops.fp8_rows_desc(normed, Wq.w_q, Wq.w_s, qkv, w_frags=Wq.frags(False)))
+            ops.gemm_fp8_rows_qkv_rope_kv(d, qw, kwt, 1e-6, tab, pos, slot, bt, kc, vc, q, nh, kvh, hd)
+            res.append((q.clone(), kc.clone(), vc.clone()))
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
+        assert res[0][0].abs().sum() > 0

@@ -135,7 +135,7 @@ class NormPrologue(ctypes.Structure):
 class Fp8RowsDesc(ctypes.Structure):
     """Mirror of i64h_fp8_rows_desc (include/i64h.h)."""
     _fields_ = [("A", _P), ("a_src_row", _P), ("a_src_mod", _I), ("B", _P), ("b_scale", _P), ("group_offsets", _P), ("num_groups", _I),
-                ("M", _L), ("N", _I), ("K", _I), ("C", _P), ("c_row_map", _P), ("b_frags", _I)]
+                ("M", _L), ("N", _I), ("K", _I), ("C", _P), ("c_row_map", _P), ("b_frags", _I), ("c_add", _P), ("norm_w", _P), ("norm_eps", _F)]
 
 
 class MoeLayer(ctypes.Structure):

@@ -191,6 +191,9 @@ struct Fp8RowsArgs {
     float* C;
     const int32_t* c_row_map;
     int b_frags;  // B is the fragment pack of the weights (i64h_pack_weight_frags on the e4m3 bytes)
+    const float* c_add;   // plain epilogue: C = c_add + product (the residual stream; may be C itself)
+    const float* norm_w;  // RMSNorm of the operand rows in front of the quantizer (K <= 1024), or NULL
+    float norm_eps;
 };
 struct Fp8RowsPair {
     Fp8RowsArgs p[2];
@@ -202,7 +205,12 @@ struct Fp8RowsPair {
 // EPI 0 would have stored; p.C is not written).
 // HW = 2: eight waves - all of them request and quantize the operand rows (32 threads per row), waves 4..7 then only keep the
 // barriers: the phase in front of the K loop is bound by what one wave can request and convert, not by the CU.
-template <int EPI, int HW = 2>
+// PRO: a problem with norm_w normalises its operand rows first - x * rsqrt(mean(x^2) + eps) * w in the arithmetic of
+// fused_residual_norm_kernel (that kernel's thread i holds float4 i of the row: a wave's butterfly over lanes ^ 32, 16, 8, 4, 2, 1,
+// then the four wave sums in order; here thread c of the row's 32 holds float4 c + 32 j, so j and j + 1 are that kernel's lanes l and
+// l ^ 32 and the rest of its butterfly runs over this row's 32 lanes) - so the residual + norm launch in front of the call is saved
+// and the normalised rows never go to memory.
+template <int EPI, int HW = 2, int PRO = 0>
 __global__ __launch_bounds__(256 * HW) void gemm_fp8_skinny_kernel(Fp8RowsPair pp, RowTailArgs ta) {
     extern __shared__ __attribute__((aligned(16))) char f8s_smem[];
     const bool second = (int)blockIdx.x >= pp.nblk0;
@@ -334,6 +342,47 @@ __global__ __launch_bounds__(256 * HW) void gemm_fp8_skinny_kernel(Fp8RowsPair p
             const int i = c + TPR * j;
             v[j] = (rok && i < nv) ? ap[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        if constexpr (PRO == 1) {
+            static_assert(PRO == 0 || HW == 2, "the norm prologue is laid out for 32 threads per row");
+            if (p.norm_w) {  // uniform over the workgroup; launcher: K <= 1024, i.e. at most 8 float4 per thread
+                float4 gw[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int i = c + TPR * j;
+                    gw[j] = i < nv ? ((const float4*)p.norm_w)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                float tot[4];
+#pragma unroll
+                for (int w4 = 0; w4 < 4; ++w4) {
+                    float sq[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const float4 a = v[2 * w4 + e];
+                        float ss = __builtin_fmaf(a.x, a.x, 0.0f);
+                        ss = __builtin_fmaf(a.y, a.y, ss);
+                        ss = __builtin_fmaf(a.z, a.z, ss);
+                        ss = __builtin_fmaf(a.w, a.w, ss);
+                        sq[e] = ss;
+                    }
+                    float t = sq[0] + sq[1];                 // lanes l and l ^ 32 of that kernel's wave w4
+                    const PairF a2 = swap_rows(t);           // ^ 16
+                    t = a2.lo + a2.hi;
+                    t += I64H_DPPF(t, 0x128);                // ^ 8
+                    t += I64H_DPPF(t, 0x124);                // ^ 4
+                    t += I64H_DPPF(t, 0x4E);                 // ^ 2
+                    t += I64H_DPPF(t, 0xB1);                 // ^ 1
+                    tot[w4] = t;
+                }
+                const float rr = rsqrtf((tot[0] + tot[1] + tot[2] + tot[3]) / (float)K + p.norm_eps);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float4 a = v[j];
+                    const float4 g4 = gw[j];
+                    a.x = a.x * rr * g4.x; a.y = a.y * rr * g4.y; a.z = a.z * rr * g4.z; a.w = a.w * rr * g4.w;
+                    v[j] = a;
+                }
+            }
+        }
         if (!helper) bload(0);
         tail_lookup();
 #pragma unroll
@@ -443,7 +492,8 @@ __global__ __launch_bounds__(256 * HW) void gemm_fp8_skinny_kernel(Fp8RowsPair p
             const float gate = acc[0][reg] * (as * ws0), up = acc[NF - 1][reg] * (as * ws1);
             C[crow * I + col] = (gate / (1.0f + expf(-gate))) * up;
         } else {
-            C[crow * N + col] = acc[0][reg] * (as * ws0);
+            const float val = acc[0][reg] * (as * ws0);
+            C[crow * N + col] = p.c_add ? p.c_add[crow * N + col] + val : val;
         }
     }
 }
@@ -513,6 +563,8 @@ static int fp8_rows_check(const i64h_fp8_rows_desc* d, int epilogue, const char*
     I64H_CHECK_ARG(epilogue == 0 || (epilogue == 1 && d->N % 2 == 0), "%s: bad epilogue %d / N=%d", who, epilogue, d->N);
     I64H_CHECK_ARG(d->a_src_row == nullptr || d->a_src_mod > 0, "%s: a_src_row needs a_src_mod > 0", who);
     I64H_CHECK_ARG(!d->b_frags || d->N % (epilogue ? 32 : 16) == 0, "%s: a weight fragment pack needs whole fragment columns (N=%d)", who, d->N);
+    I64H_CHECK_ARG(d->norm_w == nullptr || d->K <= 1024, "%s: the norm in front of the quantizer takes rows of at most 1024 elements (K=%d)", who, d->K);
+    I64H_CHECK_ARG(d->c_add == nullptr || epilogue == 0, "%s: c_add goes with the plain epilogue", who);
     return 0;
 }
 static Fp8RowsArgs fp8_rows_args(const i64h_fp8_rows_desc* d) {
@@ -520,6 +572,7 @@ static Fp8RowsArgs fp8_rows_args(const i64h_fp8_rows_desc* d) {
     p.A = d->A; p.a_src_row = d->a_src_row; p.a_src_mod = d->a_src_mod; p.B = d->B; p.b_scale = d->b_scale; p.group_off = d->group_offsets;
     p.G = d->group_offsets ? d->num_groups : 1; p.M = (int)d->M; p.N = d->N; p.K = d->K; p.C = d->C; p.c_row_map = d->c_row_map;
     p.b_frags = d->b_frags;
+    p.c_add = d->c_add; p.norm_w = d->norm_w; p.norm_eps = d->norm_eps;
     return p;
 }
 static int64_t fp8_rows_blocks(const i64h_fp8_rows_desc* d, int epilogue) {
@@ -546,7 +599,11 @@ int i64h_gemm_fp8_rows_pair(const i64h_fp8_rows_desc* a, const i64h_fp8_rows_des
     hipStream_t st = (hipStream_t)stream;
     RowTailArgs ta;
     memset(&ta, 0, sizeof(ta));
-    if (epilogue) {
+    const bool pro = a->norm_w != nullptr || (b && b->norm_w != nullptr);
+    if (pro) {  // rows of at most 1024 elements: the default LDS limit holds
+        if (epilogue) hipLaunchKernelGGL((gemm_fp8_skinny_kernel<1, 2, 1>), dim3((unsigned)(n0 + n1)), dim3(512), lds, st, pp, ta);
+        else hipLaunchKernelGGL((gemm_fp8_skinny_kernel<0, 2, 1>), dim3((unsigned)(n0 + n1)), dim3(512), lds, st, pp, ta);
+    } else if (epilogue) {
         if (lds > 64 * 1024 && raise_lds_limit((const void*)gemm_fp8_skinny_kernel<1>, 1)) return 1;
         hipLaunchKernelGGL(gemm_fp8_skinny_kernel<1>, dim3((unsigned)(n0 + n1)), dim3(512), lds, st, pp, ta);
     } else {
@@ -587,8 +644,13 @@ int i64h_gemm_fp8_rows_qkv_rope_kv(const i64h_fp8_rows_desc* d, const float* q_n
     // the 4 KB head tile reuses the operand codes' LDS and must end in front of the row scales behind them: 16 (K + 32) >= 4096
     I64H_CHECK_ARG(d->K >= 256, "gemm_fp8_rows_qkv_rope_kv: K=%d too short (>= 256)", d->K);
     const size_t lds = (size_t)F8S_BM * (d->K + 32) + F8S_BM * 4 + 16;
-    if (lds > 64 * 1024 && raise_lds_limit((const void*)gemm_fp8_skinny_kernel<2>, 2)) return 1;
-    hipLaunchKernelGGL(gemm_fp8_skinny_kernel<2>, dim3((unsigned)n0), dim3(512), lds, (hipStream_t)stream, pp, ta);
+    I64H_CHECK_ARG(d->c_add == nullptr, "gemm_fp8_rows_qkv_rope_kv: no residual (nothing is stored to C)");
+    if (d->norm_w) {
+        hipLaunchKernelGGL((gemm_fp8_skinny_kernel<2, 2, 1>), dim3((unsigned)n0), dim3(512), lds, (hipStream_t)stream, pp, ta);
+    } else {
+        if (lds > 64 * 1024 && raise_lds_limit((const void*)gemm_fp8_skinny_kernel<2>, 2)) return 1;
+        hipLaunchKernelGGL(gemm_fp8_skinny_kernel<2>, dim3((unsigned)n0), dim3(512), lds, (hipStream_t)stream, pp, ta);
+    }
     I64H_CHECK_LAUNCH();
     return 0;
 }
@@ -600,6 +662,7 @@ int i64h_gemm_fp8_rows(const float* A, const int32_t* a_src_row, int32_t a_src_m
     d.A = A; d.a_src_row = a_src_row; d.a_src_mod = a_src_mod; d.B = B; d.b_scale = b_scale; d.group_offsets = group_offsets;
     d.num_groups = num_groups; d.M = M; d.N = N; d.K = K; d.C = C; d.c_row_map = c_row_map;
     d.b_frags = 0;
+    d.c_add = nullptr; d.norm_w = nullptr; d.norm_eps = 0.0f;
     return i64h_gemm_fp8_rows_pair(&d, nullptr, epilogue, stream);
 }
 

@@ -309,6 +309,10 @@ class I64MoEModel:
     # e4m3 runner, decode-sized steps: QK norm + RoPE + cache write in the epilogue of the qkv projection (8 instead of 9 launches per
     # layer, bit-identical; 2.017 -> 1.992 ms per step once the kernel had its helper waves - before that it measured slower)
     FP8_FUSE_QKV = os.environ.get("I64H_FP8_FUSE_QKV", "1") != "0"
+    # e4m3 runner, decode-sized steps: the residual add rides in the epilogue of the o (dense: also the down) projection and RMSNorm in
+    # front of the quantizer of the launch that reads the normalised rows - a row's e4m3 scale needs only that row, so nothing is
+    # exchanged between workgroups; 6 instead of 7 launches per MoE layer (5 instead of 7 dense), bit-identical
+    FP8_FUSE_DECODE_NORM = os.environ.get("I64H_FP8_FUSE_DECODE_NORM", "1") != "0"
     FP8_FRAGS = os.environ.get("I64H_FP8_FRAGS", "1") != "0"  # e4m3 runner: prefill-sized Linears on the operand-stationary kernel
     FUSE_QKV_PREFILL = os.environ.get("I64H_FUSE_QKV_PREFILL", "1") != "0"  # prefill chunks: QK norm + RoPE + cache write in the qkv GEMM's epilogue
     FUSE_NORM_QUANT = os.environ.get("I64H_FUSE_NORM_QUANT", "1") != "0"  # prefill chunks: residual + norm + quantization in one launch
@@ -764,8 +768,16 @@ class I64MoEModel:
         # prefill-sized chunks (see FP8_FUSE_NORM): the norm quantizes the normalised rows itself (a row's scale needs only that
         # row), the fp32 rows are not stored; decode-sized steps quantize inside their GEMMs; recording runs keep the fp32 rows
         nq = self.FP8_FUSE_NORM and not small and record is None and H <= 1024 and H % 4 == 0
+        qkr_ok = lambda W: (self.FP8_FUSE_QKV and small and not nq and record is None and cfg.head_dim == 64 and ops.fp8_rows_ok(H)
+                            and H >= 256 and (W["q_norm"] is None) == (W["k_norm"] is None))
+        # decode-sized steps: no norm launches in front of the qkv / gate_up calls, no residual launches behind o / down (see
+        # FP8_FUSE_DECODE_NORM).  pend: the norm weight still to be applied to B.h by the next call that reads the normalised rows
+        fuse = self.FP8_FUSE_DECODE_NORM and small and H <= 1024 and all(qkr_ok(W) for W in self.layers)
+        pend = None
         if nq:
             ops.fused_residual_norm_fp8(B.h, self.layers[0]["ln1"], eps, B.xa, B.xs, h_out=B.h)
+        elif fuse:
+            pend = self.layers[0]["ln1"]
         else:
             ops.fused_residual_norm(B.h, self.layers[0]["ln1"], eps, h_out=B.h, normed=B.normed)
 
@@ -787,13 +799,14 @@ class I64MoEModel:
         for l, W in enumerate(self.layers):
             if record is not None:
                 record[f"l{l}.in"] = B.h.clone()
-            if (self.FP8_FUSE_QKV and small and not nq and record is None and cfg.head_dim == 64 and ops.fp8_rows_ok(H) and H >= 256
-                    and (W["q_norm"] is None) == (W["k_norm"] is None)):
+            if qkr_ok(W):
                 # decode-sized step: QK norm, RoPE and the cache write ride in the epilogue of the qkv projection (one launch)
                 Wq = W["qkv"]
-                ops.gemm_fp8_rows_qkv_rope_kv(ops.fp8_rows_desc(B.normed, Wq.w_q, Wq.w_s, B.qkv, w_frags=Wq.frags(False)), W["q_norm"],
-                                              W["k_norm"], 1e-6, self.rope, positions, slot_ids, kvc.block_table, kvc.k[l], kvc.v[l], B.q,
-                                              cfg.num_heads, cfg.num_kv_heads, cfg.head_dim)
+                d = (ops.fp8_rows_desc(B.h, Wq.w_q, Wq.w_s, B.qkv, w_frags=Wq.frags(False), norm_w=pend, norm_eps=eps) if pend is not None
+                     else ops.fp8_rows_desc(B.normed, Wq.w_q, Wq.w_s, B.qkv, w_frags=Wq.frags(False)))
+                pend = None
+                ops.gemm_fp8_rows_qkv_rope_kv(d, W["q_norm"], W["k_norm"], 1e-6, self.rope, positions, slot_ids, kvc.block_table, kvc.k[l],
+                                              kvc.v[l], B.q, cfg.num_heads, cfg.num_kv_heads, cfg.head_dim)
             else:
                 linear(None if nq else B.normed, B.xa, B.xs, W["qkv"], B.qkv)
                 ops.qk_norm_rope_kv(B.qkv, W["q_norm"], W["k_norm"], 1e-6, self.rope, positions, slot_ids, kvc.block_table,
@@ -803,11 +816,15 @@ class I64MoEModel:
             attn2d = B.attn.view(n, H)
             if record is not None:
                 record[f"l{l}.attn_out"] = attn2d.clone()
-            linear(attn2d, B.xa, B.xs, W["o"], B.o)
-            if nq:
-                ops.fused_residual_norm_fp8(B.h, W["ln2"], eps, B.xa, B.xs, add=B.o, h_out=B.h)
+            if fuse:
+                linear(attn2d, B.xa, B.xs, W["o"], B.h, c_add=B.h)   # h += o_proj(attn); ln2 rides in the calls below
+                pend = W["ln2"]
             else:
-                ops.fused_residual_norm(B.h, W["ln2"], eps, add=B.o, h_out=B.h, normed=B.normed)
+                linear(attn2d, B.xa, B.xs, W["o"], B.o)
+                if nq:
+                    ops.fused_residual_norm_fp8(B.h, W["ln2"], eps, B.xa, B.xs, add=B.o, h_out=B.h)
+                else:
+                    ops.fused_residual_norm(B.h, W["ln2"], eps, add=B.o, h_out=B.h, normed=B.normed)
             if record is not None:
                 record[f"l{l}.mlp_in"] = B.normed.clone()
             nxt = self.layers[l + 1]["ln1"] if l + 1 < cfg.num_layers else self.final_norm
@@ -816,6 +833,9 @@ class I64MoEModel:
             if not fused_in and not nq:
                 ops.quantize_fp8_rows(B.normed, B.xa, B.xs)  # one quantization serves the shared expert and every routed expert
             x_in = B.normed if fused_in else None
+            nk = {}
+            if pend is not None:   # (fuse implies fused_in)
+                x_in, nk, pend = B.h, dict(norm_w=pend, norm_eps=eps), None
             if cfg.is_moe:
                 plan = B.plan
                 R = plan.rows
@@ -825,9 +845,9 @@ class I64MoEModel:
                     # expert, results scattered back into (route, token) order) and the shared expert as its second problem
                     # (the shared expert's tiles first: the surplus tiles of the grouped problem's upper bound end the launch)
                     ops.gemm_fp8_rows_pair(
-                        ops.fp8_rows_desc(B.normed, W["sh_gu"].w_q, W["sh_gu"].w_s, B.sh_inter, w_frags=W["sh_gu"].frags(True)),
-                        ops.fp8_rows_desc(B.normed, W["exp_gu"].w_q, W["exp_gu"].w_s, B.e_inter, m=R, a_src_row=plan.perm[l], a_src_mod=n,
-                                          group_offsets=plan.expert_offsets[l], w_frags=W["exp_gu"].frags(True)),
+                        ops.fp8_rows_desc(x_in, W["sh_gu"].w_q, W["sh_gu"].w_s, B.sh_inter, w_frags=W["sh_gu"].frags(True), **nk),
+                        ops.fp8_rows_desc(x_in, W["exp_gu"].w_q, W["exp_gu"].w_s, B.e_inter, m=R, a_src_row=plan.perm[l], a_src_mod=n,
+                                          group_offsets=plan.expert_offsets[l], w_frags=W["exp_gu"].frags(True), **nk),
                         epilogue=ops.EPI_SWIGLU)
                     ops.gemm_fp8_rows_pair(
                         ops.fp8_rows_desc(B.sh_inter, W["sh_dn"].w_q, W["sh_dn"].w_s, B.sh_out, w_frags=W["sh_dn"].frags()),
@@ -838,10 +858,10 @@ class I64MoEModel:
                         # rows in bucket order are grouped by expert; the gather out of the token rows and the scatter back into
                         # (route, token) order ride in the GEMMs
                         linear(x_in, B.xa, B.xs, W["exp_gu"], B.e_inter, m=R, a_src_row=plan.perm[l], a_src_mod=n,
-                               group_offsets=plan.expert_offsets[l], epilogue=ops.EPI_SWIGLU)
+                               group_offsets=plan.expert_offsets[l], epilogue=ops.EPI_SWIGLU, **nk)
                         linear(B.e_inter, B.eia, B.eis, W["exp_dn"], B.e_out, group_offsets=plan.expert_offsets[l], c_row_map=plan.perm[l])
                     if S:
-                        linear(x_in, B.xa, B.xs, W["sh_gu"], B.sh_inter, epilogue=ops.EPI_SWIGLU)
+                        linear(x_in, B.xa, B.xs, W["sh_gu"], B.sh_inter, epilogue=ops.EPI_SWIGLU, **nk)
                         linear(B.sh_inter, B.sha, B.shs, W["sh_dn"], B.sh_out)
                 mk = dict(moe_rows=B.e_out, moe_inv=None, moe_shared=B.sh_out if S else None, route_weights=rw,
                           routed_scale=W["routed_scale"], shared_scale=W["shared_scale"], h_out=B.h)
@@ -849,8 +869,15 @@ class I64MoEModel:
                     ops.fused_residual_norm_fp8(B.h, nxt, eps, B.xa, B.xs, **mk)
                 else:
                     ops.fused_residual_norm(B.h, nxt, eps, normed=B.normed, **mk)
+            elif fuse and ops.fp8_rows_ok(cfg.intermediate_size):
+                linear(x_in, B.xa, B.xs, W["gu"], B.d_inter, epilogue=ops.EPI_SWIGLU, **nk)
+                linear(B.d_inter, B.da, B.ds, W["dn"], B.h, c_add=B.h)   # h += down(...); the next norm rides in the next qkv call
+                if last:
+                    ops.fused_residual_norm(B.h, nxt, eps, normed=B.normed)
+                else:
+                    pend = nxt
             else:
-                linear(x_in, B.xa, B.xs, W["gu"], B.d_inter, epilogue=ops.EPI_SWIGLU)
+                linear(x_in, B.xa, B.xs, W["gu"], B.d_inter, epilogue=ops.EPI_SWIGLU, **nk)
                 linear(B.d_inter, B.da, B.ds, W["dn"], B.d_out)
                 if nq and not last:
                     ops.fused_residual_norm_fp8(B.h, nxt, eps, B.xa, B.xs, add=B.d_out, h_out=B.h)

@@ -317,19 +317,21 @@ def gemm_fp8(a: torch.Tensor, a_scale: torch.Tensor, w: torch.Tensor, w_scale: t
 
 
 def gemm_fp8_rows(a: torch.Tensor, w: torch.Tensor, w_scale: torch.Tensor, out: torch.Tensor, *, m: Optional[int] = None, a_src_row=None,
-                  a_src_mod: int = 0, group_offsets=None, c_row_map=None, epilogue: int = EPI_STORE, w_frags=None) -> torch.Tensor:
+                  a_src_mod: int = 0, group_offsets=None, c_row_map=None, epilogue: int = EPI_STORE, w_frags=None, c_add=None,
+                  norm_w=None, norm_eps: float = 0.0) -> torch.Tensor:
     """Decode-sized fp8_linear in one launch: fp32 rows `a`, per-token e4m3fn quantization inside the kernel (bit for bit
     quantize_fp8_rows), then the product of gemm_fp8.  K a multiple of 64 up to 8192.  w_frags: the fragment pack of w, read
     instead of it."""
     assert epilogue in (EPI_STORE, EPI_SWIGLU)
     gemm_fp8_rows_pair(fp8_rows_desc(a, w, w_scale, out, m=m, a_src_row=a_src_row, a_src_mod=a_src_mod, group_offsets=group_offsets,
-                                     c_row_map=c_row_map, w_frags=w_frags), None, epilogue)
+                                     c_row_map=c_row_map, w_frags=w_frags, c_add=c_add, norm_w=norm_w, norm_eps=norm_eps), None, epilogue)
     return out
 
 
 def fp8_rows_desc(a: torch.Tensor, w: torch.Tensor, w_scale: torch.Tensor, out: torch.Tensor, *, m: Optional[int] = None, a_src_row=None,
-                  a_src_mod: int = 0, group_offsets=None, c_row_map=None, w_frags=None):
-    """One problem of gemm_fp8_rows_pair (arguments as gemm_fp8_rows)."""
+                  a_src_mod: int = 0, group_offsets=None, c_row_map=None, w_frags=None, c_add=None, norm_w=None, norm_eps: float = 0.0):
+    """One problem of gemm_fp8_rows_pair (arguments as gemm_fp8_rows).  c_add: out = c_add + product (plain epilogue; may be out).
+    norm_w: the operand rows are RMS-normalised with this weight and norm_eps in front of the quantizer (K <= 1024)."""
     _chk(a, torch.float32, "a")
     if w.dim() == 2:
         w, w_scale = w.unsqueeze(0), w_scale.reshape(1, -1)
@@ -340,6 +342,7 @@ def fp8_rows_desc(a: torch.Tensor, w: torch.Tensor, w_scale: torch.Tensor, out: 
     d.b_frags = int(w_frags is not None)
     d.group_offsets, d.num_groups, d.M, d.N, d.K = ptr(group_offsets), G, m if m is not None else a.shape[0], N, K
     d.C, d.c_row_map = ptr(out), ptr(c_row_map)
+    d.c_add, d.norm_w, d.norm_eps = ptr(c_add), ptr(norm_w), float(norm_eps)
     return d
 
 
