@@ -479,3 +479,45 @@ def test_fp8_rows_with_the_norm_in_front_and_the_residual_behind(dev, K, n):
         for a, b in zip(*res):
             assert torch.equal(a, b)
         assert res[0][0].abs().sum() > 0
+
+
+def test_fp8_quantizers_divide_like_the_reference_on_many_scales(dev):
+    """The e4m3 quantizers form x / scale with a reciprocal and one correction step instead of a division per element: the codes must be
+    the division's - four million elements in rows of every magnitude (scales from 1e-9 to 1e4, rows of tiny values under the 1e-12
+    floor of the maximum, rows of constants, values at the ties of the e4m3 grid after scaling) against the CPU restatement of
+    quantize_activations_fp8 (vllm_i64/core/fp8.py:113-130), code for code and scale for scale; and the same rows through the norm
+    that quantizes its own output."""
+    from oracle import ops_ref as O
+    from vllm_i64_amd import ops
+    g = torch.Generator().manual_seed(11)
+    K = 1024
+    mags = torch.cat([10.0 ** torch.empty(3000).uniform_(-9, 4, generator=g), torch.tensor([1e-13, 3e-14, 1.0, 448.0, 447.99997, 3.0e38 / 448])])
+    x = torch.empty(mags.numel(), K).normal_(0, 1, generator=g) * mags.unsqueeze(1)
+    x[5] = 0.37                                                     # a row of constants: every quotient is exactly 448
+    codes = torch.arange(1, 127, dtype=torch.uint8).view(torch.float8_e4m3fn).float()
+    ties = torch.cat([(codes[:-1] + codes[1:]) / 2, torch.tensor([448.0])])   # row maximum 448 * 1.7: quotients land on and next to ties
+    x[7, :ties.numel()] = ties * 1.7
+    x[7, ties.numel():] = 0.0
+    x[8, :ties.numel()] = ties * (1.7 * (1 + 2 ** -23))
+    x[8, ties.numel()] = 448.0 * 1.7
+    x[8, ties.numel() + 1:] = 0.0
+    wq, ws = O.quantize_fp8_rows(x)
+    gq, gs = ops.quantize_fp8_rows(x.to(dev))
+    assert torch.equal(gs.cpu(), ws)
+    bad = (gq.cpu() != wq.view(torch.uint8)).nonzero()
+    assert bad.numel() == 0, (bad[:5], x[bad[0, 0], bad[0, 1]].item(), ws[bad[0, 0]].item())
+    # rows whose length is no multiple of 4 take the byte path
+    y = x[:64, :1023].contiguous()
+    wq2, ws2 = O.quantize_fp8_rows(y)
+    gq2, gs2 = ops.quantize_fp8_rows(y.to(dev))
+    assert torch.equal(gs2.cpu(), ws2) and torch.equal(gq2.cpu(), wq2.view(torch.uint8))
+    # the norm that quantizes its own rows: same codes as the quantizer on the rows the plain norm stores
+    h = x[:512].to(dev)
+    nw = (torch.rand(K, generator=g) + 0.5).to(dev)
+    normed = torch.empty_like(h)
+    ops.fused_residual_norm(h, nw, 1e-6, normed=normed)
+    q_ref, s_ref = ops.quantize_fp8_rows(normed)
+    q_n, s_n = torch.empty(512, K, dtype=torch.uint8, device=dev), torch.empty(512, device=dev)
+    ops.fused_residual_norm_fp8(h, nw, 1e-6, q_n, s_n)
+    assert torch.equal(q_n, q_ref) and torch.equal(s_n, s_ref)
+    assert torch.equal(q_ref.cpu(), O.quantize_fp8_rows(normed.cpu())[0].view(torch.uint8))

@@ -200,6 +200,29 @@ __device__ __forceinline__ uint32_t pack4_e4m3fn(float x0, float x1, float x2, f
 // a NaN stays a NaN (fminf / fmaxf would turn it into -448): the reference's clamp().to(float8_e4m3fn) keeps it, and the
 // hardware conversion encodes it as the e4m3fn NaN
 __device__ __forceinline__ float clamp448(float x) { return x != x ? x : fminf(fmaxf(x, -448.0f), 448.0f); }
+// x / s for many x and one s, correctly rounded (the bits of the IEEE division) in three instructions per quotient instead of the
+// division's expansion: with r = RN(1 / s) computed once, q0 = RN(x r) is within an ulp of the quotient, its remainder x - q0 s is exact
+// in one fma, and RN(q0 + remainder r) is the correctly rounded quotient (Markstein's correction step).  For the quantizers' ranges
+// (|x / s| <= 448 (1 + eps), 2e-15 <= s) nothing under- or overflows on the way; a NaN in x stays one; a scale outside
+// [1e-15, 1e30] (a row that holds an infinity or a NaN) takes the division itself.
+struct DivBy {
+    float s, r;
+    bool fast;
+    __device__ __forceinline__ explicit DivBy(float s_) : s(s_), r(1.0f / s_), fast(s_ >= 1e-15f && s_ <= 1e30f) {}
+    __device__ __forceinline__ float operator()(float x) const {
+        const float q0 = x * r;
+        const float e = __builtin_fmaf(q0, s, -x);  // the negated remainder: in this form a zero keeps its sign through both steps
+        return __builtin_fmaf(-e, r, q0);
+    }
+};
+// body(div) with div(x) = x / s: the three-instruction form when every lane of the wave has a scale in range (one branch per call, not
+// per quotient), the division itself otherwise
+template <typename F>
+__device__ __forceinline__ void with_div_by(const float s, F&& body) {
+    const DivBy dv(s);
+    if (__builtin_amdgcn_ballot_w64(!dv.fast) == 0ull) body([&](float x) { return dv(x); });
+    else body([&](float x) { return x / s; });
+}
 
 // Device-coherent accesses for data handed from one workgroup to another inside a launch: relaxed agent-scope atomics
 // compile to sc1 stores / loads, which are coherent across CUs and XCDs without any cache write-back or invalidate.

@@ -29,14 +29,16 @@ __global__ __launch_bounds__(256) void quantize_fp8_rows_kernel(const float* __r
     const float s = fmaxf(m, 1e-12f) / 448.0f;
     if (threadIdx.x == 0) scale[row] = s;
     uint8_t* qr = q + row * K;
-    if ((K & 3) == 0 && (((uintptr_t)xr | (uintptr_t)qr) & 15) == 0) {
-        for (int64_t i = threadIdx.x; i < K / 4; i += 256) {
-            const float4 x = ((const float4*)xr)[i];
-            ((uint32_t*)qr)[i] = pack4_e4m3fn(clamp448(x.x / s), clamp448(x.y / s), clamp448(x.z / s), clamp448(x.w / s));
+    with_div_by(s, [&](auto dv) {  // dv(x) = x / s, the division's bits
+        if ((K & 3) == 0 && (((uintptr_t)xr | (uintptr_t)qr) & 15) == 0) {
+            for (int64_t i = threadIdx.x; i < K / 4; i += 256) {
+                const float4 x = ((const float4*)xr)[i];
+                ((uint32_t*)qr)[i] = pack4_e4m3fn(clamp448(dv(x.x)), clamp448(dv(x.y)), clamp448(dv(x.z)), clamp448(dv(x.w)));
+            }
+        } else {
+            for (int64_t i = threadIdx.x; i < K; i += 256) qr[i] = (uint8_t)(pack4_e4m3fn(clamp448(dv(xr[i])), 0.f, 0.f, 0.f) & 0xff);
         }
-    } else {
-        for (int64_t i = threadIdx.x; i < K; i += 256) qr[i] = (uint8_t)(pack4_e4m3fn(clamp448(xr[i] / s), 0.f, 0.f, 0.f) & 0xff);
-    }
+    });
 }
 
 #define F8_BM 64
@@ -180,6 +182,8 @@ __global__ __launch_bounds__(256) void gemm_fp8_kernel(const uint8_t* __restrict
 #define F8S_BM 16
 #define F8S_MAXV 32  // float4 per thread kept in registers between the amax pass and the quantization: K <= 2048
 
+__host__ __device__ __forceinline__ int f8s_pad_tiles(int n_tiles) { return n_tiles >= 6 ? (n_tiles + 7) & ~7 : n_tiles; }
+
 struct Fp8RowsArgs {
     const float* A;
     const int32_t* a_src_row;
@@ -234,8 +238,11 @@ __global__ __launch_bounds__(256 * HW) void gemm_fp8_skinny_kernel(Fp8RowsPair p
     const bool helper = HW > 1 && wid >= 4;  // wave-uniform
     const int fr = lane & 15, fq = lane >> 4;
     const int I = N / 2, nout = EPI == 1 ? I : N;
-    const int n_tiles = (nout + 63) / 64;
-    const int mt = bid / n_tiles, nt = bid % n_tiles;
+    // workgroups are dealt to the 8 XCDs round-robin and every XCD has an L2 of its own: with the column-tile count padded to a
+    // multiple of 8, the row tiles that stream the same weight slice run on one XCD and the slice crosses the fabric once
+    const int n_tiles = (nout + 63) / 64, n_pad = f8s_pad_tiles(n_tiles);
+    const int mt = bid / n_pad, nt = bid % n_pad;
+    if (nt >= n_tiles) return;
     if (wid == 0) {  // (group, first row, rows) of m-tile mt: lane i looks at group c0 + i; the grid is an upper bound
         int g = -1, row0 = 0, rows = 0, base = 0;
         const int ng = group_off ? G : 1;
@@ -305,7 +312,10 @@ __global__ __launch_bounds__(256 * HW) void gemm_fp8_skinny_kernel(Fp8RowsPair p
     const int nv = K / 4;
     // this lane's weight columns, requested behind the rows (loads return in order: the rows can be quantized while the
     // weights are still on their way)
-    const int col = nt * 64 + (helper ? 0 : wid) * 16 + fr;
+    // (Splitting the K blocks between a main wave and its helper, as the int8 kernel does, measured slower here: 1.929 against 1.892 ms
+    // per decode step - the exchange of the fp32 partial sums costs two more barriers than the halved loop saves.)
+    const int wcol = helper ? 0 : wid;
+    const int col = nt * 64 + wcol * 16 + fr;
     const bool col_ok = col < nout && !helper;
     const uint8_t* Bg = B + (int64_t)g * N * K;
     const uint8_t* bp[NF];
@@ -313,20 +323,21 @@ __global__ __launch_bounds__(256 * HW) void gemm_fp8_skinny_kernel(Fp8RowsPair p
     if (p.b_frags) {
         // fragment (column fragment c, K block t) = the 1 KB at (c * K / 64 + t) * 1024, this lane's 16 bytes at lane * 16: a wave's
         // load is 8 whole cache lines instead of 16 rows x 64 bytes
-        const int c16 = nt * 4 + (helper ? 0 : wid);
+        const int c16 = nt * 4 + wcol;
         const int c_ok = c16 * 16 < nout ? c16 : 0;
         bp[0] = Bg + (int64_t)c_ok * K * 16 + lane * 16;
         if constexpr (NF == 2) bp[1] = Bg + (int64_t)((I >> 4) + c_ok) * K * 16 + lane * 16;
         bstep = 1024;
     } else {
-        bp[0] = Bg + (int64_t)(col_ok ? col : 0) * K + fq * 16;
-        if constexpr (NF == 2) bp[1] = Bg + (int64_t)(I + (col_ok ? col : 0)) * K + fq * 16;
+        bp[0] = Bg + (int64_t)(col < nout ? col : 0) * K + fq * 16;
+        if constexpr (NF == 2) bp[1] = Bg + (int64_t)(I + (col < nout ? col : 0)) * K + fq * 16;
     }
     float m = 0.0f;
     const bool in_regs = nv <= TPR * MAXV;
     float4 v[MAXV];
     const int nblk = K / 64;
     constexpr int BATCH = 8;
+    const int t_begin = 0, t_end = helper ? 0 : nblk;
     uint4 bq[NF][BATCH];
     auto bload = [&](int t0) {
 #pragma unroll
@@ -383,7 +394,7 @@ __global__ __launch_bounds__(256 * HW) void gemm_fp8_skinny_kernel(Fp8RowsPair p
                 }
             }
         }
-        if (!helper) bload(0);
+        if (t_end > t_begin) bload(t_begin);
         tail_lookup();
 #pragma unroll
         for (int j = 0; j < MAXV; ++j) m = fmaxf(m, fmaxf(fmaxf(fabsf(v[j].x), fabsf(v[j].y)), fmaxf(fabsf(v[j].z), fabsf(v[j].w))));
@@ -392,39 +403,41 @@ __global__ __launch_bounds__(256 * HW) void gemm_fp8_skinny_kernel(Fp8RowsPair p
             const float4 x = rok ? ap[i] : make_float4(0.f, 0.f, 0.f, 0.f);
             m = fmaxf(m, fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w))));
         }
-        if (!helper) bload(0);
+        if (t_end > t_begin) bload(t_begin);
         tail_lookup();
     }
     m = row16_max(m);  // the threads of a row are 16 (32) consecutive lanes
     if constexpr (HW == 2) m = fmaxf(m, lane_xor(m, 16));
     const float sc = fmaxf(m, 1e-12f) / 448.0f;
     if (c == 0) row_s[r] = rok ? sc : 0.0f;
-    auto q4 = [&](float4 x) -> uint32_t { return pack4_e4m3fn(clamp448(x.x / sc), clamp448(x.y / sc), clamp448(x.z / sc), clamp448(x.w / sc)); };
-    if (in_regs) {
+    with_div_by(sc, [&](auto dv) {
+        auto q4 = [&](float4 x) -> uint32_t { return pack4_e4m3fn(clamp448(dv(x.x)), clamp448(dv(x.y)), clamp448(dv(x.z)), clamp448(dv(x.w))); };
+        if (in_regs) {
 #pragma unroll
-        for (int j = 0; j < MAXV; ++j) {
-            const int i = c + TPR * j;
-            if (i < nv) *(uint32_t*)(rows_q + r * LDA + i * 4) = rok ? q4(v[j]) : 0u;
+            for (int j = 0; j < MAXV; ++j) {
+                const int i = c + TPR * j;
+                if (i < nv) *(uint32_t*)(rows_q + r * LDA + i * 4) = rok ? q4(v[j]) : 0u;
+            }
+        } else {
+            for (int i = c; i < nv; i += TPR) *(uint32_t*)(rows_q + r * LDA + i * 4) = rok ? q4(ap[i]) : 0u;  // second read: cache
         }
-    } else {
-        for (int i = c; i < nv; i += TPR) *(uint32_t*)(rows_q + r * LDA + i * 4) = rok ? q4(ap[i]) : 0u;  // second read: cache
-    }
+    });
     __syncthreads();
 
     // ---- K loop: weight fragments in batches of 8 blocks of 64 bytes (the first batch was requested behind the rows) ----
     v4f acc[NF];
 #pragma unroll
     for (int f = 0; f < NF; ++f) acc[f] = (v4f){0.f, 0.f, 0.f, 0.f};
-    for (int t0 = 0; t0 < (helper ? 0 : nblk); t0 += BATCH) {
+    for (int t0 = t_begin; t0 < t_end; t0 += BATCH) {
         uint4 bc[NF][BATCH];
 #pragma unroll
         for (int t = 0; t < BATCH; ++t)
 #pragma unroll
             for (int f = 0; f < NF; ++f) bc[f][t] = bq[f][t];
-        if (t0 + BATCH < nblk) bload(t0 + BATCH);  // next batch streams in behind the MFMAs of this one
+        if (t0 + BATCH < t_end) bload(t0 + BATCH);  // next batch streams in behind the MFMAs of this one
 #pragma unroll
         for (int t = 0; t < BATCH; ++t) {
-            if (t0 + t >= nblk) break;
+            if (t0 + t >= t_end) break;
             const uint4 a = *(const uint4*)(rows_q + fr * LDA + (t0 + t) * 64 + fq * 16);
             const long a0 = (long)(((unsigned long long)a.y << 32) | a.x), a1 = (long)(((unsigned long long)a.w << 32) | a.z);
 #pragma unroll
@@ -579,7 +592,7 @@ static int64_t fp8_rows_blocks(const i64h_fp8_rows_desc* d, int epilogue) {
     if (d->M == 0) return 0;
     const int nout = epilogue ? d->N / 2 : d->N;
     // grouped: an upper bound on the row tiles (every group may end with a partial tile); one group: exact
-    return ((d->M + F8S_BM - 1) / F8S_BM + (d->group_offsets ? d->num_groups : 0)) * (int64_t)((nout + 63) / 64);
+    return ((d->M + F8S_BM - 1) / F8S_BM + (d->group_offsets ? d->num_groups : 0)) * (int64_t)f8s_pad_tiles((nout + 63) / 64);
 }
 
 int i64h_gemm_fp8_rows_pair(const i64h_fp8_rows_desc* a, const i64h_fp8_rows_desc* b, int32_t epilogue, void* stream) {

@@ -387,12 +387,14 @@ __global__ __launch_bounds__(256) void fused_residual_norm_rows_kernel(FrrArgs p
             m = wave_max(m);
             const float s = fmaxf(m, 1e-12f) / 448.0f;
             if (lane == 0) f8s[t] = s;
+            with_div_by(s, [&](auto dv) {
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int i = lane + 64 * v;
-                if (i < nv)
-                    ((uint32_t*)(f8q + t * p.H))[i] = pack4_e4m3fn(clamp448(y[v].x / s), clamp448(y[v].y / s), clamp448(y[v].z / s), clamp448(y[v].w / s));
-            }
+                for (int v = 0; v < 4; ++v) {
+                    const int i = lane + 64 * v;
+                    if (i < nv)
+                        ((uint32_t*)(f8q + t * p.H))[i] = pack4_e4m3fn(clamp448(dv(y[v].x)), clamp448(dv(y[v].y)), clamp448(dv(y[v].z)), clamp448(dv(y[v].w)));
+                }
+            });
         }
         if (!normed) continue;
 #pragma unroll
