@@ -525,3 +525,37 @@ def test_mu_guidance_layers_teacher_forced_and_refusals(dev):
     assert (prec["l1.out"].cpu() - rec["l1.out"]).abs().max() > 0.05
     with pytest.raises(NotImplementedError, match="mu-guidance"):
         I64MoEModel(ModelConfig.from_any(ocfg), w, device=dev, max_seqs=4, num_kv_blocks=64, quant="fp8")
+
+
+def test_mu_guidance_checkpoint_files_to_gpu_logits(dev, golden_dir, tmp_path):
+    """A mu-guidance model through the files: native export (config.json with use_mu_guidance + safetensors under the reference's
+    tensor names) -> load_checkpoint -> GPU runner, and the packed int8 file -> load_packed -> GPU runner: the logits of the model built
+    from the weights directly, bit for bit, and the reference's captured int8 logits at the bound of the other model tests."""
+    from vllm_i64_amd import checkpoint as C
+    from vllm_i64_amd.config import ModelConfig
+    from vllm_i64_amd.model import GreedyDecoder, I64MoEModel
+    z = np.load(os.path.join(golden_dir, "model_tiny-mu.npz"))
+    ocfg = M.named_config("tiny-mu")
+    cfg0 = ModelConfig.from_any(ocfg)
+    w0 = M.make_weights(ocfg, seed=0)
+    C.save_native(str(tmp_path / "native"), cfg0, w0)
+    cfg1, w1 = C.load_checkpoint(str(tmp_path / "native"))
+    assert cfg1.use_mu_guidance
+    C.save_packed(str(tmp_path / "packed.safetensors"), cfg1, w1)
+    cfg2, w2 = C.load_packed(str(tmp_path / "packed.safetensors"))
+    ids = M.make_token_ids(ocfg, 54, seed=7)
+    runs = []
+    for c, ww in ((cfg0, w0), (cfg1, w1), (cfg2, w2)):
+        model = I64MoEModel(c, ww, device=dev, max_seqs=2, num_kv_blocks=64)
+        dec = GreedyDecoder(model, 2, use_graph=False)
+        outs = [dec.prefill([ids[:33], ids[33:]], reserve_extra=8).cpu().numpy()]
+        for i in range(1, 3):
+            dec.tokens.copy_(torch.from_numpy(z["int8_tokens"][i - 1]))
+            outs.append(dec.step().cpu().numpy())
+        runs.append(outs)
+    for other in runs[1:]:
+        for x, y in zip(runs[0], other):
+            assert np.array_equal(x, y)
+    last = np.cumsum(z["prompt_lens"]) - 1
+    assert np.abs(runs[1][0] - z["int8_prefill_logits"][last]).max() <= 2e-2
+    assert np.abs(runs[1][1] - z["int8_decode1_logits"]).max() <= 2e-2
