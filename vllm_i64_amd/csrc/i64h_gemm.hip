@@ -876,7 +876,9 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
         }
 #pragma unroll
         for (int u = 0; u < CPT; ++u) {
-            const float* ap = (const float*)p.A + (int64_t)src[u] * K + kc[u] * 16;
+            // a chunk of a padding row is never used: its lanes all ask for the tile's first 64 bytes, one request per instruction
+            // instead of 64 (the load itself stays, so that the loads in flight can be counted)
+            const float* ap = (const float*)p.A + (int64_t)src[u] * K + (aok[u] ? kc[u] : 0) * 16;
 #pragma unroll
             for (int e = 0; e < 4; ++e) f[u][e] = *(const float4*)(ap + e * 4);
         }
@@ -950,7 +952,7 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) x[u][e] = ((const float4*)((const float*)p.A + (int64_t)src[u] * K + kq * 16))[e];
+            for (int e = 0; e < 4; ++e) x[u][e] = ((const float4*)((const float*)p.A + (int64_t)src[u] * K + (rok[u] ? kq : 0) * 16))[e];  // padding rows: one request
 #pragma unroll
         for (int e = 0; e < 4; ++e) gw[e] = ((const float4*)(np.w + kq * 16))[e];
         if (s_end > s_begin) bload(s_begin);
