@@ -339,13 +339,14 @@ def main():
     ctx_now = max(dec.host_lens)   # tokens every sequence holds now
     kvb = {torch.bfloat16: 2, torch.float16: 2, torch.float32: 4, torch.float8_e4m3fn: 1, torch.float8_e5m2: 1}[kv_dtype]
     Bf = model.buffers(B, B)
-    splits = Bf.attn_splits
+    (_, _, splits), = model.attention_plan(Bf, B, dec.max_ctx_hint, True, None)   # the decode step's own launch shape
+    attn_ws = Bf.attn_ws.get((B, splits))
     # one event pair around the launches of all layers (every layer's cache is cold again by the time its turn comes), so that
     # the figure is the kernel's duration as a kernel trace reports it, without an event record and its gap in front of each launch
     def attn_all_layers():
         for l in range(cfg.num_layers):
             ops.paged_attn(Bf.q, model.kv.k[l], model.kv.v[l], model.kv.block_table, dec.ctx_len, slot_ids=dec.slot_ids,
-                           softmax_scale=cfg.head_dim ** -0.5, splits=splits, out=Bf.attn, workspace=Bf.attn_ws)
+                           softmax_scale=cfg.head_dim ** -0.5, splits=splits, out=Bf.attn, workspace=attn_ws)
     # the launches go out as one graph replay, as in the decode step (launched one by one from the host, the gaps between them
     # vary by a microsecond or two from box to box and end up in the figure)
     attn_graph = None

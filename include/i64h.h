@@ -528,7 +528,11 @@ int i64h_advance(int32_t* positions, int32_t* ctx_len, int64_t n, void* stream);
  * (i64h_paged_attn_workspace_init, once after allocation) and that every launch leaves zero: the splits of a row (or of a
  * row's head group) are merged by their last-finishing workgroup, so launches sharing one workspace must not overlap.
  * splits is an upper bound: the library may split a context fewer ways when it spreads a row's kv heads over workgroups
- * instead (i64h_set_decode_attn_head_split).  With stats != NULL the minimum and maximum of the output (with zero) are
+ * instead (i64h_set_decode_attn_head_split).  The form of the launch follows from it: splits == 1 with 256 or more rows
+ * (head_dim 64) runs 16-row tiles whose rows share the K/V tiles of their sequence - made for runs of consecutive rows of one
+ * sequence (prefill chunks); a tile of 16 different sequences walks 16 contexts one after the other, so rows that are one
+ * per sequence (decode steps of any size) are passed with splits >= 2, which always takes a row-per-workgroup form.
+ * With stats != NULL the minimum and maximum of the output (with zero) are
  * folded into stat slot stat_slot - the input statistics of o_proj - by the split merge, by the unsplit kernels' own
  * epilogue, or by a pass over the output behind the one kernel that has neither. */
 int64_t i64h_paged_attn_workspace_floats(int64_t rows, int32_t num_heads, int32_t head_dim, int32_t splits);

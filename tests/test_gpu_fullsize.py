@@ -211,3 +211,53 @@ def test_prefill_chunk_of_several_thousand_rows_fused_and_unfused_launches_give_
     assert float(outs[0][1][1].abs().max()) > 0
     for s in range(4):
         model.kv.free(s)
+
+
+@pytest.mark.parametrize("kv_dtype", [torch.float32, torch.bfloat16])
+def test_steps_of_many_decode_rows_and_mixed_steps_launch_attention_per_kind_of_row(dev, two_layer, kv_dtype):
+    """A step of 300 one-token sequences, a 280-token chunk and 5 more one-token sequences (the engine's mixed batches,
+    vllm_i64/engine/i64_scheduler.py:345-503): the runner's plan is one attention launch per run of rows of a kind - decode rows
+    never reach the many-row form (whose 16-row tiles would walk 16 whole contexts one after the other), the chunk does.  The
+    output and the folded range are those of the row-per-workgroup kernel over all rows; a pure decode step of 300 rows is one
+    launch of that kernel."""
+    from vllm_i64_amd import ops
+    ocfg, w, model = two_layer
+    nh, kvh, hd = ocfg.num_heads, ocfg.num_kv_heads, ocfg.head_dim
+    tps = [1] * 300 + [280] + [1] * 5
+    n, seqs = sum(tps), len(tps)
+    g = torch.Generator().manual_seed(11)
+    ctx_of = torch.randint(1, 200, (seqs,), generator=g)
+    ctx_of[300] = 400                                          # the chunk: tokens 120..399 of its sequence
+    blocks_per = 26
+    nblk = seqs * blocks_per
+    kc = torch.randn(nblk, 16, kvh, hd, generator=g).to(kv_dtype).to(dev)
+    vc = (torch.randn(nblk, 16, kvh, hd, generator=g) + 0.2).to(kv_dtype).to(dev)
+    bt = torch.randperm(nblk, generator=g).to(torch.int32).view(seqs, blocks_per).contiguous().to(dev)
+    slot = torch.repeat_interleave(torch.arange(seqs, dtype=torch.int32), torch.tensor(tps)).to(dev)
+    ctx = torch.cat([torch.arange(400 - t + 1, 401) if t > 1 else ctx_of[s:s + 1] for s, t in enumerate(tps)]).to(torch.int32).to(dev)
+    q = torch.randn(n, nh, hd, generator=g).to(dev)
+
+    class _KV:
+        k, v, block_table = [kc], [vc], bt
+    B = model.buffers(n, n)
+    B.q.copy_(q)
+    plan = model.attention_plan(B, n, 400, False, tps)
+    assert [(a, b) for a, b, _ in plan] == [(0, 300), (300, 580), (580, 585)]
+    assert plan[0][2] >= 2 and plan[1][2] == 1                 # decode form for the 300 rows, many-row form for the chunk
+    assert model.attention_plan(B, 300, 400, True, None)[0][2] >= 2 and model.attention_plan(B, 300, 400, False, [1] * 300)[0][2] >= 2
+    assert model.attention_plan(B, n, 0, False, None) == [(0, n, 1)]            # no hint: a prefill chunk as before
+    assert model.attention_plan(B, 64, 2048, True, None) == [(0, 64, 4)]        # the benchmark's decode step
+    fine = [1, 17] * 40                                        # kinds alternate 80 times: one launch, the form by the majority
+    assert model.attention_plan(B, sum(fine), 64, False, fine) == [(0, sum(fine), 1)]
+    st, st_ref = ops.stats_alloc(3, dev), ops.stats_alloc(3, dev)
+    ops.stats_reset(st)
+    ops.stats_reset(st_ref)
+    model._attention(B, _KV, 0, ctx, slot, plan, stats=st, stat_slot=1)
+    got = B.attn.clone()
+    want = ops.paged_attn(q, kc, vc, bt, ctx, slot_ids=slot, splits=2)            # every row through the row-per-workgroup kernel
+    d = (got - want).abs().max().item()
+    print(f"mixed step, {n} rows in {len(plan)} launches, cache {kv_dtype}: max abs diff to the row kernel {d:.3e}")
+    assert torch.equal(got[:300], want[:300]) or d <= 2e-6     # same kernel for the decode rows (its split count may differ)
+    assert d <= 5e-6
+    ops.rows_minmax(got.view(n, nh * hd), st_ref, slot_base=1)
+    assert all(torch.equal(a, b) for a, b in zip(ops.qparams(st, 3), ops.qparams(st_ref, 3)))

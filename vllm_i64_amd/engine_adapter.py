@@ -99,7 +99,7 @@ class EngineModel:
                              f"{kv_cache.block_table.shape[1]} per sequence")
         self._ensure_blocks(kv_cache, seq_ids, [max(m, 0) for m in max_pos])
         logits = r.forward(ids, pos, slots, (pos + 1).contiguous(), max_ctx_hint=max(max_pos) + 1 if max_pos else 0,
-                           kv=_CacheView(kv_cache))
+                           kv=_CacheView(kv_cache), tokens_per_seq=tps)
         # launches that wait on a grid barrier (prefill-sized chunks) report an expired wait through a device word: read it
         # back before the logits leave (the engine reads the logits on the host right after, so this adds no idle time)
         r.check_sync(force=False)

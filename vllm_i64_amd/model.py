@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import math
 import os
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -189,8 +189,7 @@ class _Buffers:
         self.logits = torch.empty(n_logit_rows, cfg.vocab_size, **f32)
         self.lm_ws: Optional[torch.Tensor] = None     # activation planes of the lm_head (allocated on first use)
         self.lm_planes_ws: Optional[torch.Tensor] = None  # the same, zeroed once and written by the final norm of a decode-sized step
-        self.attn_ws: Optional[torch.Tensor] = None
-        self.attn_splits = 1
+        self.attn_ws: Dict[Tuple[int, int], torch.Tensor] = {}   # split-attention workspaces by (rows, splits)
         self.tails: Dict[tuple, list] = {}   # prepared persistent-launch descriptions per set of external buffers
 
 
@@ -475,7 +474,8 @@ class I64MoEModel:
     # ---- one forward (prefill chunk or decode step) ----
     def forward(self, token_ids: torch.Tensor, positions: torch.Tensor, slot_ids: torch.Tensor, ctx_len: torch.Tensor,
                 logit_rows: Optional[torch.Tensor] = None, max_ctx_hint: int = 0, record: Optional[dict] = None,
-                inject: Optional[Dict[int, torch.Tensor]] = None, kv=None, rows_are_slots: bool = False) -> torch.Tensor:
+                inject: Optional[Dict[int, torch.Tensor]] = None, kv=None, rows_are_slots: bool = False,
+                tokens_per_seq: Optional[List[int]] = None) -> torch.Tensor:
         """token_ids int64 [N]; positions / slot_ids / ctx_len int32 [N] (ctx_len = position + 1 for causal rows);
         logit_rows int32 [M] selects the rows whose logits are wanted (None = all).  Returns fp32 logits [M, V].
         record: dict filled with per-layer activations; inject: {layer: hidden [N, H]} replaces the residual stream at the
@@ -488,7 +488,7 @@ class I64MoEModel:
         n = token_ids.numel()
         if self.quant == "fp8":
             assert inject is None, "teacher forcing is a facility of the int8 runner"
-            return self._forward_fp8(token_ids, positions, slot_ids, ctx_len, logit_rows, kvc, record, max_ctx_hint, rows_are_slots)
+            return self._forward_fp8(token_ids, positions, slot_ids, ctx_len, logit_rows, kvc, record, max_ctx_hint, rows_are_slots, tokens_per_seq)
         if positions.device.type != "cuda" and n:  # host positions: check them (device positions are the caller's contract:
             # GreedyDecoder and EngineModel bound them on the host)
             if int(positions.max()) >= cfg.max_pos or int(positions.max()) // kvc.k[0].shape[1] >= kvc.block_table.shape[1]:
@@ -520,13 +520,7 @@ class I64MoEModel:
             B.plan.run(token_ids, self.tables)
         if self.ep is not None or not (cfg.is_moe and self.PLAN_WITH_EMBEDDING):
             ops.embedding(token_ids, self.embed, out=B.h, reset_stats=st)  # + the reset of the step's stat slots
-        # attention splits: enough workgroups to fill the chip when few rows carry long contexts (decode)
-        splits = 1
-        if max_ctx_hint >= 256 and n <= 256:
-            splits = max(1, min(self.attn_max_splits, self.attn_target_wgs // n, max_ctx_hint // 64))
-        if splits > 1 and (B.attn_ws is None or B.attn_splits != splits):
-            B.attn_ws = ops.attn_workspace(n, cfg.num_heads, cfg.head_dim, splits, self.device)
-            B.attn_splits = splits
+        splits = self.attention_plan(B, n, max_ctx_hint, rows_are_slots, tokens_per_seq)
         # prefill-sized chunks that fit one resident grid: residual + norm + the quantization of the calls that read the normalised
         # rows are one launch (the fp32 normalised rows are never stored); record / inject / expert-parallel runs keep the two-kernel form
         mu = cfg.use_mu_guidance   # mu-guidance keeps the one-kernel-per-operation form: its Linears sit between the fused ones
@@ -563,9 +557,7 @@ class I64MoEModel:
                     ops.gemm_i8_qkv_rope_kv(ops.gemm_desc(B.normed, W["qkv"].w_q, W["qkv"].w_s, B.qkv, a_slot_base=0, stats=st, w_frags=self._wf(W["qkv"])),
                                             W["q_norm"], W["k_norm"], 1e-6, self.rope, positions, slot_ids, kvc.block_table, kvc.k[0], kvc.v[0],
                                             B.q, cfg.num_heads, cfg.num_kv_heads, cfg.head_dim)
-                ops.paged_attn(B.q, kvc.k[l], kvc.v[l], kvc.block_table, ctx_len, slot_ids=None if rows_are_slots else slot_ids,
-                               softmax_scale=1.0 / math.sqrt(cfg.head_dim), splits=splits, out=B.attn, workspace=B.attn_ws,
-                               stats=st, stat_slot=base + 1)
+                self._attention(B, kvc, l, ctx_len, None if rows_are_slots else slot_ids, splits, stats=st, stat_slot=base + 1)
                 tails[l].run()  # o projection ... combine + next norm (+ the next layer's qkv projection, RoPE, cache write)
                 continue
             if inject is not None and l in inject:
@@ -610,9 +602,7 @@ class I64MoEModel:
                     self._linear(B.normed, W["qkv"], base + 0, B.xa, B.xs, B.qkv)
                 ops.qk_norm_rope_kv(B.qkv, W["q_norm"], W["k_norm"], 1e-6, self.rope, positions, slot_ids, kvc.block_table,
                                     kvc.k[l], kvc.v[l], cfg.num_heads, cfg.num_kv_heads, cfg.head_dim, q_out=B.q)
-            ops.paged_attn(B.q, kvc.k[l], kvc.v[l], kvc.block_table, ctx_len, slot_ids=None if rows_are_slots else slot_ids,
-                           softmax_scale=1.0 / math.sqrt(cfg.head_dim), splits=splits, out=B.attn, workspace=B.attn_ws,
-                           stats=st, stat_slot=base + 1)  # the range of the output is folded into the o projection's slot
+            self._attention(B, kvc, l, ctx_len, None if rows_are_slots else slot_ids, splits, stats=st, stat_slot=base + 1)  # the range of the output is folded into the o projection's slot
             attn2d = B.attn.view(n, H)
             if record is not None:
                 record[f"l{l}.attn_out"] = attn2d.clone()
@@ -680,7 +670,67 @@ class I64MoEModel:
         self._lm_head(B, logit_rows)
         return B.logits
 
-    def _layers_norm_fused(self, B: _Buffers, kvc, positions, slot_ids, ctx_len, splits: int, rows_are_slots: bool, lm_ws=None):
+    # many-row attention form of the library (16-row tiles, rows of a tile that share a sequence share its K/V tiles): taken for
+    # launches of this many rows with splits == 1; rows that are one per sequence must not end up there (a tile of 16 sequences
+    # walks 16 whole contexts, one after the other)
+    ATTN_TILE_ROWS = 256
+    ATTN_MAX_SEGMENTS = 4
+
+    def attention_plan(self, B: "_Buffers", n: int, max_ctx_hint: int, rows_are_slots: bool, tokens_per_seq: Optional[List[int]]):
+        """The attention launches of a step: [(first row, end row, splits)].  Rows of one-token sequences (decode rows) go to the
+        row-per-workgroup form - enough splits to fill the chip when few rows carry long contexts, and never the many-row form;
+        runs of rows that share sequences (prefill chunks) go to the many-row form from ATTN_TILE_ROWS rows on.  With
+        tokens_per_seq (host list, rows in sequence order) a mixed step becomes one launch per maximal run of either kind."""
+        def few_row_splits(rows: int, one_per_seq: bool) -> int:
+            sp = 1
+            if max_ctx_hint >= 256 and rows <= self.ATTN_TILE_ROWS:
+                sp = max(1, min(self.attn_max_splits, self.attn_target_wgs // rows, max_ctx_hint // 64))
+            if one_per_seq and rows >= self.ATTN_TILE_ROWS:
+                sp = max(sp, 2)   # an upper bound: the library launches fewer (one) when the rows alone fill the chip
+            return sp
+
+        segs: List[Tuple[int, int, bool]] = []
+        if rows_are_slots:
+            segs = [(0, n, True)]
+        elif tokens_per_seq is not None:
+            row = 0
+            for t in tokens_per_seq:
+                t = int(t)
+                if t <= 0:
+                    continue
+                kind = t == 1
+                if segs and segs[-1][2] == kind:
+                    segs[-1] = (segs[-1][0], row + t, kind)
+                else:
+                    segs.append((row, row + t, kind))
+                row += t
+            assert row == n, "tokens_per_seq does not add up to the rows of the step"
+            if len(segs) > self.ATTN_MAX_SEGMENTS:   # finely interleaved kinds: one launch, the form by the majority of rows
+                dec = sum(b - a for a, b, k in segs if k)
+                segs = [(0, n, 2 * dec >= n)]
+        else:
+            segs = [(0, n, False)]
+        plan = []
+        for a, b, one_per_seq in segs:
+            sp = few_row_splits(b - a, one_per_seq)
+            if sp > 1 and (b - a, sp) not in B.attn_ws:
+                B.attn_ws[(b - a, sp)] = ops.attn_workspace(b - a, self.cfg.num_heads, self.cfg.head_dim, sp, self.device)
+            plan.append((a, b, sp))
+        return plan
+
+    def _attention(self, B: "_Buffers", kvc, l: int, ctx_len, slot_ids, plan, stats=None, stat_slot: int = 0):
+        """Paged attention of layer l over the step's rows, one launch per plan entry (the range of the output rows is folded
+        into the same statistics slot by every launch).  slot_ids None: row i is sequence i (then the plan is one launch)."""
+        scale = 1.0 / math.sqrt(self.cfg.head_dim)
+        n = B.q.shape[0]
+        for a, b, sp in plan:
+            whole = a == 0 and b == n
+            assert whole or slot_ids is not None
+            ops.paged_attn(B.q if whole else B.q[a:b], kvc.k[l], kvc.v[l], kvc.block_table, ctx_len if whole else ctx_len[a:b],
+                           slot_ids=slot_ids if whole or slot_ids is None else slot_ids[a:b], softmax_scale=scale, splits=sp,
+                           out=B.attn if whole else B.attn[a:b], workspace=B.attn_ws.get((b - a, sp)), stats=stats, stat_slot=stat_slot)
+
+    def _layers_norm_fused(self, B: _Buffers, kvc, positions, slot_ids, ctx_len, splits, rows_are_slots: bool, lm_ws=None):
         """The layers of a decode-sized step with five launches each: qkv projection (+ QK norm, RoPE, cache write; from the second
         layer on with the previous layer's combine + residual + norm in front of its quantizer), attention, o projection with the
         residual add in its epilogue, the gate_up launch with residual norm in front of its quantizer, the down launch.  Enters with
@@ -702,9 +752,7 @@ class I64MoEModel:
             else:
                 d = ops.gemm_desc(hbuf, W["qkv"].w_q, W["qkv"].w_s, B.qkv, a_slot_base=base, stats=st, w_frags=self._wf(W["qkv"]))
                 ops.gemm_i8_qkv_rope_kv_norm(d, ops.norm_prologue(W["ln1"], eps, self.dec_sync, slot_base=base), *qkr)
-            ops.paged_attn(B.q, kvc.k[l], kvc.v[l], kvc.block_table, ctx_len, slot_ids=None if rows_are_slots else slot_ids,
-                           softmax_scale=1.0 / math.sqrt(cfg.head_dim), splits=splits, out=B.attn, workspace=B.attn_ws,
-                           stats=st, stat_slot=base + 1)
+            self._attention(B, kvc, l, ctx_len, None if rows_are_slots else slot_ids, splits, stats=st, stat_slot=base + 1)
             # h += o_proj(attn): the add rides in the projection's epilogue
             ops.gemm_i8_pair(ops.gemm_desc(B.attn.view(n, H), W["o"].w_q, W["o"].w_s, hbuf, a_slot_base=base + 1, stats=st, w_frags=self._wf(W["o"]),
                                            c_residual=hbuf))
@@ -742,7 +790,7 @@ class I64MoEModel:
         else:
             ops.fused_residual_norm(hbuf, self.final_norm, eps, normed=B.normed, h_out=B.h, lm_workspace=lm_ws)
 
-    def _forward_fp8(self, token_ids, positions, slot_ids, ctx_len, logit_rows, kvc, record, max_ctx_hint, rows_are_slots):
+    def _forward_fp8(self, token_ids, positions, slot_ids, ctx_len, logit_rows, kvc, record, max_ctx_hint, rows_are_slots, tokens_per_seq=None):
         """The forward with every Linear an fp8_linear (vllm_i64/core/fp8.py:137-194, its torch._scaled_mm branch): activations are
         quantized per token, so no call-wide statistics exist and the expert rows need no per-bucket treatment - one
         quantization of the normalised rows serves the shared expert and, gathered inside the GEMM, every routed expert."""
@@ -757,12 +805,7 @@ class I64MoEModel:
         if cfg.is_moe:
             B.plan.run(token_ids, self.tables)
         ops.embedding(token_ids, self.embed, out=B.h)
-        splits = 1
-        if max_ctx_hint >= 256 and n <= 256:
-            splits = max(1, min(self.attn_max_splits, self.attn_target_wgs // n, max_ctx_hint // 64))
-        if splits > 1 and (B.attn_ws is None or B.attn_splits != splits):
-            B.attn_ws = ops.attn_workspace(n, cfg.num_heads, cfg.head_dim, splits, self.device)
-            B.attn_splits = splits
+        splits = self.attention_plan(B, n, max_ctx_hint, rows_are_slots, tokens_per_seq)
         S = cfg.shared_intermediate_size if cfg.is_moe else 0
         small = n * max(1, cfg.top_k if cfg.is_moe else 1) <= self.FUSE_MAX_ROWS
         # prefill-sized chunks (see FP8_FUSE_NORM): the norm quantizes the normalised rows itself (a row's scale needs only that
@@ -811,8 +854,7 @@ class I64MoEModel:
                 linear(None if nq else B.normed, B.xa, B.xs, W["qkv"], B.qkv)
                 ops.qk_norm_rope_kv(B.qkv, W["q_norm"], W["k_norm"], 1e-6, self.rope, positions, slot_ids, kvc.block_table,
                                     kvc.k[l], kvc.v[l], cfg.num_heads, cfg.num_kv_heads, cfg.head_dim, q_out=B.q)
-            ops.paged_attn(B.q, kvc.k[l], kvc.v[l], kvc.block_table, ctx_len, slot_ids=None if rows_are_slots else slot_ids,
-                           softmax_scale=1.0 / math.sqrt(cfg.head_dim), splits=splits, out=B.attn, workspace=B.attn_ws)
+            self._attention(B, kvc, l, ctx_len, None if rows_are_slots else slot_ids, splits)
             attn2d = B.attn.view(n, H)
             if record is not None:
                 record[f"l{l}.attn_out"] = attn2d.clone()
