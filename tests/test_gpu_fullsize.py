@@ -125,13 +125,18 @@ def test_decode_attention_at_2048_tokens_against_oracle_rows(dev):
 
 
 @pytest.mark.parametrize("name,lens", [("trmoe306-synth", [1] * 16), ("trmoe306-synth", [200, 57]), ("dense306-synth", [1]),
-                                       ("dense306-synth", [23, 10]), ("dense306-synth", [180, 120])])
+                                       ("dense306-synth", [23, 10]), ("dense306-synth", [180, 120]),
+                                       ("trhash500m-synth", [1] * 128), ("trhash500m-synth", [1] * 129), ("trhash500m-synth", [1] * 256),
+                                       ("trhash500m-synth", [1] * 257), ("dense306-synth", [1] * 300)])
 def test_other_baseline_configs_teacher_forced(dev, name, lens):
     """BASELINE configurations 1 and 2 at their real dimensions (two-layer cuts): `trmoe306-synth` (4 experts of 512, shared
     2048 - the shared down projection's K = 2048 sits on the decode-sized kernel's limit; cyclic top-2 routing, 0.95 / 0.05
     weights) with 16 decode rows and with a prefill; `dense306-synth` (dense MLP of 4096: the down projection's K = 4096 is
     beyond the decode-sized kernel and runs the tiled kernel with the quantizer in its staging loop) at batch 1, a small
-    prefill and a 300-row prefill.  Every layer is fed the oracle's layer input; decode rows attend to a 40-token history."""
+    prefill and a 300-row prefill.  Every layer is fed the oracle's layer input; decode rows attend to a 40-token history.
+    Decode steps of the headline model around the row counts where the runner changes kernels: 128 / 129 sequences (256 / 258
+    routed rows: experts inside the decode-sized launch or through the tiled kernel), 256 / 257 (the Linear calls change to the
+    prefill-sized path; the attention must stay in a row-per-workgroup form), and 300 rows of the dense model (12-token histories)."""
     from vllm_i64_amd.config import ModelConfig
     from vllm_i64_amd.model import I64MoEModel
     ocfg = dataclasses.replace(M.named_config(name), num_layers=2, name=name + "-2layer")
@@ -140,7 +145,7 @@ def test_other_baseline_configs_teacher_forced(dev, name, lens):
     model = I64MoEModel(ModelConfig.from_any(ocfg), w, device=dev, kv_dtype=torch.float32, max_seqs=nseq, num_kv_blocks=nseq * 16 + 32)
     eng = M.OracleEngine(ocfg, w, mode="int8_torch", max_seqs=nseq, num_blocks=nseq * 16 + 32)
     decode = all(k == 1 for k in lens)
-    hist = 40 if decode else 0
+    hist = (40 if nseq <= 16 else 12) if decode else 0
     if decode:  # a 40-token history computed by the oracle; the GPU cache starts from the oracle's cache contents and block table
         eng.prefill([M.make_token_ids(ocfg, hist, seed=50 + s) for s in range(nseq)])
         for l in range(ocfg.num_layers):
@@ -160,7 +165,10 @@ def test_other_baseline_configs_teacher_forced(dev, name, lens):
     slots = torch.cat([torch.full((k,), s, dtype=torch.int32) for s, k in enumerate(lens)]).to(dev)
     grec = {}
     model.forward(ids.to(dev), pos, slots, (pos + 1).contiguous(), record=grec,
-                  inject={l: rec[f"l{l}.in"].to(dev) for l in range(ocfg.num_layers)}, max_ctx_hint=hist + 1 if decode else 0)
+                  inject={l: rec[f"l{l}.in"].to(dev) for l in range(ocfg.num_layers)}, max_ctx_hint=hist + 1 if decode else 0,
+                  tokens_per_seq=lens)
+    if decode and n >= 256:
+        assert all(sp >= 2 for _, _, sp in model.attention_plan(model.buffers(n, n), n, hist + 1, False, lens))
     for l in range(ocfg.num_layers):
         da = (grec[f"l{l}.attn_out"].cpu() - rec[f"l{l}.attn_out"]).abs()
         do = (grec[f"l{l}.out"].cpu() - rec[f"l{l}.out"]).abs()
@@ -173,8 +181,20 @@ def test_other_baseline_configs_teacher_forced(dev, name, lens):
             continue
         row_err = do.max(dim=1).values
         flipped = row_err > 1e-5   # a row whose fp32 input sits on a rounding tie of the 7-bit quantizer (see the test above)
-        assert int(flipped.sum()) <= max(2, n // 64), (int(flipped.sum()), row_err[flipped])
-        assert row_err.max() <= 1e-1 and do.mean() <= 2e-4
+        # One such row in front of the MLP moves that row's MLP input by a quantization step; every Linear call it enters has ONE
+        # activation range (vllm_i64/core/loader.py:57-76), so when the row carries the call's extreme, the scale of the whole call -
+        # the rows of its (route, expert) buckets, or every row of a dense MLP - moves with it.  Those rows are held to the bounds only.
+        moved = ((grec[f"l{l}.mlp_in"].cpu() - rec[f"l{l}.mlp_in"]).abs().max(dim=1).values > 1e-5).nonzero().flatten().tolist()
+        excused = torch.zeros(n, dtype=torch.bool)
+        if moved and ocfg.num_experts > 1:
+            ex = M.make_tables(ocfg)[l][:, ids.clamp(0, ocfg.vocab_size - 1)]   # [top_k, n]
+            for r in moved:
+                for k in range(ex.shape[0]):
+                    excused |= ex[k] == ex[k, r]
+        elif moved:
+            excused[:] = True
+        assert int((flipped & ~excused).sum()) <= max(2, n // 64), (int(flipped.sum()), moved, row_err[flipped])
+        assert row_err.max() <= 1e-1 and do.mean() <= (2e-4 if not moved else 1e-3)
 
 
 def test_prefill_chunk_of_several_thousand_rows_fused_and_unfused_launches_give_the_same_bits(dev, two_layer):
