@@ -417,7 +417,7 @@ def test_prefill_with_norm_and_quantization_in_one_launch_gives_the_same_bits(de
     form - logits and KV cache bit for bit."""
     from vllm_i64_amd.model import I64MoEModel
     ocfg, w, model = _model(name, dev, max_seqs=4)
-    lens = [200, 130, 77]
+    lens = [200, 130, 77, 150]
     n = sum(lens)
     assert n > I64MoEModel.FUSE_MAX_ROWS
     ids = M.make_token_ids(ocfg, n, seed=5).to(dev)
@@ -431,11 +431,11 @@ def test_prefill_with_norm_and_quantization_in_one_launch_gives_the_same_bits(de
     for fused in (True, False):
         for kc in model.kv.k + model.kv.v:
             kc.zero_()
-        model.FUSE_NORM_QUANT = fused
+        model.FUSE_NORM_QUANT, model.FQ_MIN_ROWS = fused, 0   # (the runner itself takes the one-launch form from FQ_MIN_ROWS rows on)
         try:
             logits = model.forward(ids, pos, slots, (pos + 1).contiguous()).clone()
         finally:
-            model.FUSE_NORM_QUANT = I64MoEModel.FUSE_NORM_QUANT
+            model.FUSE_NORM_QUANT, model.FQ_MIN_ROWS = I64MoEModel.FUSE_NORM_QUANT, I64MoEModel.FQ_MIN_ROWS
         outs.append((logits, [k.clone() for k in model.kv.k], [v.clone() for v in model.kv.v], model.kv.block_table.clone()))
         model.check_sync()
     assert torch.equal(outs[0][3], outs[1][3])
@@ -452,25 +452,26 @@ def test_expired_grid_barrier_is_reported_by_the_decoder_and_the_engine_adapter(
     from vllm_i64_amd.engine_adapter import EngineModel
     from vllm_i64_amd.model import GreedyDecoder, I64MoEModel
     ocfg, w, model = _model("tiny-moe", dev, max_seqs=4)
-    lens = [200, 130, 77]     # 407 rows: seven workgroups of 64 rows in the resident launch
+    lens = [200, 130, 77, 150]     # 557 rows: nine workgroups of 64 rows in the resident launch
     assert sum(lens) > I64MoEModel.FUSE_MAX_ROWS and model.FUSE_NORM_QUANT
+    model.FQ_MIN_ROWS = 0     # the resident launch also for this small chunk (the runner's own threshold is FQ_MIN_ROWS rows)
     ids = M.make_token_ids(ocfg, sum(lens), seed=5)
-    prompts = [ids[:200], ids[200:330], ids[330:]]
-    dec = GreedyDecoder(model, 3, use_graph=False)
+    prompts = list(ids.split(lens))
+    dec = GreedyDecoder(model, 4, use_graph=False)
     good = dec.prefill(prompts).clone()
-    for s in range(3):
+    for s in range(4):
         model.kv.free(s)
     ops.call("i64h_set_grid_wait_budget", 1)
     try:
         with pytest.raises(RuntimeError, match="wait budget"):
             dec.prefill(prompts)
-        for s in range(3):
+        for s in range(4):
             model.kv.free(s)
         cache = _EngineLikeCache(model.cfg, 64, 4, dev)
         cache.block_table = torch.full((4, 16), -1, dtype=torch.int32, device=dev)   # 256 positions per sequence
         pos = torch.cat([torch.arange(t) for t in lens])
         with pytest.raises(RuntimeError, match="wait budget"):
-            EngineModel(model)(ids, pos, cache, [0, 1, 2], lens)
+            EngineModel(model)(ids, pos, cache, [0, 1, 2, 3], lens)
     finally:
         ops.call("i64h_set_grid_wait_budget", 0)
     again = dec.prefill(prompts)

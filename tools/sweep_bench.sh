@@ -1,5 +1,6 @@
 #!/bin/bash
 # Decode throughput of the headline model beside its BASELINE point: tools/sweep_bench.sh <tag> ["batch:prompt_len ..."]
+# (SWEEP_ARGS="--config trmoe306-synth", "--weights fp8", ...: more bench.py options for every point)
 # One bench.py process per point (own prefill, own graph), JSON lines under gpurun_out/<tag>/sweep_<batch>_<prompt>.json.
 # A point that ends by a signal, a time limit or an abort ends the sweep (nothing more is started on the GPU after that).
 set -u
@@ -11,7 +12,7 @@ mkdir -p $OUT
 for p in $POINTS; do
   b=${p%%:*}; l=${p##*:}
   echo "== batch $b prompt $l"
-  timeout -k 10 400 python3 bench.py --batch $b --prompt-len $l --steps 64 --warmup 8 --no-cpu-baseline > $OUT/sweep_${b}_${l}.json 2> $OUT/sweep_${b}_${l}.err
+  timeout -k 10 400 python3 bench.py --batch $b --prompt-len $l --steps 64 --warmup 8 --no-cpu-baseline ${SWEEP_ARGS:-} > $OUT/sweep_${b}_${l}.json 2> $OUT/sweep_${b}_${l}.err
   rc=$?
   if [ $rc -ne 0 ]; then
     echo "   exit code $rc"; tail -5 $OUT/sweep_${b}_${l}.err

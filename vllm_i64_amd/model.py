@@ -315,6 +315,10 @@ class I64MoEModel:
     FP8_FRAGS = os.environ.get("I64H_FP8_FRAGS", "1") != "0"  # e4m3 runner: prefill-sized Linears on the operand-stationary kernel
     FUSE_QKV_PREFILL = os.environ.get("I64H_FUSE_QKV_PREFILL", "1") != "0"  # prefill chunks: QK norm + RoPE + cache write in the qkv GEMM's epilogue
     FUSE_NORM_QUANT = os.environ.get("I64H_FUSE_NORM_QUANT", "1") != "0"  # prefill chunks: residual + norm + quantization in one launch
+    # ... from this many rows on: the launch holds the whole grid at a barrier, which costs 33 us per launch at 512 rows where the
+    # two kernels it replaces take 12 (prefill in 512 / 1024 / 2048 / 4096-row chunks, k tokens/s: 98 / 165 / 263 / 380 with it,
+    # 114 / 177 / 249 / 369 without)
+    FQ_MIN_ROWS = int(os.environ.get("I64H_FQ_MIN_ROWS", "1536"))
 
     def _fq_rows(self) -> int:
         if not hasattr(self, "_fq_rows_cached"):
@@ -345,7 +349,14 @@ class I64MoEModel:
     # every workgroup of the qkv launch (four row streams) and forming it in producer workgroups in front of that launch both
     # measured slower than the launch they replace
     FUSE_DECODE_QKV_NORM = os.environ.get("I64H_FUSE_DECODE_QKV_NORM", "1") != "0"
-    FUSE_MAX_ROWS = 256  # up to this many operand rows the quantizer runs inside the GEMM (one launch per Linear call)
+    # Up to this many operand rows the quantizer runs inside the GEMM (one launch per Linear call, weights streamed once per 16-row
+    # tile); beyond, the rows are quantized once and go through the tiled kernels.  Measured on decode steps of the headline model
+    # (ms/step at 256 | 512 | 1024): 300 sequences 5.43 | 4.49 | 4.14, 512 sequences 6.75 | 6.04 | 6.18, 768 sequences - | 6.77 | 6.73.
+    FUSE_MAX_ROWS = int(os.environ.get("I64H_FUSE_MAX_ROWS", "512"))
+    NORM_FUSE_MAX_ROWS = 256  # the library's limit for the launches with the RMSNorm in front of the quantizer
+    # the same for the routed (route, token) rows of a step: 600 rows 4.14 fused against 4.49, 768 rows 4.96 against 5.08, 1024 rows 6.18 against 6.04
+    EXPERT_FUSE_MAX_ROWS = int(os.environ.get("I64H_EXPERT_FUSE_MAX_ROWS", "768"))
+    FP8_FUSE_MAX_ROWS = int(os.environ.get("I64H_FP8_FUSE_MAX_ROWS", "256"))  # e4m3 runner: routed rows of a decode-sized step
     EP_FUSE_MAX_ROWS = 1024  # the same for the pooled expert rows of the expert-parallel runner (8 ranks x 64 sequences x top-2)
     # expert-parallel runner, steps with more pooled expert rows than that (prefill chunks): dispatch every (route, token) row to the
     # rank that owns its expert and return the result by variable-split all-to-alls (each rank quantizes and multiplies only the rows of
@@ -524,7 +535,7 @@ class I64MoEModel:
         # prefill-sized chunks that fit one resident grid: residual + norm + the quantization of the calls that read the normalised
         # rows are one launch (the fp32 normalised rows are never stored); record / inject / expert-parallel runs keep the two-kernel form
         mu = cfg.use_mu_guidance   # mu-guidance keeps the one-kernel-per-operation form: its Linears sit between the fused ones
-        fq = (self.FUSE_NORM_QUANT and n > self.FUSE_MAX_ROWS and n <= self._fq_rows() and record is None and inject is None
+        fq = (self.FUSE_NORM_QUANT and n > self.FUSE_MAX_ROWS and n >= self.FQ_MIN_ROWS and n <= self._fq_rows() and record is None and inject is None
               and self.ep is None and H <= 1024 and H % 4 == 0 and not mu)
         if fq:
             self._resident_used = True
@@ -537,9 +548,9 @@ class I64MoEModel:
         if fuse_rows and record is None and inject is None and not mu and self._tail_supported(n):
             tails = self._tails(B, kvc, positions, slot_ids)
             self._resident_used = True
-        if (self.FUSE_DECODE_NORM and fuse_rows and tails is None and record is None and inject is None and self.ep is None and self.fuse_qkr and not mu
+        if (self.FUSE_DECODE_NORM and fuse_rows and n <= self.NORM_FUSE_MAX_ROWS and tails is None and record is None and inject is None and self.ep is None and self.fuse_qkr and not mu
                 and cfg.head_dim == 64 and 256 <= H <= 1024 and H % 64 == 0
-                and (not cfg.is_moe or (cfg.shared_intermediate_size and 0 < B.plan.rows <= self.FUSE_MAX_ROWS))):
+                and (not cfg.is_moe or (cfg.shared_intermediate_size and 0 < B.plan.rows <= min(self.FUSE_MAX_ROWS, self.NORM_FUSE_MAX_ROWS)))):
             # every row's logits are wanted (a decode step): the final norm writes the lm_head's activation planes itself
             lm_planes = (self.LM_HEAD_BF16X3 and self.LM_PLANES_FROM_NORM and logit_rows is None and H % 32 == 0 and B.logits.shape[0] == n)
             if lm_planes and B.lm_planes_ws is None:
@@ -807,7 +818,7 @@ class I64MoEModel:
         ops.embedding(token_ids, self.embed, out=B.h)
         splits = self.attention_plan(B, n, max_ctx_hint, rows_are_slots, tokens_per_seq)
         S = cfg.shared_intermediate_size if cfg.is_moe else 0
-        small = n * max(1, cfg.top_k if cfg.is_moe else 1) <= self.FUSE_MAX_ROWS
+        small = n * max(1, cfg.top_k if cfg.is_moe else 1) <= self.FP8_FUSE_MAX_ROWS
         # prefill-sized chunks (see FP8_FUSE_NORM): the norm quantizes the normalised rows itself (a row's scale needs only that
         # row), the fp32 rows are not stored; decode-sized steps quantize inside their GEMMs; recording runs keep the fp32 rows
         nq = self.FP8_FUSE_NORM and not small and record is None and H <= 1024 and H % 4 == 0
@@ -939,7 +950,7 @@ class I64MoEModel:
         plan = B.plan
         n, R = plan.n, plan.rows
         shared = bool(cfg.shared_intermediate_size)
-        if R <= self.FUSE_MAX_ROWS and R > 0:
+        if R <= self.EXPERT_FUSE_MAX_ROWS and R > 0:
             # decode-sized step: two launches per layer.  Each holds the routed experts (rows gathered in bucket order, every
             # (route, expert) bucket quantized with its own statistics) and the shared expert as a second problem.
             e_gu = ops.gemm_desc(B.normed, W["exp_gu"].w_q, W["exp_gu"].w_s, B.e_inter, a_src_row=plan.perm[l], a_src_mod=n,
