@@ -347,13 +347,15 @@ def test_fp8_decode_steps_without_norm_and_residual_launches_give_the_same_bits(
     assert outs[0].abs().sum() > 0
 
 
-@pytest.mark.parametrize("scenario", ["prefill4096", "decode64"])
+@pytest.mark.parametrize("scenario", ["prefill4096", "decode64", "decode300", "decode512", "decode513"])
 def test_fp8_model_at_the_bench_dimensions(dev, scenario):
     """The fp8 configuration at trhash500m-synth's real dimensions (two-layer cut), teacher-forced against the oracle's "fp8" mode:
     "prefill4096" - two 2048-token prompts = 4096 rows, so every prefill-sized Linear runs the operand-stationary e4m3 kernel
     (i64h_gemm_fp8_frags at K = 1024 / 1792 / 448, grouped with gather and scatter for the experts) and the matrix-core
     attention, followed by one decode step; "decode64" - 64 sequences decoding, i.e. the decode-sized e4m3 launches
-    (i64h_gemm_fp8_rows_pair, i64h_gemm_fp8_rows_qkv_rope_kv) at the benchmark's batch.  The fp8 x fp8 product itself is parity
+    (i64h_gemm_fp8_rows_pair, i64h_gemm_fp8_rows_qkv_rope_kv) at the benchmark's batch; "decode300" / "decode512" - the same launches
+    with 600 and 1024 routed rows (the runner's limit for them), "decode513" - the first row count on the other side of it.
+    The fp8 x fp8 product itself is parity
     unpinned (the reference's torch._scaled_mm branch runs on no machine available here); the bound is the one of
     test_fp8_model_logits: the distance between the reference's two branches (its dequantizing branch is what the fixtures
     pin), computed here from the oracle's restatement of both."""
@@ -365,7 +367,7 @@ def test_fp8_model_at_the_bench_dimensions(dev, scenario):
     if scenario == "prefill4096":
         lens, steps = [2048, 2048], 1
     else:
-        lens, steps = [5 + (i % 4) for i in range(64)], 2
+        lens, steps = [5 + (i % 4) for i in range(int(scenario[6:]))], 2
     nseq = len(lens)
     model = I64MoEModel(ModelConfig.from_any(ocfg), w, device=dev, kv_dtype=torch.float32, max_seqs=nseq,
                         num_kv_blocks=sum((n + steps + 16) // 16 + 1 for n in lens), quant="fp8")

@@ -356,7 +356,9 @@ class I64MoEModel:
     NORM_FUSE_MAX_ROWS = 256  # the library's limit for the launches with the RMSNorm in front of the quantizer
     # the same for the routed (route, token) rows of a step: 600 rows 4.14 fused against 4.49, 768 rows 4.96 against 5.08, 1024 rows 6.18 against 6.04
     EXPERT_FUSE_MAX_ROWS = int(os.environ.get("I64H_EXPERT_FUSE_MAX_ROWS", "768"))
-    FP8_FUSE_MAX_ROWS = int(os.environ.get("I64H_FP8_FUSE_MAX_ROWS", "256"))  # e4m3 runner: routed rows of a decode-sized step
+    # e4m3 runner: routed rows of a decode-sized step (ms/step at 256 | 512 | 1024: 200 sequences 4.97 | 3.48 | 3.48, 256 sequences
+    # 5.75 | 4.41 | 4.40, 512 sequences 6.15 | 6.14 | 5.48)
+    FP8_FUSE_MAX_ROWS = int(os.environ.get("I64H_FP8_FUSE_MAX_ROWS", "1024"))
     EP_FUSE_MAX_ROWS = 1024  # the same for the pooled expert rows of the expert-parallel runner (8 ranks x 64 sequences x top-2)
     # expert-parallel runner, steps with more pooled expert rows than that (prefill chunks): dispatch every (route, token) row to the
     # rank that owns its expert and return the result by variable-split all-to-alls (each rank quantizes and multiplies only the rows of
@@ -696,8 +698,11 @@ class I64MoEModel:
             sp = 1
             if max_ctx_hint >= 256 and rows <= self.ATTN_TILE_ROWS:
                 sp = max(1, min(self.attn_max_splits, self.attn_target_wgs // rows, max_ctx_hint // 64))
-            if one_per_seq and rows >= self.ATTN_TILE_ROWS:
-                sp = max(sp, 2)   # an upper bound: the library launches fewer (one) when the rows alone fill the chip
+            if one_per_seq and (rows >= self.ATTN_TILE_ROWS or (max_ctx_hint >= 256 and rows > 64)):
+                # an upper bound: the library launches fewer (one) when the rows alone fill the chip - but only a launch that may be
+                # split spreads the kv heads of a row over workgroups (200 rows of 1024 tokens: 75 us with all kv heads in one
+                # workgroup per row)
+                sp = max(sp, 2)
             return sp
 
         segs: List[Tuple[int, int, bool]] = []
