@@ -533,7 +533,7 @@ class I64MoEModel:
             B.plan.run(token_ids, self.tables)
         if self.ep is not None or not (cfg.is_moe and self.PLAN_WITH_EMBEDDING):
             ops.embedding(token_ids, self.embed, out=B.h, reset_stats=st)  # + the reset of the step's stat slots
-        splits = self.attention_plan(B, n, max_ctx_hint, rows_are_slots, tokens_per_seq)
+        splits = self.attention_plan(B, n, max_ctx_hint, rows_are_slots, tokens_per_seq, kvc.k[0].dtype)
         # prefill-sized chunks that fit one resident grid: residual + norm + the quantization of the calls that read the normalised
         # rows are one launch (the fp32 normalised rows are never stored); record / inject / expert-parallel runs keep the two-kernel form
         mu = cfg.use_mu_guidance   # mu-guidance keeps the one-kernel-per-operation form: its Linears sit between the fused ones
@@ -689,19 +689,27 @@ class I64MoEModel:
     ATTN_TILE_ROWS = 256
     ATTN_MAX_SEGMENTS = 4
 
-    def attention_plan(self, B: "_Buffers", n: int, max_ctx_hint: int, rows_are_slots: bool, tokens_per_seq: Optional[List[int]]):
+    def attention_plan(self, B: "_Buffers", n: int, max_ctx_hint: int, rows_are_slots: bool, tokens_per_seq: Optional[List[int]],
+                       kv_dtype: Optional[torch.dtype] = None):
         """The attention launches of a step: [(first row, end row, splits)].  Rows of one-token sequences (decode rows) go to the
         row-per-workgroup form - enough splits to fill the chip when few rows carry long contexts, and never the many-row form;
         runs of rows that share sequences (prefill chunks) go to the many-row form from ATTN_TILE_ROWS rows on.  With
         tokens_per_seq (host list, rows in sequence order) a mixed step becomes one launch per maximal run of either kind."""
+        cfg = self.cfg
+        # the library's one-kv-head-per-workgroup form: only launches that may be split take it
+        heads_spread = (cfg.head_dim == 64 and cfg.num_kv_heads == 4 and cfg.num_heads == 16
+                        and (kv_dtype if kv_dtype is not None else self.kv.k[0].dtype) in (torch.float32, torch.float16, torch.bfloat16))
+
         def few_row_splits(rows: int, one_per_seq: bool) -> int:
             sp = 1
             if max_ctx_hint >= 256 and rows <= self.ATTN_TILE_ROWS:
                 sp = max(1, min(self.attn_max_splits, self.attn_target_wgs // rows, max_ctx_hint // 64))
-            if one_per_seq and (rows >= self.ATTN_TILE_ROWS or (max_ctx_hint >= 256 and rows > 64)):
-                # an upper bound: the library launches fewer (one) when the rows alone fill the chip - but only a launch that may be
-                # split spreads the kv heads of a row over workgroups (200 rows of 1024 tokens: 75 us with all kv heads in one
-                # workgroup per row)
+            if one_per_seq and rows >= self.ATTN_TILE_ROWS:
+                sp = max(sp, 2)   # an upper bound: the library launches fewer (one) when the rows alone fill the chip
+            elif heads_spread and max_ctx_hint > 64 and rows < self.ATTN_TILE_ROWS:
+                # also an upper bound, for the form that spreads the kv heads of a row over workgroups: 200 rows of 1024 tokens 75 us
+                # with all kv heads in one workgroup per row, 52 us spread; 7 rows of 129 tokens 10.4 against 6.8 us, 64 rows of 250
+                # tokens 16.2 against 7.2 us
                 sp = max(sp, 2)
             return sp
 
@@ -821,7 +829,7 @@ class I64MoEModel:
         if cfg.is_moe:
             B.plan.run(token_ids, self.tables)
         ops.embedding(token_ids, self.embed, out=B.h)
-        splits = self.attention_plan(B, n, max_ctx_hint, rows_are_slots, tokens_per_seq)
+        splits = self.attention_plan(B, n, max_ctx_hint, rows_are_slots, tokens_per_seq, kvc.k[0].dtype)
         S = cfg.shared_intermediate_size if cfg.is_moe else 0
         small = n * max(1, cfg.top_k if cfg.is_moe else 1) <= self.FP8_FUSE_MAX_ROWS
         # prefill-sized chunks (see FP8_FUSE_NORM): the norm quantizes the normalised rows itself (a row's scale needs only that
