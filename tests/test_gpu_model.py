@@ -560,3 +560,34 @@ def test_mu_guidance_checkpoint_files_to_gpu_logits(dev, golden_dir, tmp_path):
     last = np.cumsum(z["prompt_lens"]) - 1
     assert np.abs(runs[1][0] - z["int8_prefill_logits"][last]).max() <= 2e-2
     assert np.abs(runs[1][1] - z["int8_decode1_logits"]).max() <= 2e-2
+
+
+def test_step_buffers_are_kept_for_recent_row_counts_only_and_a_captured_graph_keeps_its_set(dev):
+    """An engine's steps come in many row counts: the runner keeps the buffer sets of the most recent ones (MAX_BUFFER_SETS),
+    and the set a decoder's graph was captured on survives any number of other shapes - the replay after them gives the bits
+    of an eager step from the same state."""
+    from vllm_i64_amd.model import GreedyDecoder
+    ocfg, w, model = _model("tiny-moe", dev, max_seqs=4)
+    ids = M.make_token_ids(ocfg, 64, seed=21)
+    prompts = [ids[:9], ids[9:20], ids[20:26]]
+    for s in range(4):
+        model.kv.free(s)
+    dec = GreedyDecoder(model, 3, use_graph=True)
+    dec.prefill(prompts, reserve_extra=8)
+    dec.step()
+    assert dec.graph is not None and (3, 3) in model._pinned
+    held = model._bufs[(3, 3)]
+    model.kv.reserve(3, 40)
+    for n in range(4, 4 + 2 * model.MAX_BUFFER_SETS):            # other shapes, on a sequence of their own
+        pos = torch.arange(n, dtype=torch.int32, device=dev)
+        model.forward(ids[:n].to(dev), pos, torch.full((n,), 3, dtype=torch.int32, device=dev), (pos + 1).contiguous())
+    loose = [k for k in model._bufs if k not in model._pinned]
+    assert len(loose) <= model.MAX_BUFFER_SETS and model._bufs[(3, 3)] is held
+    state = (dec.tokens.clone(), dec.positions.clone(), dec.ctx_len.clone(), list(dec.host_lens))
+    replayed = dec.step().clone()
+    kv_after = [k.clone() for k in model.kv.k]
+    eager = GreedyDecoder(model, 3, use_graph=False)
+    eager.tokens.copy_(state[0]); eager.positions.copy_(state[1]); eager.ctx_len.copy_(state[2])
+    eager.host_lens, eager.max_ctx_hint = list(state[3]), dec.max_ctx_hint
+    again = eager.step()
+    assert torch.equal(replayed, again) and all(torch.equal(a, b) for a, b in zip(kv_after, model.kv.k))

@@ -272,6 +272,7 @@ class I64MoEModel:
             self.spl += 2
         self.stats = ops.stats_alloc(self.spl * cfg.num_layers + 1, dev)
         self._bufs: Dict[tuple, _Buffers] = {}
+        self._pinned: set = set()
         self.dec_sync = ops.decode_sync_alloc(dev)
         self._resident_used = False   # a launch with a grid barrier was issued since the last check_sync
 
@@ -293,14 +294,29 @@ class I64MoEModel:
         return B.logits
 
     # ---- helpers ----
+    # An engine's steps come in many row counts (chunked prefill, mixed batches): the step buffers of the most recently used counts
+    # are kept, older sets are dropped (their memory goes back to the allocator, ordered by the stream).  A set whose addresses a
+    # captured graph holds is pinned and never dropped.
+    MAX_BUFFER_SETS = int(os.environ.get("I64H_MAX_BUFFER_SETS", "8"))
+
     def buffers(self, n: int, n_logit_rows: int) -> _Buffers:
         key = (n, n_logit_rows)
-        if key not in self._bufs:
+        B = self._bufs.pop(key, None)
+        if B is None:
             ep_world = self.ep.world if self.ep is not None else 0
             if ep_world and self.EP_A2A_PREFILL and n * ep_world * self.cfg.top_k > self.EP_FUSE_MAX_ROWS:
                 ep_world = 0   # prefill-sized step of the expert-parallel runner: rows travel by all-to-all, no pooled buffers
-            self._bufs[key] = _Buffers(self.cfg, n, n_logit_rows, self.device, ep_world=ep_world)
-        return self._bufs[key]
+            B = _Buffers(self.cfg, n, n_logit_rows, self.device, ep_world=ep_world)
+        self._bufs[key] = B   # most recently used last
+        loose = [k for k in self._bufs if k not in self._pinned and k != key]
+        for k in loose[:max(0, len(loose) + 1 - self.MAX_BUFFER_SETS)]:
+            del self._bufs[k]
+        return B
+
+    def pin_buffers(self, n: int, n_logit_rows: int) -> None:
+        """The step buffers of this row count stay for the life of the model (a captured graph replays on their addresses)."""
+        self.buffers(n, n_logit_rows)
+        self._pinned.add((n, n_logit_rows))
 
     # e4m3 runner, prefill chunks: residual + norm + per-token quantization in one pass (40.8 us against 46.5 + 22.8 us per launch,
     # bit-identical; prefill 656-665 k -> 716 k tokens/s in alternating processes on one box; "0" keeps the two launches)
@@ -1204,6 +1220,7 @@ class GreedyDecoder:
         for dst, src in zip((self.tokens, self.positions, self.ctx_len), state):
             dst.copy_(src)
         torch.cuda.synchronize()
+        self.m.pin_buffers(self.batch, self.batch)   # the graph replays on these addresses
         self.graph = torch.cuda.CUDAGraph()
         try:
             # thread_local: other threads of the process (e.g. a collective library's watchdog) may touch the runtime
