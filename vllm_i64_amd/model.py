@@ -489,7 +489,7 @@ class I64MoEModel:
             return pl.frags()
         return None
 
-    FRAGS_MIN_ROWS = 4096  # from this many operand rows on a call has enough 128-row tiles for the operand-stationary kernel
+    FRAGS_MIN_ROWS = int(os.environ.get("I64H_FRAGS_MIN_ROWS", "4096"))  # from this many operand rows on a call has enough 128-row tiles for the operand-stationary kernel
 
     def _gemm_i8(self, a8, rs, pl: PackedLinear, out, *, epilogue=ops.EPI_STORE, group_offsets=None, row_slot=None, slot_base=0, stats=None):
         """int8 operand rows x one packed Linear (or a stack of them, grouped): the operand-stationary kernel on the weight's
