@@ -128,8 +128,8 @@ def test_decode_attention_at_2048_tokens_against_oracle_rows(dev):
                                        ("dense306-synth", [23, 10]), ("dense306-synth", [180, 120]),
                                        ("trhash500m-synth", [1] * 128), ("trhash500m-synth", [1] * 129), ("trhash500m-synth", [1] * 256),
                                        ("trhash500m-synth", [1] * 257), ("dense306-synth", [1] * 300), ("trhash500m-synth", [1] * 384),
-                                       ("trhash500m-synth", [1] * 385), ("trhash500m-synth", [1] * 512), ("trhash500m-synth", [1] * 513),
-                                       ("trmoe306-synth", [1] * 384), ("dense306-synth", [1] * 513)])
+                                       ("trhash500m-synth", [1] * 385), ("trhash500m-synth", [1] * 512), ("trhash500m-synth", [1] * 1024), ("trhash500m-synth", [1] * 1025),
+                                       ("trmoe306-synth", [1] * 384), ("dense306-synth", [1] * 1025), ("trhash500m-synth", [512] + [1] * 31)])
 def test_other_baseline_configs_teacher_forced(dev, name, lens):
     """BASELINE configurations 1 and 2 at their real dimensions (two-layer cuts): `trmoe306-synth` (4 experts of 512, shared
     2048 - the shared down projection's K = 2048 sits on the decode-sized kernel's limit; cyclic top-2 routing, 0.95 / 0.05
@@ -139,7 +139,8 @@ def test_other_baseline_configs_teacher_forced(dev, name, lens):
     Decode steps around the row counts where the runner changes kernels (12-token histories): 128 / 129 sequences (the launches with
     the norm in front of the quantizer end at 256 routed rows), 256 / 257 (... and at 256 rows; the attention must stay in a
     row-per-workgroup form), 384 / 385 (768 / 770 routed rows: experts inside the decode-sized launch or through the tiled kernel),
-    512 / 513 (the Linear calls change to the prefill-sized path), 300 and 513 rows of the dense model."""
+    1024 / 1025 (the Linear calls change to the prefill-sized path), 300 and 1025 rows of the dense model, and the reference engine's
+    default step: a 512-token chunk of one sequence with 31 other sequences' decode rows behind it."""
     from vllm_i64_amd.config import ModelConfig
     from vllm_i64_amd.model import I64MoEModel
     ocfg = dataclasses.replace(M.named_config(name), num_layers=2, name=name + "-2layer")

@@ -419,7 +419,7 @@ def test_prefill_with_norm_and_quantization_in_one_launch_gives_the_same_bits(de
     ocfg, w, model = _model(name, dev, max_seqs=4)
     lens = [200, 130, 77, 150]
     n = sum(lens)
-    assert n > I64MoEModel.FUSE_MAX_ROWS
+    model.FUSE_MAX_ROWS = 256   # (the runner itself keeps steps of this size on the decode-sized launches)
     ids = M.make_token_ids(ocfg, n, seed=5).to(dev)
     pos = torch.cat([torch.arange(t) for t in lens]).to(torch.int32).to(dev)
     slots = torch.cat([torch.full((t,), s, dtype=torch.int32) for s, t in enumerate(lens)]).to(dev)
@@ -453,8 +453,8 @@ def test_expired_grid_barrier_is_reported_by_the_decoder_and_the_engine_adapter(
     from vllm_i64_amd.model import GreedyDecoder, I64MoEModel
     ocfg, w, model = _model("tiny-moe", dev, max_seqs=4)
     lens = [200, 130, 77, 150]     # 557 rows: nine workgroups of 64 rows in the resident launch
-    assert sum(lens) > I64MoEModel.FUSE_MAX_ROWS and model.FUSE_NORM_QUANT
-    model.FQ_MIN_ROWS = 0     # the resident launch also for this small chunk (the runner's own threshold is FQ_MIN_ROWS rows)
+    assert model.FUSE_NORM_QUANT
+    model.FUSE_MAX_ROWS, model.FQ_MIN_ROWS = 256, 0     # the resident launch also for this small chunk (the runner's own threshold is FQ_MIN_ROWS rows)
     ids = M.make_token_ids(ocfg, sum(lens), seed=5)
     prompts = list(ids.split(lens))
     dec = GreedyDecoder(model, 4, use_graph=False)

@@ -205,13 +205,15 @@ def ptr(t) -> int:
     """Device (or host) address of a tensor / ctypes buffer; None -> NULL."""
     if t is None:
         return 0
-    if hasattr(t, "data_ptr"):
-        # every tensor argument of the C ABI is device memory (host arrays go in as ctypes buffers): a host tensor's address
-        # handed to a kernel is a GPU memory fault, so it is refused here
-        if not getattr(t, "is_cuda", False):
-            raise I64HError("expected a GPU tensor, got one on " + str(getattr(t, "device", "the host")))
-        return t.data_ptr()
-    return ctypes.addressof(t)
+    try:   # (called a couple of thousand times per eager step: the tensor case first, without attribute probing)
+        on_gpu = t.is_cuda
+    except AttributeError:
+        return ctypes.addressof(t)
+    # every tensor argument of the C ABI is device memory (host arrays go in as ctypes buffers): a host tensor's address
+    # handed to a kernel is a GPU memory fault, so it is refused here
+    if not on_gpu:
+        raise I64HError("expected a GPU tensor, got one on " + str(getattr(t, "device", "the host")))
+    return t.data_ptr()
 
 
 def call(name: str, *args):

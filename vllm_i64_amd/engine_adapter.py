@@ -15,6 +15,7 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence
 
+import numpy as np
 import torch
 
 from .model import I64MoEModel
@@ -85,9 +86,14 @@ class EngineModel:
         pos_h = positions.to("cpu", torch.int64)
         pos = pos_h.to(device=dev, dtype=torch.int32).contiguous()
         slots = torch.repeat_interleave(torch.tensor([int(s) for s in seq_ids], dtype=torch.int32), torch.tensor(tps)).to(dev)
-        ends = torch.cumsum(torch.tensor(tps), 0)
-        last_pos = [int(pos_h[int(e) - 1 if t > 0 else 0]) if t > 0 else -1 for e, t in zip(ends, tps)]
-        max_pos = [int(pos_h[int(e) - t:int(e)].max()) if t > 0 else -1 for e, t in zip(ends, tps)]
+        # highest position of every sequence in the step (-1: no token), in one pass over the host copy of the positions
+        pos_np, tps_np = pos_h.numpy(), np.asarray(tps, dtype=np.int64)
+        starts = np.concatenate(([0], np.cumsum(tps_np)[:-1])) if len(tps) else np.zeros(0, dtype=np.int64)
+        max_pos = [-1] * len(tps)
+        live = np.nonzero(tps_np > 0)[0]
+        if n > 0 and live.size:
+            for i, m in zip(live.tolist(), np.maximum.reduceat(pos_np, starts[live]).tolist()):
+                max_pos[i] = int(m)
         self._check_cache(kv_cache)
         # the kernels index the rotary table by position and the block table by position / block without bounds: a position
         # beyond either would read another sequence's table row and write K/V into its blocks
@@ -103,11 +109,14 @@ class EngineModel:
         # launches that wait on a grid barrier (prefill-sized chunks) report an expired wait through a device word: read it
         # back before the logits leave (the engine reads the logits on the host right after, so this adds no idle time)
         r.check_sync(force=False)
+        # seq_lens follows the tokens written (the reference's batched form, core/kv_cache.py:457-459): one indexed maximum where the
+        # tensor lives - reading it back per sequence would wait for the whole forward once per sequence
         sl = kv_cache.seq_lens
-        for sid, m in zip(seq_ids, max_pos):
-            if m >= 0:
-                sl[int(sid)] = max(int(sl[int(sid)]), m + 1)
-        del last_pos
+        upd = [(int(sid), m + 1) for sid, m in zip(seq_ids, max_pos) if m >= 0]
+        if upd:
+            idx = torch.tensor([u[0] for u in upd], dtype=torch.long).to(sl.device)
+            new_len = torch.tensor([u[1] for u in upd], dtype=sl.dtype).to(sl.device)
+            sl[idx] = torch.maximum(sl[idx], new_len)
         return logits
 
     __call__ = forward

@@ -368,7 +368,9 @@ class I64MoEModel:
     # Up to this many operand rows the quantizer runs inside the GEMM (one launch per Linear call, weights streamed once per 16-row
     # tile); beyond, the rows are quantized once and go through the tiled kernels.  Measured on decode steps of the headline model
     # (ms/step at 256 | 512 | 1024): 300 sequences 5.43 | 4.49 | 4.14, 512 sequences 6.75 | 6.04 | 6.18, 768 sequences - | 6.77 | 6.73.
-    FUSE_MAX_ROWS = int(os.environ.get("I64H_FUSE_MAX_ROWS", "512"))
+    # 1024 is the library's limit for these launches, and the reference engine's default step (512 prefill tokens + up to 32 decode
+    # rows, engine/i64_scheduler.py:177-194) must stay on this side: 8.0 -> 5.5 ms per such step.
+    FUSE_MAX_ROWS = int(os.environ.get("I64H_FUSE_MAX_ROWS", "1024"))
     NORM_FUSE_MAX_ROWS = 256  # the library's limit for the launches with the RMSNorm in front of the quantizer
     # the same for the routed (route, token) rows of a step: 600 rows 4.14 fused against 4.49, 768 rows 4.96 against 5.08, 1024 rows 6.18 against 6.04
     EXPERT_FUSE_MAX_ROWS = int(os.environ.get("I64H_EXPERT_FUSE_MAX_ROWS", "768"))
