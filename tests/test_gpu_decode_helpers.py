@@ -99,3 +99,52 @@ def test_fused_qkv_launch_with_and_without_helper_waves(dev):
     for u, v in zip(a, b):
         assert torch.equal(u, v)
     assert a[0].abs().sum() > 0 and a[1].abs().sum() > 0
+
+
+@pytest.mark.parametrize("rows,K,N,epi,groups,packed", [
+    (300, 1024, 1024, 0, 1, True),     # 32-row tiles, ragged last tile (300 = 9 x 32 + 12)
+    (543, 1024, 3584, 1, 1, True),     # 64-row tiles: a 512-token chunk + 31 decode rows, SwiGLU + statistics
+    (600, 1792, 1024, 0, 1, True),     # 64-row tiles, two batches of K steps
+    (1024, 1024, 1536, 0, 1, False),   # the launcher's row limit, row-major weights
+    (257, 4096, 320, 0, 1, True),      # long K: 32 rows x (K + 32) bytes fit LDS, 64 would not
+    (1000, 1024, 896, 1, 3, True),     # grouped: 333 rows per group on average -> 32-row tiles over ragged groups (one empty), bucket statistics
+    (1000, 448, 1024, 0, 3, True),     # grouped down projection, K too short for the partial sums
+])
+def test_decode_gemm_tiles_of_32_and_64_rows_give_the_bits_of_16_row_tiles(dev, rows, K, N, epi, groups, packed):
+    """Launches of more than 256 (512) operand rows per group take 32- (64-) row tiles: every output and every statistics word is
+    the one the 16-row tiles give."""
+    from vllm_i64_amd import ops
+    g = torch.Generator().manual_seed(rows * 3 + K + N)
+    x = torch.empty(rows, K).normal_(0, 1, generator=g).to(dev)
+    w = torch.randint(-128, 128, (groups, N, K), dtype=torch.int8, generator=g).to(dev)
+    ws = (torch.rand(groups, generator=g) * 1e-2 + 1e-3).to(dev)
+    wf = ops.pack_weight_frags(w) if packed else None
+    off = slot = None
+    if groups > 1:
+        cnt = torch.tensor([587, 0, rows - 587])
+        off = torch.cat([torch.zeros(1, dtype=torch.long), cnt.cumsum(0)]).to(torch.int32).to(dev)
+        grp = torch.repeat_interleave(torch.arange(groups), cnt)
+        slot = (grp * 2 + (torch.arange(rows) % 2)).to(torch.int32).to(dev)
+    n_in = 2 * groups if groups > 1 else 1
+    stats = ops.stats_alloc(1 + 2 * n_in, dev)
+    outs = []
+    try:
+        for tall in (0, 1):
+            ops.call("i64h_set_skinny_tall", tall)
+            ops.stats_reset(stats)
+            if slot is None:
+                ops.rows_minmax(x, stats, slot_base=1)
+            else:
+                ops.rows_minmax(x, stats, slot_base=1, slots=slot.view(-1, 1))
+            out = torch.zeros(rows, N // 2 if epi else N, device=dev)
+            d = ops.gemm_desc(x, w, ws, out, a_row_slot=slot, a_slot_base=1, group_offsets=off, epilogue=epi, out_row_slot=slot,
+                              out_slot_base=1 + n_in, stats=stats, want_stats=bool(epi), m_total=rows, a_group_slots=2 if groups > 1 else 0,
+                              w_frags=wf)
+            ops.gemm_i8_pair(d)
+            torch.cuda.synchronize()
+            # (a slot's words are shards that tiles pick by their index: the ranges they fold to are what must agree)
+            outs.append((out.cpu(), [t.cpu() for t in ops.qparams(stats, 1 + 2 * n_in)]))
+    finally:
+        ops.call("i64h_set_skinny_tall", 1)
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][0].abs().sum() > 0
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))

@@ -88,6 +88,7 @@ SIGNATURES: Dict[str, str] = {
     "i64h_moe_forward_static_init": "",
     "i64h_set_skinny_waves": "i",
     "i64h_set_skinny_helpers": "i",
+    "i64h_set_skinny_tall": "i",
     "i64h_debug_set_stamps": "pl",
     "i64h_set_gemm_stage64": "i",
     "i64h_set_gemm_rowstream": "i",

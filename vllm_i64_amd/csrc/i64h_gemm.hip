@@ -611,7 +611,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void g
 // parked in LDS for the whole K (row stride K + 32 bytes: conflict-free ds_read_b128 fragments).
 // Workgroup = 4 waves; wave w owns output columns [16w, 16w+16) of the workgroup's 64 (EPI_SWIGLU: 16 gate columns and
 // their 16 up partners), all row fragments.
-#define SK_BM 16  // operand rows per workgroup: one MFMA row fragment (more, smaller workgroups; each reads 1/4 of a 64-row operand)
+#define SK_BM 16  // operand rows per workgroup: one MFMA row fragment (more, smaller workgroups; each reads 1/4 of a 64-row operand);
+                  // launches of more than 256 rows take 32- or 64-row tiles (template parameter BMR of the kernel)
 #define SK_MF (SK_BM / 16)
 #define SK_AREA_MIN 4096  // >= 2 * I64H_STAT_TAB * 4 (statistics table) and >= 16 * 64 * 4 (head tile)
 static_assert(SK_AREA_MIN >= 2 * I64H_STAT_TAB * 4 && SK_AREA_MIN >= 16 * 64 * 4, "epilogue scratch of the decode-sized kernel");
@@ -667,21 +668,22 @@ __device__ __forceinline__ void pro_norm_row(float4 (&x)[4], const float4 (&gw)[
 
 // PRO: RMSNorm of the operand rows in front of the quantizer, with the call statistics handed
 // between the workgroups of the launch (NormPro, i64h_gemm_dev.h); pub: this problem's column-tile-0 workgroups publish them.
-template <int EPI, int NW, int HW = 1, int PRO = 0>  // PRO: 0 none, 1 norm prologue
+template <int EPI, int NW, int HW = 1, int PRO = 0, int BMR = SK_BM>  // PRO: 0 none, 1 norm prologue; BMR: operand rows per workgroup (16, 32 or 64)
 __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const int bid, char* smem, const RowTailArgs& ta,
                                                     const NormPro& np = NormPro(), const bool pub_problem = false) {
     constexpr int NF = (EPI == EPI_SWIGLU) ? 2 : 1;  // B fragments per wave per step
+    constexpr int MF = BMR / 16;                     // MFMA row fragments of the tile
     // K steps (64 deep) whose B fragments are in flight together: all of K = 1024 in one batch (half with two fragments per step)
     // (with helper waves a wave streams half of K: 8 steps cover K = 1024 in one batch for either epilogue)
     constexpr int SK_STEPS = HW > 1 ? 8 : 16 / NF;
     const int K = p.K, LDA = K + 32;
     // LDS: operand rows [16][LDA] int8, reused by the epilogues (statistics table, head tile of EPI_QKR: SK_AREA_MIN bytes at
     // least, which matters for K < 224) | info (16 B) | q_inv[16] q_scale[16] q_zp[16]
-    const int area = max(SK_BM * LDA, SK_AREA_MIN);
+    const int area = max(BMR * LDA, SK_AREA_MIN);
     int* s_info = (int*)(smem + area);
     float* q_inv = (float*)(smem + area + 16);
-    float* q_scale = q_inv + SK_BM;
-    int* q_zp = (int*)(q_scale + SK_BM);
+    float* q_scale = q_inv + BMR;
+    int* q_zp = (int*)(q_scale + BMR);
 
     const int nout = (EPI == EPI_SWIGLU) ? p.N / 2 : p.N;
     constexpr int BNB = NW * 16, NT = NW * HW * 64;  // output columns / threads per workgroup
@@ -720,11 +722,11 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
     int g, row0, rows;
     if (p.group_off == nullptr) {  // one group: nothing to look up
         g = 0;
-        row0 = mt * SK_BM;
-        rows = min(SK_BM, p.M_total - row0);
+        row0 = mt * BMR;
+        rows = min(BMR, p.M_total - row0);
         if (rows <= 0) return;
     } else {
-        if (wid == 0) locate_mtile<SK_BM>(p, mt, lane, s_info);  // one round trip: lane i looks at group i
+        if (wid == 0) locate_mtile<BMR>(p, mt, lane, s_info);  // one round trip: lane i looks at group i
         __syncthreads();
         g = s_info[0]; row0 = s_info[1]; rows = s_info[2];
         if (g < 0) return;
@@ -759,8 +761,8 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
     const int col = nt * BNB + wcol * 16 + fr;
     const bool col_in = col < nout;
     const bool col_ok = col_in && !helper;
-    constexpr int PART_OFF = SK_AREA_MIN, PART_BYTES = NW * SK_MF * NF * 64 * 16;
-    const bool ksplit = HW > 1 && SK_BM * LDA >= PART_OFF + PART_BYTES && nsteps >= 2;  // uniform over the workgroup
+    constexpr int PART_OFF = SK_AREA_MIN, PART_BYTES = NW * MF * NF * 64 * 16;
+    const bool ksplit = HW > 1 && BMR * LDA >= PART_OFF + PART_BYTES && nsteps >= 2;  // uniform over the workgroup
     const int s_half = (nsteps + 1) / 2;
     const int s_begin = (ksplit && helper) ? s_half : 0;
     const int s_end = ksplit ? (helper ? nsteps : s_half) : (helper ? 0 : nsteps);
@@ -798,10 +800,10 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
         }
     }
     // output rows of this lane's four accumulator rows (a scatter back to token order spares the consumer an index lookup)
-    int c_row[SK_MF][4];
+    int c_row[MF][4];
     if (EPI == EPI_STORE) {
 #pragma unroll
-        for (int i = 0; i < SK_MF; ++i)
+        for (int i = 0; i < MF; ++i)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int r = i * 16 + fq * 4 + reg;
@@ -809,10 +811,10 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
             }
     }
     // residual form (C = c_add + product): the lane's four addends are requested now, far ahead of the epilogue
-    float c_res[SK_MF][4];
+    float c_res[MF][4];
     if (EPI == EPI_STORE) {
 #pragma unroll
-        for (int i = 0; i < SK_MF; ++i)
+        for (int i = 0; i < MF; ++i)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int r = i * 16 + fq * 4 + reg;
@@ -821,10 +823,10 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
     }
     // SwiGLU with statistics: the slot of each of this lane's four output rows, requested now (the epilogue would otherwise
     // start with a dependent read)
-    int o_rel[SK_MF][4];
+    int o_rel[MF][4];
     if (EPI == EPI_SWIGLU) {
 #pragma unroll
-        for (int i = 0; i < SK_MF; ++i)
+        for (int i = 0; i < MF; ++i)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int r = i * 16 + fq * 4 + reg;
@@ -887,7 +889,7 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
         a_issue(tid);
         if (s_end > s_begin) bload(s_begin);
         SK_STAMP(1);
-        if (tid < SK_BM) {
+        if (tid < BMR) {
             QParams q;
             q.scale = 0.0f; q.inv_scale = 0.0f; q.zp = 0;
             if (tid < rows) {
@@ -917,7 +919,9 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
         __syncthreads();
         SK_STAMP(3);
     } else {
-        static_assert(!PRO || (NW == 4 && HW == 2 && SK_BM == 16), "the norm prologue is laid out for eight waves and one row fragment");
+#if BMR == 16   // (a build with taller tiles, for measurements, must not be given these launches)
+        static_assert(!PRO || (NW == 4 && HW == 2 && BMR == 16), "the norm prologue is laid out for eight waves and one row fragment");
+#endif
         // wave wid holds rows wid and wid + 8 of the tile, lane l elements [16 l, 16 l + 16) of each (K <= 1024: launcher)
         const bool lane_in = lane < cpr;
         const int kq = lane_in ? lane : 0;
@@ -1009,7 +1013,7 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
             mx = max(mx, (uint32_t)__shfl_xor((int)mx, 16));
             mn = min(mn, (uint32_t)__shfl_xor((int)mn, 32));
             mx = max(mx, (uint32_t)__shfl_xor((int)mx, 32));
-            if (lane < SK_BM) {
+            if (lane < BMR) {
                 QParams q;
                 q.scale = 0.0f; q.inv_scale = 0.0f; q.zp = 0;
                 if (lane < rows) q = choose_qparams_u7(ordered_to_f32(mn), ordered_to_f32(mx));
@@ -1034,9 +1038,9 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
         SK_STAMP(3);
     }
 
-    v4i acc[SK_MF][NF];
+    v4i acc[MF][NF];
 #pragma unroll
-    for (int i = 0; i < SK_MF; ++i)
+    for (int i = 0; i < MF; ++i)
 #pragma unroll
         for (int f = 0; f < NF; ++f) acc[i][f] = (v4i){0, 0, 0, 0};
     for (int s0 = s_begin; s0 < s_end; s0 += SK_STEPS) {
@@ -1050,7 +1054,7 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
         for (int s = 0; s < SK_STEPS; ++s) {
             if (s0 + s >= s_end) break;
 #pragma unroll
-            for (int i = 0; i < SK_MF; ++i) {
+            for (int i = 0; i < MF; ++i) {
                 if (i >= mfr) break;
                 const v4i a = *(const v4i*)(smem + (i * 16 + fr) * LDA + (s0 + s) * 64 + fq * 16);
 #pragma unroll
@@ -1061,17 +1065,17 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
 
     if (HW > 1 && ksplit) {
         __syncthreads();  // every wave is done with the operand rows: their LDS takes the helper waves' partial sums
-        v4i* part = (v4i*)(smem + PART_OFF) + (wcol * (SK_MF * NF)) * 64 + lane;
+        v4i* part = (v4i*)(smem + PART_OFF) + (wcol * (MF * NF)) * 64 + lane;
         if (helper) {
 #pragma unroll
-            for (int i = 0; i < SK_MF; ++i)
+            for (int i = 0; i < MF; ++i)
 #pragma unroll
                 for (int f = 0; f < NF; ++f) part[(i * NF + f) * 64] = acc[i][f];
         }
         __syncthreads();
         if (!helper) {
 #pragma unroll
-            for (int i = 0; i < SK_MF; ++i)
+            for (int i = 0; i < MF; ++i)
 #pragma unroll
                 for (int f = 0; f < NF; ++f) acc[i][f] += part[(i * NF + f) * 64];
         }
@@ -1079,7 +1083,7 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
     SK_STAMP(4);
     if constexpr (EPI == EPI_STORE) {
 #pragma unroll
-        for (int i = 0; i < SK_MF; ++i)
+        for (int i = 0; i < MF; ++i)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int r = i * 16 + fq * 4 + reg;
@@ -1092,7 +1096,9 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
         // The workgroup's 64 columns are exactly one head (launcher: head_dim == 64 == NW * 16), so the per-head RMSNorm, the
         // rotate-half RoPE and the cache write need nothing from other workgroups.  The tile goes through LDS once so that
         // a wave owns whole rows (lane = dim), the same shape and operation order as the stand-alone row kernel.
-        static_assert(SK_MF == 1 && NW == 4, "one row fragment, four waves = 64 columns");
+#if BMR == 16
+        static_assert(MF == 1 && NW == 4, "one row fragment, four waves = 64 columns");
+#endif
         __syncthreads();  // the operand rows in LDS are no longer needed
         float* s_c = (float*)smem;  // [16][64]
         if (!helper) {
@@ -1139,7 +1145,7 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
             __syncthreads();
         }
 #pragma unroll
-        for (int i = 0; i < SK_MF; ++i)
+        for (int i = 0; i < MF; ++i)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 if (helper) break;
@@ -1184,11 +1190,11 @@ __device__ __forceinline__ void gemm_i8_skinny_body(const GemmI8Args& p, const i
 #undef SK_STAMP
 }
 
-template <int EPI, int NW, int HW = 1>
+template <int EPI, int NW, int HW = 1, int BMR = SK_BM>
 __global__ __launch_bounds__(NW * HW * 64) void gemm_i8_skinny_kernel(GemmI8Pair pp, RowTailArgs ta) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if ((int)blockIdx.x < pp.nblk0) gemm_i8_skinny_body<EPI, NW, HW>(pp.p[0], blockIdx.x, smem, ta);
-    else gemm_i8_skinny_body<EPI, NW, HW>(pp.p[1], blockIdx.x - pp.nblk0, smem, ta);
+    if ((int)blockIdx.x < pp.nblk0) gemm_i8_skinny_body<EPI, NW, HW, 0, BMR>(pp.p[0], blockIdx.x, smem, ta);
+    else gemm_i8_skinny_body<EPI, NW, HW, 0, BMR>(pp.p[1], blockIdx.x - pp.nblk0, smem, ta);
 }
 
 // The same with the RMSNorm prologue (NormPro): the first problem's column-tile-0 workgroups publish the call statistics.
@@ -1482,55 +1488,79 @@ static bool rs_ok(const i64h_gemm_desc* d) {
     return !d->a_fp32 && d->K % 64 == 0 && (int64_t)d->N * d->K < (1ll << 31) && d->M_total / d->num_groups >= 1024;
 }
 
-static int skinny_blocks(const i64h_gemm_desc* d, int bnb) {
+static int skinny_blocks(const i64h_gemm_desc* d, int bnb, int bm = SK_BM) {
     const int nout = d->epilogue == EPI_SWIGLU ? d->N / 2 : d->N;
     // grouped: an upper bound (every group may end with a partial tile); one group: exact
-    const int m_tiles = (int)((d->M_total + SK_BM - 1) / SK_BM) + (d->group_offsets ? d->num_groups : 0);
+    const int m_tiles = (int)((d->M_total + bm - 1) / bm) + (d->group_offsets ? d->num_groups : 0);
     return d->M_total == 0 ? 0 : m_tiles * sk_pad_tiles((nout + bnb - 1) / bnb);
 }
 
 static int g_skinny_waves = 0;  // 0 = default; test/tuning override through i64h_set_skinny_waves
 static int g_skinny_helpers = 1;  // four-wave workgroups get four helper waves for the operand rows (i64h_set_skinny_helpers)
 
-template <int EPI, int NW, int HW = 1>
+template <int EPI, int NW, int HW = 1, int BMR = SK_BM>
 static int launch_skinny(const i64h_gemm_desc* a, const i64h_gemm_desc* b, hipStream_t st, const RowTailArgs* tail = nullptr) {
     if constexpr ((NW == 4 || NW == 2) && HW == 1) {
-        if (g_skinny_helpers) return launch_skinny<EPI, NW, 2>(a, b, st, tail);
+        if (g_skinny_helpers) return launch_skinny<EPI, NW, 2, BMR>(a, b, st, tail);
     }
     RowTailArgs ta;
     if (tail) ta = *tail; else memset(&ta, 0, sizeof(ta));
     GemmI8Pair pp;
     pp.p[0] = to_args(a);
     pp.p[1] = b ? to_args(b) : pp.p[0];
-    pp.nblk0 = skinny_blocks(a, NW * 16);
-    const int total = pp.nblk0 + (b ? skinny_blocks(b, NW * 16) : 0);
+    pp.nblk0 = skinny_blocks(a, NW * 16, BMR);
+    const int total = pp.nblk0 + (b ? skinny_blocks(b, NW * 16, BMR) : 0);
     if (total == 0) return 0;
     if (g_stamps && g_stamp_cur + total <= g_stamp_cap) {
         pp.p[0].stamps = pp.p[1].stamps = g_stamps + g_stamp_cur * 8;
         g_stamp_cur += total;
     }
     const int kmax = b && b->K > a->K ? b->K : a->K;
-    size_t area = (size_t)SK_BM * (kmax + 32);
+    size_t area = (size_t)BMR * (kmax + 32);
     if (area < SK_AREA_MIN) area = SK_AREA_MIN;  // the epilogues reuse the operand area
-    const size_t lds = area + 16 + 3 * SK_BM * 4;
+    const size_t lds = area + 16 + 3 * BMR * 4;
     if (lds > 64 * 1024) {  // long K (e.g. a dense down projection with K = 4096): more dynamic LDS than the default limit
         static bool raised[64] = {};  // per instantiation and device (one process may drive several GPUs)
         int device = 0;
         I64H_CHECK_HIP(hipGetDevice(&device));
         if (device < 0 || device >= 64 || !raised[device]) {
-            I64H_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_i8_skinny_kernel<EPI, NW, HW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            I64H_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_i8_skinny_kernel<EPI, NW, HW, BMR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             if (device >= 0 && device < 64) raised[device] = true;
         }
     }
-    hipLaunchKernelGGL((gemm_i8_skinny_kernel<EPI, NW, HW>), dim3((unsigned)total), dim3(NW * HW * 64), lds, st, pp, ta);
+    hipLaunchKernelGGL((gemm_i8_skinny_kernel<EPI, NW, HW, BMR>), dim3((unsigned)total), dim3(NW * HW * 64), lds, st, pp, ta);
     I64H_CHECK_LAUNCH();
     return 0;
+}
+
+static int g_skinny_tall = 1;  // tuning knob: 0 = 16-row tiles for every decode-sized launch (i64h_set_skinny_tall)
+
+// Rows of the launch's largest call per group -> tile height.  A tile streams its column slice of the weights once and quantizes
+// its operand rows once per column tile, so taller tiles divide both; below a few hundred rows they leave CUs idle instead.
+// Measured (ms per decode step of the headline model, 16 | 32 | 64 rows): 64 sequences 1.87 | 2.11 | 2.53, 300 sequences
+// 4.17 | 3.80 | 4.18, 512 sequences 6.08 | 5.78 | 5.84, a 512-token chunk + 31 decode rows 7.36 | 6.14 | 5.83.
+static int skinny_tile_rows(const i64h_gemm_desc* a, const i64h_gemm_desc* b) {
+    if (!g_skinny_tall || !g_skinny_helpers) return SK_BM;
+    int64_t m = a->M_total / (a->group_offsets ? a->num_groups : 1);
+    if (b) {
+        const int64_t mb = b->M_total / (b->group_offsets ? b->num_groups : 1);
+        m = mb > m ? mb : m;
+    }
+    const int kmax = b && b->K > a->K ? b->K : a->K;
+    int bm = m > 512 ? 64 : m > 256 ? 32 : SK_BM;
+    while (bm > SK_BM && (size_t)bm * (kmax + 32) + 16 + 3 * bm * 4 > 160 * 1024) bm >>= 1;  // the tile's rows stay in LDS for the whole K
+    return bm;
 }
 
 template <int EPI>
 static int launch_skinny_nw(const i64h_gemm_desc* a, const i64h_gemm_desc* b, hipStream_t st) {
     const int nw = g_skinny_waves ? g_skinny_waves : 4;
     if (nw == 2) return launch_skinny<EPI, 2>(a, b, st);
+    if (nw == 4) {
+        const int bm = skinny_tile_rows(a, b);
+        if (bm == 64) return launch_skinny<EPI, 4, 2, 64>(a, b, st);
+        if (bm == 32) return launch_skinny<EPI, 4, 2, 32>(a, b, st);
+    }
     if (nw == 4) return launch_skinny<EPI, 4>(a, b, st);
     if (nw == 16) return launch_skinny<EPI, 16>(a, b, st);
     return launch_skinny<EPI, 8>(a, b, st);
@@ -1599,6 +1629,12 @@ extern "C" {
 // tuning knob: 1 (default) = the decode-sized kernel's four-wave workgroups get four helper waves for the operand rows
 int i64h_set_skinny_helpers(int32_t on) {
     g_skinny_helpers = on ? 1 : 0;
+    return 0;
+}
+
+// tuning knob: 1 (default) = decode-sized launches of more than 256 (512) rows per group take 32- (64-) row tiles; 0 = 16-row tiles always
+int i64h_set_skinny_tall(int32_t on) {
+    g_skinny_tall = on ? 1 : 0;
     return 0;
 }
 

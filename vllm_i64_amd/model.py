@@ -382,7 +382,7 @@ class I64MoEModel:
     # rank that owns its expert and return the result by variable-split all-to-alls (each rank quantizes and multiplies only the rows of
     # its own experts); "0" keeps the fixed-shape all-gather form of the decode-sized steps for every step
     EP_A2A_PREFILL = os.environ.get("I64H_EP_A2A_PREFILL", "1") != "0"
-    fuse_qkr = True   # decode-sized steps: QK norm / RoPE / cache write inside the qkv GEMM
+    fuse_qkr = os.environ.get("I64H_FUSE_QKR", "1") != "0"   # decode-sized steps: QK norm / RoPE / cache write inside the qkv GEMM
     # decode attention: at most this many splits per row.  The row's last-arriving workgroup merges the splits, and in-kernel stamps
     # (tools/attn_stamps.py) put that merge at 4-6 k cycles up to 8 splits but 17 k at 16 and 34 k at 32 (the partial rows come
     # back through cache-bypassing 8-byte loads), more than the shorter token loops of the extra splits save: batch 16 x 2048
