@@ -148,3 +148,34 @@ def test_decode_gemm_tiles_of_32_and_64_rows_give_the_bits_of_16_row_tiles(dev, 
         ops.call("i64h_set_skinny_tall", 1)
     assert torch.equal(outs[0][0], outs[1][0]) and outs[0][0].abs().sum() > 0
     assert all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
+
+
+@pytest.mark.parametrize("rows,K,N,epi,groups", [(2048, 1024, 1024, 0, 1), (1100, 1792, 1024, 0, 1), (2048, 1024, 1792, 1, 1), (3000, 448, 1024, 0, 8)])
+def test_tiled_gemm_on_64_and_128_row_tiles_gives_the_same_bits(dev, rows, K, N, epi, groups):
+    """Prefill-sized int8 launches that would fill fewer than 1.5 workgroup slots per CU with 128 x 128 tiles take 64 x 64 tiles:
+    same outputs, same statistics."""
+    from vllm_i64_amd import ops
+    g = torch.Generator().manual_seed(rows + K + N)
+    a = torch.randint(-64, 64, (rows, K), dtype=torch.int8, generator=g).to(dev)
+    rs = (torch.rand(rows, generator=g) * 1e-2 + 1e-3).to(dev)
+    w = torch.randint(-128, 128, (groups, N, K), dtype=torch.int8, generator=g).to(dev)
+    ws = (torch.rand(groups, generator=g) * 1e-2 + 1e-3).to(dev)
+    off = slot = None
+    if groups > 1:
+        cnt = torch.tensor([700, 0, 333, 290, 560, 417, 33, rows - 2333])
+        off = torch.cat([torch.zeros(1, dtype=torch.long), cnt.cumsum(0)]).to(torch.int32).to(dev)
+    if epi:
+        slot = (torch.arange(rows) % 3).to(torch.int32).to(dev)
+    stats = ops.stats_alloc(4, dev)
+    outs = []
+    try:
+        for tiles in (0, 1 << 30):     # 128 x 128 tiles whatever the count | 64 x 64 tiles whatever the count
+            ops.call("i64h_set_gemm_big_tile_min", tiles)
+            ops.stats_reset(stats)
+            out = ops.gemm_i8(a, rs, w, ws, group_offsets=off, epilogue=epi, row_slot=slot, slot_base=1, stats=stats if epi else None)
+            torch.cuda.synchronize()
+            outs.append((out.cpu(), [t.cpu() for t in ops.qparams(stats, 4)]))
+    finally:
+        ops.call("i64h_set_gemm_big_tile_min", 384)
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][0].abs().sum() > 0
+    assert all(torch.equal(x, y) for x, y in zip(outs[0][1], outs[1][1]))

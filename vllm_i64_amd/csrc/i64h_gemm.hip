@@ -1567,6 +1567,9 @@ static int launch_skinny_nw(const i64h_gemm_desc* a, const i64h_gemm_desc* b, hi
 }
 
 static int g_stage64 = 1;  // tuning knob: 0 = 128-byte stages (two workgroups per CU) for every prefill-sized problem
+// launches with fewer 128 x 128 tiles than this (1.5 per CU) take 64 x 64 tiles (i64h_set_gemm_big_tile_min).  Measured, prefill in
+// chunks of 1100 / 2048 rows: 188 -> 225 / 264 -> 287 k tokens/s; same results bit for bit
+static int g_big_tile_min = 384;
 
 #define SK_MAX_ROWS 1024  // beyond this the operand is worth quantizing once instead of once per column tile
 #define SK_MAX_K 8192  // 16 operand rows x (K + 32) bytes of LDS: 129 KB at this K
@@ -1635,6 +1638,12 @@ int i64h_set_skinny_helpers(int32_t on) {
 // tuning knob: 1 (default) = decode-sized launches of more than 256 (512) rows per group take 32- (64-) row tiles; 0 = 16-row tiles always
 int i64h_set_skinny_tall(int32_t on) {
     g_skinny_tall = on ? 1 : 0;
+    return 0;
+}
+
+int i64h_set_gemm_big_tile_min(int32_t tiles) {
+    I64H_CHECK_ARG(tiles >= 0, "set_gemm_big_tile_min: bad value %d", tiles);
+    g_big_tile_min = tiles;
     return 0;
 }
 
@@ -1716,7 +1725,9 @@ int i64h_gemm_i8_pair(const i64h_gemm_desc* a, const i64h_gemm_desc* b, void* st
         return a->epilogue == EPI_STORE ? launch_rs<EPI_STORE, 2>(a, b, st) : launch_rs<EPI_SWIGLU, 2>(a, b, st);
     }
     const int64_t rows = a->M_total / a->num_groups;
-    const bool big = !a->a_fp32 && rows >= 256;  // fp32 operands are meant for small M (quantized per workgroup)
+    // 128 x 128 tiles need enough of them to fill the chip: below g_big_tile_min tiles over the launch, 64 x 64 tiles (four times as many)
+    const int64_t tiles128 = nblocks_of<128, 128>(a) + (b ? nblocks_of<128, 128>(b) : 0);
+    const bool big = !a->a_fp32 && rows >= 256 && tiles128 >= g_big_tile_min;  // fp32 operands are meant for small M (quantized per workgroup)
     // short K: a tile's K loop is a handful of steps, so occupancy (4 workgroups per CU) hides the per-tile prologue and
     // epilogue; long K: 128-byte stages, fewer barriers
     const bool s64 = big && g_stage64 && a->K <= 2048;
