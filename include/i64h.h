@@ -220,6 +220,7 @@ int i64h_set_skinny_waves(int32_t waves); /* tuning knob of the decode-sized (we
 int i64h_set_skinny_helpers(int32_t on);  /* tuning knob of the same kernel: 1 (default) = its four-wave workgroups get four more waves that only request and quantize operand rows */
 int i64h_set_skinny_tall(int32_t on); /* tuning knob: 1 (default) = decode-sized int8 launches of more than 256 (512) operand rows per group take 32- (64-) row tiles - the weights stream once per tile; same results bit for bit; 0 = 16-row tiles always */
 int i64h_set_gemm_big_tile_min(int32_t tiles); /* tuning knob of the tiled int8 kernel: launches with fewer 128 x 128 tiles than this (default 384 = 1.5 per CU) take 64 x 64 tiles (same results bit for bit) */
+int i64h_set_gemm_os_part_units(int32_t units); /* tuning knob of the operand-stationary kernels: when a launch has few row tiles its columns are dealt to several workgroups; a part holds at least this many units of 32 columns (default 8); same results */
 /* C[M, N] = A[a_rows ? a_rows[m] : m, :K] . B[N, K]^T in fp32 (tied lm_head, vllm_i64/models/complexity_deep/model.py:436-437). */
 int i64h_gemm_f32(const float* A, const int32_t* a_rows, const float* B, float* C, int64_t M, int32_t N, int32_t K, void* stream);
 /* The tied fp32 lm_head (F.linear(hidden.float(), embed.weight.float()), vllm_i64/models/complexity_deep/model.py:436-437) on the

@@ -90,6 +90,7 @@ SIGNATURES: Dict[str, str] = {
     "i64h_set_skinny_helpers": "i",
     "i64h_set_skinny_tall": "i",
     "i64h_set_gemm_big_tile_min": "i",
+    "i64h_set_gemm_os_part_units": "i",
     "i64h_debug_set_stamps": "pl",
     "i64h_set_gemm_stage64": "i",
     "i64h_set_gemm_rowstream": "i",

@@ -566,6 +566,9 @@ static unsigned long long* g_os_stamps = nullptr;  // diagnostics (i64h_debug_se
 static int g_os_rotk = 0;  // tuning knob: per-workgroup rotation of the K order (0 = off)
 
 static int g_os_tall = 1;  // tuning knob: 0 = tiles of 128 rows only
+// fewest units (pairs of fragment columns) of a column part (i64h_set_gemm_os_part_units): one per wave of the eight-wave form.
+// Measured, prefill in 2048 / 4096-row chunks at 16 | 8 | 4: 286 | 301 | 308 and 381 | 399 | 395 k tokens/s
+static int g_os_part_units = 8;
 static size_t os_lds_bytes(int K, int mfr) { return (size_t)(K / 64) * mfr * 1024 + mfr * 128 + 2 * I64H_STAT_TAB * 4 + 16 * 16 + 1024; }  // image, row arrays, table, per-wave words, prefetch sink
 
 template <int EPI, int DB, int NW, int WMAX, bool F8 = false>
@@ -604,6 +607,12 @@ int i64h_set_gemm_os(int32_t workgroups, int32_t depth) {
     I64H_CHECK_ARG(workgroups >= 1 && (depth == 2 || depth == 3), "set_gemm_os: bad values %d, %d", workgroups, depth);
     g_os_grid = workgroups;
     g_os_depth = depth;
+    return 0;
+}
+
+int i64h_set_gemm_os_part_units(int32_t units) {
+    I64H_CHECK_ARG(units >= 1, "set_gemm_os_part_units: bad value %d", units);
+    g_os_part_units = units;
     return 0;
 }
 
@@ -666,7 +675,7 @@ int i64h_gemm_fp8_frags(const uint8_t* A, const float* a_scale, const int32_t* a
     int parts = 1;
     if (m_tiles < (g_os_grid * 3) / 4) {
         parts = (g_os_grid + m_tiles - 1) / m_tiles;
-        const int maxp = units / 16 > 0 ? units / 16 : 1;
+        const int maxp = units / g_os_part_units > 0 ? units / g_os_part_units : 1;
         if (parts > maxp) parts = maxp;
     }
     const int n_items = m_tiles * parts;
@@ -742,7 +751,7 @@ int i64h_gemm_i8_frags(const int8_t* A, const float* row_scale, const int8_t* B_
     int parts = 1;
     if (m_tiles < (g_os_grid * 3) / 4) {
         parts = (g_os_grid + m_tiles - 1) / m_tiles;
-        const int maxp = units / 16 > 0 ? units / 16 : 1;  // at least two units per wave
+        const int maxp = units / g_os_part_units > 0 ? units / g_os_part_units : 1;
         if (parts > maxp) parts = maxp;
     }
     const int n_items = m_tiles * parts;

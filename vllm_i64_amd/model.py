@@ -273,8 +273,9 @@ class I64MoEModel:
         self.stats = ops.stats_alloc(self.spl * cfg.num_layers + 1, dev)
         self._bufs: Dict[tuple, _Buffers] = {}
         self._pinned: set = set()
-        if os.environ.get("I64H_BIG_TILE_MIN"):   # measurements
-            ops.call("i64h_set_gemm_big_tile_min", int(os.environ["I64H_BIG_TILE_MIN"]))
+        for env, setter in (("I64H_BIG_TILE_MIN", "i64h_set_gemm_big_tile_min"), ("I64H_OS_PART_UNITS", "i64h_set_gemm_os_part_units")):
+            if os.environ.get(env):   # measurements
+                ops.call(setter, int(os.environ[env]))
         self.dec_sync = ops.decode_sync_alloc(dev)
         self._resident_used = False   # a launch with a grid barrier was issued since the last check_sync
 
