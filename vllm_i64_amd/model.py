@@ -724,7 +724,11 @@ class I64MoEModel:
         def few_row_splits(rows: int, one_per_seq: bool) -> int:
             sp = 1
             if max_ctx_hint >= 256 and rows <= self.ATTN_TILE_ROWS:
-                sp = max(1, min(self.attn_max_splits, self.attn_target_wgs // rows, max_ctx_hint // 64))
+                # long contexts on a few rows: the token loop outweighs the merge of more partial results (1 row x 30000 tokens 42.1 us
+                # at 8 splits, 17.7 at 32; 1 row x 8000 tokens 15.3 -> 10.9; 4 rows x 4096 tokens 11.8 at 8, 12.2 at 16:
+                # tools/attn_longctx.py)
+                cap = self.attn_max_splits if max_ctx_hint < 6144 else max(self.attn_max_splits, 32)
+                sp = max(1, min(cap, self.attn_target_wgs // rows, max_ctx_hint // 64))
             if one_per_seq and rows >= self.ATTN_TILE_ROWS:
                 sp = max(sp, 2)   # an upper bound: the library launches fewer (one) when the rows alone fill the chip
             elif heads_spread and max_ctx_hint > 64 and rows < self.ATTN_TILE_ROWS:
