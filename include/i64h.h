@@ -541,7 +541,7 @@ int i64h_advance(int32_t* positions, int32_t* ctx_len, int64_t n, void* stream);
 int64_t i64h_paged_attn_workspace_floats(int64_t rows, int32_t num_heads, int32_t head_dim, int32_t splits);
 int i64h_paged_attn_workspace_init(float* workspace, void* stream);
 int i64h_debug_set_attn_stamps(void* buffer); /* diagnostics: 8 uint64 of s_memtime phase stamps per workgroup of the decode attention kernel; NULL = off */
-int i64h_set_decode_attn_head_split(int32_t mode); /* tuning: 1 (default) = split decode launches at head_dim 64, 4 kv heads of 4 q heads, 16/32-bit caches run one kv head per workgroup, the context split so that rows x 4 x splits is about one workgroup per CU (at most the caller's splits); 0 = never (every workgroup reads all kv heads of its tokens); -k = that form with k context splits (measurements) */
+int i64h_set_decode_attn_head_split(int32_t mode); /* tuning: 1 (default) = split decode launches at head_dim 64, 4 kv heads of 4 q heads, 16/32-bit caches (8-bit caches: launches of at most 32 rows) run one kv head per workgroup, the context split so that rows x 4 x splits is about one workgroup per CU (at most the caller's splits); 0 = never (every workgroup reads all kv heads of its tokens); -k = that form with k context splits (measurements) */
 int i64h_set_decode_attn_deep_rows(int32_t rows); /* tuning: split decode launches of at most this many rows (head_dim 64) keep the K/V rows of three iterations in flight per wave (default 32; 0 = never); same results bit for bit */
 int i64h_set_prefill_attn(int32_t mode); /* tuning / test knob of the many-row attention: 0 = row-per-workgroup kernel, 1 = matrix-core tile kernel (default; bf16 caches run the three-term bf16 form), 2 = f32 matrix cores for every cache dtype */
 int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, int32_t kv_dtype, const int32_t* block_table,

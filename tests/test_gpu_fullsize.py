@@ -276,7 +276,7 @@ def test_steps_of_many_decode_rows_and_mixed_steps_launch_attention_per_kind_of_
     fine = [1, 17] * 40                                        # kinds alternate 80 times: one launch, the form by the majority
     assert model.attention_plan(B, sum(fine), 64, False, fine) == [(0, sum(fine), 1)]
     assert model.attention_plan(B, 7, 129, True, None) == [(0, 7, 2)]           # short contexts: splittable, for the kv heads' sake
-    assert model.attention_plan(B, 7, 129, True, None, torch.float8_e4m3fn) == [(0, 7, 1)] and model.attention_plan(B, 7, 64, True, None) == [(0, 7, 1)]
+    assert model.attention_plan(B, 7, 129, True, None, torch.float8_e4m3fn) == [(0, 7, 2)] and model.attention_plan(B, 40, 129, True, None, torch.float8_e4m3fn) == [(0, 40, 1)] and model.attention_plan(B, 7, 64, True, None) == [(0, 7, 1)]
     st, st_ref = ops.stats_alloc(3, dev), ops.stats_alloc(3, dev)
     ops.stats_reset(st)
     ops.stats_reset(st_ref)

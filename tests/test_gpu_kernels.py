@@ -813,7 +813,8 @@ def test_final_norm_writes_the_lm_head_planes(dev, n, H):
 
 
 @pytest.mark.parametrize("rows_,splits,kv_dtype", [(1, 8, torch.bfloat16), (5, 8, torch.float32), (17, 8, torch.bfloat16), (33, 2, torch.float16),
-                                                   (70, 3, torch.bfloat16), (130, 2, torch.float32)])
+                                                   (70, 3, torch.bfloat16), (130, 2, torch.float32), (3, 8, torch.float8_e4m3fn),
+                                                   (20, 4, torch.float8_e5m2), (32, 2, torch.float8_e4m3fn)])
 def test_decode_attention_one_kv_head_per_workgroup_against_all_heads_per_workgroup(dev, rows_, splits, kv_dtype):
     """The two forms of the split decode launch at head_dim 64 / 4 kv heads of 4 q heads - one kv head per workgroup (context splits chosen by
     the library from the row count) and all kv heads per workgroup - over random contexts (one empty, one of a single token), rows in

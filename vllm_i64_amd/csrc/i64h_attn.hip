@@ -1308,6 +1308,9 @@ static int dispatch_gs(int gs, int kv_dtype, const float* q, const void* kc, con
 
 #define PF_MIN_ROWS 256      // from this many rows on, the 16-row-tile matrix-core kernel is used (splits == 1, head_dim 64)
 static unsigned long long* g_attn_stamps = nullptr;  // diagnostics, see i64h_debug_set_attn_stamps
+#define F8_HEAD_SPLIT_ROWS 32  // 8-bit caches: one kv head per workgroup up to this many rows (its 64-byte row pieces stream worse once the rows
+                              // alone fill the chip.  e4m3, 2048 tokens, one kv head per workgroup | all kv heads: 1 row 8.4 | 15.8 us, 16 rows
+                              // 12.0 | 16.9, 32 rows 16.9 | 17.6, 48 rows 23.9 | 21.9, 256 rows x 1024 tokens 52.9 | 40.6)
 static int g_decode_head_split = 1;  // 0: never; 1: decode launches of the shapes that have the form run one kv head per workgroup; -k: with k context splits (measurements)
 static int g_decode_deep_rows = 32;  // split launches of at most this many rows keep the K/V rows of three iterations in flight per wave; 0 = never
 static int g_prefill_mfma = 1;  // tuning / test knob: 0 = always the row-per-workgroup kernel, 1 = matrix cores (bf16 caches: three-term bf16 form), 2 = f32 matrix cores for every cache dtype
@@ -1420,11 +1423,11 @@ int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, in
         else AH_L(HD_, KVH_, GS_, CH_, NW_, T, false);                                 \
     } while (0)
     bool head_split = false;
-    // head_dim 64, 4 kv heads of 4 q heads, 16- and 32-bit caches: one kv head per workgroup (see the kernel's comment), context
+    // head_dim 64, 4 kv heads of 4 q heads, 16- and 32-bit caches (8-bit caches: launches of few rows): one kv head per workgroup (see the kernel's comment), context
     // splits so that rows x 4 x splits is about one workgroup per CU.  Measured against the split launch over all heads (bf16,
     // context 2048, graph replays over rotating caches): batch 1: 16.1 -> 10.0 us, 8: 17.0 -> 12.3, 16: 18.1 -> 14.3, 32: 21.8 -> 20.5,
     // 64: 33.9 -> 31.4, 96: 46.4 -> 45.1, 128: 53.6 -> 54.5
-    if (g_decode_head_split != 0 && splits > 1 && bp2 && head_dim == 64 && num_kv_heads == 4 && gs == 4 && kv_dtype <= 2 &&
+    if (g_decode_head_split != 0 && splits > 1 && bp2 && head_dim == 64 && num_kv_heads == 4 && gs == 4 && (kv_dtype <= 2 || rows <= F8_HEAD_SPLIT_ROWS) &&
         rows * 4 <= ATTN_ARRIVALS) {
         int hs = g_decode_head_split < 0 ? -g_decode_head_split : (int)(64 / rows);
         hs = hs < 1 ? 1 : (hs > splits ? splits : hs);  // the caller sized the workspace for `splits`
@@ -1435,7 +1438,9 @@ int i64h_paged_attn(const float* q, const void* k_cache, const void* v_cache, in
                        stat_slot, g_attn_stamps)
         if (kv_dtype == 0) AHH(float);
         else if (kv_dtype == 1) AHH(__half);
-        else AHH(__hip_bfloat16);
+        else if (kv_dtype == 2) AHH(__hip_bfloat16);
+        else if (kv_dtype == 3) AHH(F8E4);
+        else AHH(F8E5);
 #undef AHH
         done = head_split = true;
         rc = 0;

@@ -718,8 +718,8 @@ class I64MoEModel:
         tokens_per_seq (host list, rows in sequence order) a mixed step becomes one launch per maximal run of either kind."""
         cfg = self.cfg
         # the library's one-kv-head-per-workgroup form: only launches that may be split take it
-        heads_spread = (cfg.head_dim == 64 and cfg.num_kv_heads == 4 and cfg.num_heads == 16
-                        and (kv_dtype if kv_dtype is not None else self.kv.k[0].dtype) in (torch.float32, torch.float16, torch.bfloat16))
+        heads_shape = cfg.head_dim == 64 and cfg.num_kv_heads == 4 and cfg.num_heads == 16
+        wide_cache = (kv_dtype if kv_dtype is not None else self.kv.k[0].dtype) in (torch.float32, torch.float16, torch.bfloat16)
 
         def few_row_splits(rows: int, one_per_seq: bool) -> int:
             sp = 1
@@ -731,7 +731,7 @@ class I64MoEModel:
                 sp = max(1, min(cap, self.attn_target_wgs // rows, max_ctx_hint // 64))
             if one_per_seq and rows >= self.ATTN_TILE_ROWS:
                 sp = max(sp, 2)   # an upper bound: the library launches fewer (one) when the rows alone fill the chip
-            elif heads_spread and max_ctx_hint > 64 and rows < self.ATTN_TILE_ROWS:
+            elif heads_shape and (wide_cache or rows <= 32) and max_ctx_hint > 64 and rows < self.ATTN_TILE_ROWS:   # (8-bit caches: the library takes that form up to 32 rows)
                 # also an upper bound, for the form that spreads the kv heads of a row over workgroups: 200 rows of 1024 tokens 75 us
                 # with all kv heads in one workgroup per row, 52 us spread; 7 rows of 129 tokens 10.4 against 6.8 us, 64 rows of 250
                 # tokens 16.2 against 7.2 us
