@@ -36,9 +36,13 @@ class Cache:
         return new
 
 
-ocfg = M.named_config("trhash500m-synth")
+ocfg = M.named_config(os.environ.get("ENGINE_LOOP_CONFIG", "trhash500m-synth"))   # also: trmoe306-synth, dense306-synth
+if ocfg.max_pos < P + 4 * S + STEPS + 64:
+    import dataclasses
+    ocfg = dataclasses.replace(ocfg, max_pos=P + 4 * S + STEPS + 64)
 w = M.make_weights(ocfg, seed=0)
-model = I64MoEModel(ModelConfig.from_any(ocfg), w, device=dev, kv_dtype=torch.bfloat16, max_seqs=1, num_kv_blocks=2)
+model = I64MoEModel(ModelConfig.from_any(ocfg), w, device=dev, kv_dtype=torch.bfloat16, max_seqs=1, num_kv_blocks=2,
+                    quant=os.environ.get("ENGINE_LOOP_QUANT", "int8"))   # or fp8
 em = EngineModel(model)
 blocks_per = (P + S * ((P + CHUNK - 1) // CHUNK) + STEPS + 8 + 32) // 16 + 1   # the first sequences decode while the later ones prefill
 cache = Cache(model.cfg, S * blocks_per, S, blocks_per)
