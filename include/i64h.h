@@ -218,7 +218,7 @@ int64_t i64h_debug_stamp_cursor(void);
 int i64h_debug_set_stamps(void* buffer, int64_t capacity_workgroups); /* diagnostics: 8 uint64 per workgroup of s_memtime phase stamps from the decode-sized kernel, launches appended; NULL = off */
 int i64h_set_skinny_waves(int32_t waves); /* tuning knob of the decode-sized (weight-streaming) kernel: 4, 8, 16 or 0 = default */
 int i64h_set_skinny_helpers(int32_t on);  /* tuning knob of the same kernel: 1 (default) = its four-wave workgroups get four more waves that only request and quantize operand rows */
-int i64h_set_skinny_tall(int32_t on); /* tuning knob: 1 (default) = decode-sized int8 launches of more than 256 (512) operand rows per group take 32- (64-) row tiles - the weights stream once per tile; same results bit for bit; 0 = 16-row tiles always */
+int i64h_set_skinny_tall(int32_t on); /* tuning knob: 1 (default) = decode-sized int8 launches of more than 192 (512) operand rows per group take 32- (64-) row tiles - the weights stream once per tile; same results bit for bit; 0 = 16-row tiles always */
 int i64h_set_gemm_big_tile_min(int32_t tiles); /* tuning knob of the tiled int8 kernel: launches with fewer 128 x 128 tiles than this (default 384 = 1.5 per CU) take 64 x 64 tiles (same results bit for bit) */
 int i64h_set_gemm_os_part_units(int32_t units); /* tuning knob of the operand-stationary kernels: when a launch has few row tiles its columns are dealt to several workgroups; a part holds at least this many units of 32 columns (default 8); same results */
 /* C[M, N] = A[a_rows ? a_rows[m] : m, :K] . B[N, K]^T in fp32 (tied lm_head, vllm_i64/models/complexity_deep/model.py:436-437). */

@@ -103,6 +103,7 @@ def test_fused_qkv_launch_with_and_without_helper_waves(dev):
 
 @pytest.mark.parametrize("rows,K,N,epi,groups,packed", [
     (300, 1024, 1024, 0, 1, True),     # 32-row tiles, ragged last tile (300 = 9 x 32 + 12)
+    (193, 1024, 896, 1, 1, True),      # the first row count on 32-row tiles
     (543, 1024, 3584, 1, 1, True),     # 64-row tiles: a 512-token chunk + 31 decode rows, SwiGLU + statistics
     (600, 1792, 1024, 0, 1, True),     # 64-row tiles, two batches of K steps
     (1024, 1024, 1536, 0, 1, False),   # the launcher's row limit, row-major weights
@@ -111,7 +112,7 @@ def test_fused_qkv_launch_with_and_without_helper_waves(dev):
     (1000, 448, 1024, 0, 3, True),     # grouped down projection, K too short for the partial sums
 ])
 def test_decode_gemm_tiles_of_32_and_64_rows_give_the_bits_of_16_row_tiles(dev, rows, K, N, epi, groups, packed):
-    """Launches of more than 256 (512) operand rows per group take 32- (64-) row tiles: every output and every statistics word is
+    """Launches of more than 192 (512) operand rows per group take 32- (64-) row tiles: every output and every statistics word is
     the one the 16-row tiles give."""
     from vllm_i64_amd import ops
     g = torch.Generator().manual_seed(rows * 3 + K + N)

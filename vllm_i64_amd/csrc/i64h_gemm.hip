@@ -1538,7 +1538,8 @@ static int g_skinny_tall = 1;  // tuning knob: 0 = 16-row tiles for every decode
 // Rows of the launch's largest call per group -> tile height.  A tile streams its column slice of the weights once and quantizes
 // its operand rows once per column tile, so taller tiles divide both; below a few hundred rows they leave CUs idle instead.
 // Measured (ms per decode step of the headline model, 16 | 32 | 64 rows): 64 sequences 1.87 | 2.11 | 2.53, 300 sequences
-// 4.17 | 3.80 | 4.18, 512 sequences 6.08 | 5.78 | 5.84, a 512-token chunk + 31 decode rows 7.36 | 6.14 | 5.83.
+// 4.17 | 3.80 | 4.18, 512 sequences 6.08 | 5.78 | 5.84, a 512-token chunk + 31 decode rows 7.36 | 6.14 | 5.83; 32-row tiles beyond
+// 256 | 128 rows: 160 sequences 3.33 | 3.48, 200 sequences 3.21 | 3.16, 256 sequences 4.76 | 4.54: hence 192.
 static int skinny_tile_rows(const i64h_gemm_desc* a, const i64h_gemm_desc* b) {
     if (!g_skinny_tall || !g_skinny_helpers) return SK_BM;
     int64_t m = a->M_total / (a->group_offsets ? a->num_groups : 1);
@@ -1547,7 +1548,8 @@ static int skinny_tile_rows(const i64h_gemm_desc* a, const i64h_gemm_desc* b) {
         m = mb > m ? mb : m;
     }
     const int kmax = b && b->K > a->K ? b->K : a->K;
-    int bm = m > 512 ? 64 : m > 256 ? 32 : SK_BM;
+    const int t32 = g_skinny_tall > 1 ? g_skinny_tall : 192;   // (a knob value above 1: the row count beyond which 32-row tiles are taken)
+    int bm = m > 512 ? 64 : m > t32 ? 32 : SK_BM;
     while (bm > SK_BM && (size_t)bm * (kmax + 32) + 16 + 3 * bm * 4 > 160 * 1024) bm >>= 1;  // the tile's rows stay in LDS for the whole K
     return bm;
 }
@@ -1635,9 +1637,10 @@ int i64h_set_skinny_helpers(int32_t on) {
     return 0;
 }
 
-// tuning knob: 1 (default) = decode-sized launches of more than 256 (512) rows per group take 32- (64-) row tiles; 0 = 16-row tiles always
+// tuning knob: 1 (default) = decode-sized launches of more than 192 (512) rows per group take 32- (64-) row tiles; 0 = 16-row tiles
+// always; a value above 1 = that row count instead of 192
 int i64h_set_skinny_tall(int32_t on) {
-    g_skinny_tall = on ? 1 : 0;
+    g_skinny_tall = on < 0 ? 0 : on;
     return 0;
 }
 

@@ -273,7 +273,8 @@ class I64MoEModel:
         self.stats = ops.stats_alloc(self.spl * cfg.num_layers + 1, dev)
         self._bufs: Dict[tuple, _Buffers] = {}
         self._pinned: set = set()
-        for env, setter in (("I64H_BIG_TILE_MIN", "i64h_set_gemm_big_tile_min"), ("I64H_OS_PART_UNITS", "i64h_set_gemm_os_part_units")):
+        for env, setter in (("I64H_BIG_TILE_MIN", "i64h_set_gemm_big_tile_min"), ("I64H_OS_PART_UNITS", "i64h_set_gemm_os_part_units"),
+                            ("I64H_SKINNY_TALL", "i64h_set_skinny_tall")):
             if os.environ.get(env):   # measurements
                 ops.call(setter, int(os.environ[env]))
         self.dec_sync = ops.decode_sync_alloc(dev)
