@@ -121,3 +121,14 @@ def test_baseline_config_1_dense_batch1_greedy_on_the_cpu_engine():
     assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1])          # deterministic
     assert torch.isfinite(runs[0][1]).all()
     assert runs[2][0] == runs[0][0] and torch.equal(runs[2][1], runs[0][1])          # restatement == torch's kernels, bit for bit
+
+
+def test_engine_adapter_per_sequence_position_maxima():
+    """Host logic of the engine adapter: the highest position of each sequence of a step (what decides the blocks to allocate and
+    the new seq_lens), with sequences that contribute no token and positions that are not ascending inside a sequence."""
+    from vllm_i64_amd.engine_adapter import max_positions
+    pos = torch.tensor([5, 6, 7, 40, 2, 9, 3, 11])
+    assert max_positions(pos, [3, 1, 0, 4]) == [7, 40, -1, 11]
+    assert max_positions(pos, [0, 8, 0]) == [-1, 40, -1]
+    assert max_positions(pos[:0], []) == [] and max_positions(pos[:0], [0, 0]) == [-1, -1]
+    assert max_positions(pos[:3], [0, 0, 3]) == [-1, -1, 7] and max_positions(pos[:1], [1]) == [5]

@@ -21,6 +21,20 @@ import torch
 from .model import I64MoEModel
 
 
+def max_positions(positions: torch.Tensor, tokens_per_seq: Sequence[int]) -> List[int]:
+    """Highest position of every sequence of a step (-1: the sequence has no token in it), in one pass over the host copy of the
+    positions; rows are in sequence order, tokens_per_seq[i] of them belong to sequence i."""
+    tps = np.asarray(list(tokens_per_seq), dtype=np.int64)
+    out = [-1] * len(tps)
+    live = np.nonzero(tps > 0)[0]
+    if live.size:
+        starts = np.concatenate(([0], np.cumsum(tps)[:-1]))
+        # sequences without tokens share their start with the next one, so the starts of the live ones bound their runs
+        for i, m in zip(live.tolist(), np.maximum.reduceat(positions.numpy(), starts[live]).tolist()):
+            out[i] = int(m)
+    return out
+
+
 class _CacheView:
     """The three things the kernels need from an engine cache."""
 
@@ -86,14 +100,7 @@ class EngineModel:
         pos_h = positions.to("cpu", torch.int64)
         pos = pos_h.to(device=dev, dtype=torch.int32).contiguous()
         slots = torch.repeat_interleave(torch.tensor([int(s) for s in seq_ids], dtype=torch.int32), torch.tensor(tps)).to(dev)
-        # highest position of every sequence in the step (-1: no token), in one pass over the host copy of the positions
-        pos_np, tps_np = pos_h.numpy(), np.asarray(tps, dtype=np.int64)
-        starts = np.concatenate(([0], np.cumsum(tps_np)[:-1])) if len(tps) else np.zeros(0, dtype=np.int64)
-        max_pos = [-1] * len(tps)
-        live = np.nonzero(tps_np > 0)[0]
-        if n > 0 and live.size:
-            for i, m in zip(live.tolist(), np.maximum.reduceat(pos_np, starts[live]).tolist()):
-                max_pos[i] = int(m)
+        max_pos = max_positions(pos_h, tps)
         self._check_cache(kv_cache)
         # the kernels index the rotary table by position and the block table by position / block without bounds: a position
         # beyond either would read another sequence's table row and write K/V into its blocks
