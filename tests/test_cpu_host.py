@@ -132,3 +132,17 @@ def test_engine_adapter_per_sequence_position_maxima():
     assert max_positions(pos, [0, 8, 0]) == [-1, 40, -1]
     assert max_positions(pos[:0], []) == [] and max_positions(pos[:0], [0, 0]) == [-1, -1]
     assert max_positions(pos[:3], [0, 0, 3]) == [-1, -1, 7] and max_positions(pos[:1], [1]) == [5]
+
+
+def test_attention_segments_of_a_step():
+    """Host logic of the runner's attention plan: decode rows and prefill chunks of a mixed engine step become runs of a kind."""
+    from vllm_i64_amd.model import attention_segments
+    assert attention_segments([1] * 5, 5, 4) == [(0, 5, True)]
+    assert attention_segments([512], 512, 4) == [(0, 512, False)]
+    assert attention_segments([512, 1, 1, 0, 1], 515, 4) == [(0, 512, False), (512, 515, True)]
+    assert attention_segments([1, 1, 20, 30, 1, 0, 7], 60, 4) == [(0, 2, True), (2, 52, False), (52, 53, True), (53, 60, False)]
+    assert attention_segments([1, 17] * 40, 720, 4) == [(0, 720, False)]        # 80 runs: one launch, mostly chunk rows
+    assert attention_segments([1, 1, 1, 2] * 10, 50, 4) == [(0, 50, True)]      # ... mostly decode rows
+    assert attention_segments([], 0, 4) == [] and attention_segments([0, 0], 0, 4) == []
+    with pytest.raises(ValueError):
+        attention_segments([3, 1], 5, 4)

@@ -739,25 +739,10 @@ class I64MoEModel:
                 sp = max(sp, 2)
             return sp
 
-        segs: List[Tuple[int, int, bool]] = []
         if rows_are_slots:
             segs = [(0, n, True)]
         elif tokens_per_seq is not None:
-            row = 0
-            for t in tokens_per_seq:
-                t = int(t)
-                if t <= 0:
-                    continue
-                kind = t == 1
-                if segs and segs[-1][2] == kind:
-                    segs[-1] = (segs[-1][0], row + t, kind)
-                else:
-                    segs.append((row, row + t, kind))
-                row += t
-            assert row == n, "tokens_per_seq does not add up to the rows of the step"
-            if len(segs) > self.ATTN_MAX_SEGMENTS:   # finely interleaved kinds: one launch, the form by the majority of rows
-                dec = sum(b - a for a, b, k in segs if k)
-                segs = [(0, n, 2 * dec >= n)]
+            segs = attention_segments(tokens_per_seq, n, self.ATTN_MAX_SEGMENTS)
         else:
             segs = [(0, n, False)]
         plan = []
@@ -1133,6 +1118,30 @@ class I64MoEModel:
                                          route_weights=cfg.route_weights, routed_scale=self.layers[l]["routed_scale"],
                                          shared_scale=self.layers[l]["shared_scale"], want_normed=False)
         return out
+
+
+def attention_segments(tokens_per_seq: Sequence[int], n: int, max_segments: int) -> List[Tuple[int, int, bool]]:
+    """Rows of a step (in sequence order, tokens_per_seq[i] rows of sequence i) as maximal runs [(first row, end row, one row per
+    sequence?)]: runs of one-token sequences (decode rows) and runs of longer ones (prefill chunks).  More than max_segments runs
+    (finely interleaved kinds) collapse into one, of the kind the majority of the rows has."""
+    segs: List[Tuple[int, int, bool]] = []
+    row = 0
+    for t in tokens_per_seq:
+        t = int(t)
+        if t <= 0:
+            continue
+        kind = t == 1
+        if segs and segs[-1][2] == kind:
+            segs[-1] = (segs[-1][0], row + t, kind)
+        else:
+            segs.append((row, row + t, kind))
+        row += t
+    if row != n:
+        raise ValueError(f"tokens_per_seq adds up to {row} rows, the step has {n}")
+    if len(segs) > max_segments:
+        dec = sum(b - a for a, b, k in segs if k)
+        segs = [(0, n, 2 * dec >= n)]
+    return segs
 
 
 class GreedyDecoder:
