@@ -361,7 +361,7 @@ def main():
             attn_graph = None
             torch.cuda.synchronize()
     evs = []
-    for rep in range(4):
+    for rep in range(10):   # the first two are dropped, the other eight averaged (single replays differ by up to 10 %)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         if attn_graph is not None:
@@ -371,7 +371,7 @@ def main():
         e1.record()
         evs.append((e0, e1))
     torch.cuda.synchronize()
-    attn_ms = sorted(a.elapsed_time(b) / cfg.num_layers for a, b in evs[1:])
+    attn_ms = sorted(a.elapsed_time(b) / cfg.num_layers for a, b in evs[2:])
     attn_ms = sum(attn_ms) / len(attn_ms)
     attn_bytes = B * ctx_now * cfg.num_kv_heads * cfg.head_dim * 2 * kvb  # K and V rows of every cached token, once
     achieved = attn_bytes / (attn_ms * 1e-3) / 1e9
